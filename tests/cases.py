@@ -1,0 +1,102 @@
+"""Deterministic synthetic inputs shared by the golden generator, the CPU tests and the GPU
+parity tests.  Everything is seeded; nothing here reads /root/reference."""
+import numpy as np
+
+SIG = 6.30e-18          # sigma_HI_at_ion_freq (test/*/parameters.yml)
+MINLOGTAU, MAXLOGTAU = -20.0, 4.0
+
+# chemistry constants as derived in pyc2ray/c2ray_base.py:335-347 from parameters.yml
+BH00 = 2.59e-13
+ALBPOW = -0.7
+COLH0 = 1.3e-8 * 0.83 * 1.0 / 13.598 ** 2
+TEMPH0 = 13.598 * 11604.5250061598
+ABU_C = 7.1e-7
+
+
+def tau_table(num_tau):
+    """make_tau_table convention (pyc2ray/radiation/common.py:13-37): tau[0]=0 then log-spaced."""
+    dlog = (MAXLOGTAU - MINLOGTAU) / num_tau
+    tau = np.empty(num_tau + 1)
+    tau[0] = 0.0
+    tau[1:] = 10 ** (MINLOGTAU + np.arange(num_tau) * dlog)
+    return tau, dlog
+
+
+def grey_tables(num_tau=2000):
+    """Closed-form grey-opacity tables: thick = thin = 1e48*exp(-tau).  Any monotone table pins
+    the kernels, since the checker and the kernel receive the same table."""
+    tau, dlog = tau_table(num_tau)
+    t = 1e48 * np.exp(-tau)
+    return t.copy(), t.copy(), dlog
+
+
+def soft_tables(num_tau=2000):
+    """A non-grey-like pair (power-law tail), to make thin != thick."""
+    tau, dlog = tau_table(num_tau)
+    thick = 1e48 * (0.6 * np.exp(-tau) + 0.4 / (1.0 + tau) ** 3)
+    thin = 1e48 * (0.6 * np.exp(-tau) + 1.2 / (1.0 + tau) ** 4)
+    return thin, thick, dlog
+
+
+def grid(N, kind, seed, tau_cell, xlo=1e-4, xhi=0.5):
+    """Return (ndens, xh, dr).  tau_cell = sig * 1e-3 * dr, the optical depth of a mean cell."""
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":
+        nd = np.full((N, N, N), 1e-3)
+        xh = np.full((N, N, N), 2e-4)
+    elif kind == "lognormal":
+        nd = 1e-3 * np.exp(1.2 * rng.normal(size=(N, N, N)) - 0.72)
+        xh = rng.uniform(xlo, xhi, size=(N, N, N))
+    else:
+        raise ValueError(kind)
+    dr = tau_cell / (SIG * 1e-3)
+    return nd, xh, dr
+
+
+def sources(N, ns, seed, flux=1.0):
+    """(3,ns) 1-based positions as in generate_test_sourcefile (sourceutils.py:56-58), equal flux."""
+    rng = np.random.RandomState(seed)
+    pos = 1 + rng.randint(0, N, size=3 * ns)
+    pos = pos.reshape((ns, 3), order="C").T.copy()
+    return pos, np.full(ns, float(flux))
+
+
+def flat_sources(pos1, flux):
+    """format_sources layout (sourceutils.py:30-31): 0-based, xyz-interleaved int32."""
+    return (np.ravel((pos1 - 1).astype("int32"), order="F"), flux.astype("float64"))
+
+
+#: raytracing cases: name -> (N, kind, grid_seed, tau_cell, ns, src_seed, R)
+RT_CASES = {
+    "u16_1src_R4":   (16, "uniform",   0, 0.30, 1, 11, 4.0),
+    "u16_1src_R8":   (16, "uniform",   0, 0.30, 1, 11, 8.0),
+    "u16_7src_Rbox": (16, "uniform",   0, 0.05, 7, 12, 1000.0),
+    "l16_7src_R5.5": (16, "lognormal", 3, 0.08, 7, 13, 5.5),
+    "l17_3src_Rbox": (17, "lognormal", 4, 0.05, 3, 14, 1000.0),
+    "l32_5src_R10":  (32, "lognormal", 5, 0.10, 5, 15, 10.0),
+    "l16_thin":      (16, "lognormal", 6, 1e-9, 3, 16, 1000.0),
+    "l16_thick":     (16, "lognormal", 7, 30.0, 2, 17, 1000.0),
+}
+
+
+def rt_case(name, tables="grey"):
+    N, kind, gseed, tau_cell, ns, sseed, R = RT_CASES[name]
+    nd, xh, dr = grid(N, kind, gseed, tau_cell)
+    pos, flux = sources(N, ns, sseed, flux=3.0)
+    thin, thick, dlog = grey_tables() if tables == "grey" else soft_tables()
+    return dict(N=N, ndens=nd, xh=xh, dr=dr, pos=pos, flux=flux, R=R,
+                thin=thin, thick=thick, dlogtau=dlog, minlogtau=MINLOGTAU, sig=SIG)
+
+
+def chem_case(N, seed, dt=3.15576e13):
+    """Inputs of one global_pass: lognormal density, mixed ionisation, Gamma spanning 0..huge."""
+    rng = np.random.default_rng(seed)
+    nd = 1e-3 * np.exp(1.0 * rng.normal(size=(N, N, N)))
+    temp = 10 ** rng.uniform(3.0, 4.7, size=(N, N, N))
+    xh = 10 ** rng.uniform(-4, -0.01, size=(N, N, N))
+    xh_av = np.clip(xh * rng.uniform(0.5, 1.5, size=(N, N, N)), 1e-10, 1 - 1e-10)
+    phi = 10 ** rng.uniform(-20, -8, size=(N, N, N))
+    phi[rng.uniform(size=(N, N, N)) < 0.2] = 0.0
+    phi[rng.uniform(size=(N, N, N)) < 0.02] = 1e-2     # -> fully ionised cells
+    return dict(dt=dt, ndens=nd, temp=temp, xh=xh, xh_av=xh_av, xh_intermed=xh.copy(), phi_ion=phi,
+                bh00=BH00, albpow=ALBPOW, colh0=COLH0, temph0=TEMPH0, abu_c=ABU_C)
