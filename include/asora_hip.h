@@ -1,0 +1,162 @@
+/*
+ * asora_hip.h -- C-ABI of libasora_hip.so, the MI355X (gfx950) implementation of pyc2ray's
+ * raytracing + chemistry hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers / sizes, and returns 0 on success or
+ * a non-zero error code; asora_last_error() then holds a message.  Nothing throws across the
+ * boundary (the reference throws std::runtime_error through the CPython C-API uncaught,
+ * src/asora/memory.cu:72, src/asora/raytracing.cu:136).
+ *
+ * Section A is the drop-in boundary: one function per method of the reference's two extension
+ * modules, with the reference binding each replaces cited (paths relative to the reference
+ * checkout).  Section B is the device-resident extension the fused evolve loop uses (no
+ * per-iteration PCIe copies).  Section C holds measurement/diagnostic hooks.
+ *
+ * Host buffers are owned by the caller and only read/written during the call.  Device memory
+ * is process-global library state between asora_device_init and asora_device_close
+ * (as in src/asora/memory.cu:20-29).  Not re-entrant, one grid size per process, one GPU per
+ * process (asora_device_init_ex selects it).
+ *
+ * Grid element order: C-order logical [i][j][k], flat index N*N*i + N*j + k
+ * (src/asora/raytracing.cu:30).  Sources: int32 0-based, xyz-interleaved
+ * [x0,y0,z0,x1,...] (pyc2ray/utils/sourceutils.py:30); flux in units of 1e48 photons/s.
+ */
+#ifndef ASORA_HIP_H
+#define ASORA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* A. Drop-in boundary                                                                        */
+/* ------------------------------------------------------------------------------------------ */
+
+/* libasora.device_init(N, num_src_par)            src/asora/python_module.cu:73-82 -> memory.cu:34-80.
+ * num_src_par is accepted for signature compatibility; this build keeps the per-source
+ * column-density scratch in LDS, so no num_src_par*N^3 slab is allocated. */
+int asora_device_init(int N, int num_src_par);
+/* Same, on an explicit device (one process per GPU under torch.distributed / MPI). */
+int asora_device_init_ex(int N, int num_src_par, int device_id);
+
+/* libasora.device_close()                         python_module.cu:87-92 -> memory.cu:119-129 */
+int asora_device_close(void);
+
+/* libasora.density_to_device(ndens_flat, N)       python_module.cu:97-109 -> memory.cu:85-88 */
+int asora_density_to_device(const double *ndens, int N);
+
+/* libasora.photo_table_to_device(thin, thick, NumTau)   python_module.cu:114-128 -> memory.cu:90-98.
+ * NumTau = number of elements of each table. */
+int asora_photo_table_to_device(const double *thin_table, const double *thick_table, int NumTau);
+
+/* libasora.source_data_to_device(pos, flux, NumSrc)     python_module.cu:133-148 -> memory.cu:99-114 */
+int asora_source_data_to_device(const int32_t *pos, const double *flux, int NumSrc);
+
+/* libasora.do_all_sources(R, coldensh_out, sig, dr, ndens, xh_av, phi_ion, NumSrc, m1,
+ *                         minlogtau, dlogtau, NumTau)   python_module.cu:21-68 -> raytracing.cu:79-148.
+ * coldensh_out and ndens are ignored, as in the reference (raytracing.cu:116: the density must
+ * already be on the device).  Uploads xh_av, raytraces, downloads phi_ion (in place). */
+int asora_do_all_sources(double R, double *coldensh_out, double sig, double dr, const double *ndens,
+                         const double *xh_av, double *phi_ion, int NumSrc, int m1,
+                         double minlogtau, double dlogtau, int NumTau);
+
+/* libc2ray.chemistry.global_pass(dt, ndens, temp, xh, xh_av, xh_intermed, phi_ion, bh00, albpow,
+ *                                colh0, temph0, abu_c) -> conv_flag
+ * f2py wrapper of src/c2ray/chemistry.f90:13-48.  Elementwise: all six grids must share one
+ * storage order; xh_av and xh_intermed are updated in place.  Runs on the GPU (uploads the six
+ * grids, runs the fused kernel, downloads two); needs no prior asora_device_init. */
+int c2ray_global_pass(double dt, const double *ndens, const double *temp, const double *xh,
+                      double *xh_av, double *xh_intermed, const double *phi_ion,
+                      double bh00, double albpow, double colh0, double temph0, double abu_c,
+                      int m1, int m2, int m3, int *conv_flag);
+
+/* Message of the last failing call in this thread's process ("" if none). */
+const char *asora_last_error(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* B. Device-resident extension (fused evolve loop; pyc2ray/evolve.py:168-240 restated so that  */
+/*    only three scalars cross PCIe per iteration)                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Grid selectors for asora_grid_to_device / asora_grid_to_host / asora_device_ptr */
+enum {
+    ASORA_GRID_NDENS = 0,       /* hydrogen density                 (memory.cu n_dev)   */
+    ASORA_GRID_XH_AV = 1,       /* time-averaged ionised fraction   (memory.cu x_dev)   */
+    ASORA_GRID_PHI_ION = 2,     /* photo-ionisation rate            (memory.cu phi_dev) */
+    ASORA_GRID_TEMP = 3,        /* temperature                                          */
+    ASORA_GRID_XH = 4,          /* ionised fraction at start of the step                */
+    ASORA_GRID_XH_INTERMED = 5, /* end-of-step ionised fraction                         */
+    ASORA_GRID_COUNT = 6
+};
+
+/* Upload / download one N^3 grid.  order = 'C': buffer is logical [i][j][k] C-contiguous;
+ * order = 'F': buffer is Fortran-contiguous (element (i,j,k) at i + N*j + N*N*k) and is
+ * transposed on the device. */
+int asora_grid_to_device(int which, const double *host, int N, char order);
+int asora_grid_to_host(int which, double *host, int N, char order);
+/* Device-to-device copy between two grids (e.g. xh -> xh_av at the start of a step). */
+int asora_grid_copy(int dst, int src);
+/* Raw device pointer of a grid (for zero-copy views, e.g. an RCCL all-reduce of phi_ion
+ * through torch.distributed).  NULL when not initialised. */
+void *asora_device_ptr(int which);
+
+/* Raytrace all uploaded sources from the device-resident ndens/xh_av into the device-resident
+ * phi_ion (zeroed first).  Same arithmetic as asora_do_all_sources without the PCIe copies.
+ * Sources [src_begin, src_begin+src_count) of the uploaded list are traced. */
+int asora_raytrace_device(double R, double sig, double dr, int src_begin, int src_count,
+                          double minlogtau, double dlogtau, int NumTau);
+
+/* One chemistry pass on the device-resident grids (ndens, temp, xh, xh_av, xh_intermed,
+ * phi_ion): global_pass + the three reductions of pyc2ray/evolve.py:216-217.
+ * Outputs: conv_flag (chemistry.f90:99-104), sum(xh_intermed), sum(1-xh_intermed). */
+int asora_chemistry_device(double dt, double bh00, double albpow, double colh0, double temph0,
+                           double abu_c, int *conv_flag, double *sum_xh1, double *sum_xh0);
+
+/* ------------------------------------------------------------------------------------------ */
+/* C. Options, measurement and diagnostics                                                     */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Behaviour options (asora_set_option).  Defaults follow the CUDA library being replaced. */
+enum {
+    /* 1: sqrt(2)/sqrt(3), 1e-7, 2e30 as the Fortran's single-precision parameters
+     *    (src/c2ray/raytracing.f90:368,608-609, photorates.f90:69) and the thin-cell table
+     *    argument tau_in (photorates.f90:121);  0 (default): CUDA literals and tau_out
+     *    (src/asora/raytracing.cu:15,435,439, rates.cu:7,37). */
+    ASORA_OPT_FORTRAN_CONSTANTS = 0,
+    /* 1: analytic grey rates (GREY_NOTABLES builds, rates.cu:48-64); 0 (default): tables. */
+    ASORA_OPT_GREY_NOTABLES = 1,
+    /* 1: record HIP events around each kernel launch (asora_kernel_time_ms). */
+    ASORA_OPT_TIMING = 2,
+    /* 0: z-faces read/accumulate through the [k][j][i] transposed copies (default 1). */
+    ASORA_OPT_Z_TRANSPOSED = 3,
+    ASORA_OPT_COUNT = 4
+};
+int asora_set_option(int option, int value);
+int asora_get_option(int option);
+
+/* Kernel selectors for asora_kernel_time_ms */
+enum { ASORA_KERNEL_RAYTRACE = 0, ASORA_KERNEL_CHEMISTRY = 1, ASORA_KERNEL_PREP = 2,
+       ASORA_KERNEL_FINISH = 3, ASORA_KERNEL_COUNT = 4 };
+/* Sum of HIP-event durations (ms) and number of launches of a kernel since the last reset,
+ * measured on the library's stream (ASORA_OPT_TIMING must be 1). */
+int asora_kernel_time_ms(int kernel, double *total_ms, long *launches);
+int asora_kernel_time_reset(void);
+/* hipDeviceSynchronize on the library's device. */
+int asora_synchronize(void);
+
+/* Work accounting of the last raytrace: (source,cell) pairs that received a rate
+ * (|d|<=R inside the periodic window: the Gamma-contributing set of raytracing.cu:315), and
+ * (source,cell) column-density evaluations actually performed (incl. octant-boundary planes). */
+int asora_last_raytrace_counts(long long *gamma_cells, long long *evaluated_cells);
+
+/* Outgoing column density of ONE source over the cells its trace covers, written into a host
+ * N^3 grid (zero elsewhere), C-order.  For parity tests of the column density
+ * (the reference keeps it in cdh_dev, src/asora/memory.cu:20, and never downloads it). */
+int asora_debug_coldens(double R, double sig, double dr, int source_index, double *coldens_out, int N);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASORA_HIP_H */

@@ -1,0 +1,93 @@
+"""ctypes binding of pyc2ray_amd/lib/libasora_hip.so (the C-ABI declared in include/asora_hip.h).
+
+This is the only place the shared library is opened.  There is no fallback of any kind: when the
+library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libasora_hip.so")
+
+# grid selectors / options / kernels, as in include/asora_hip.h
+GRID_NDENS, GRID_XH_AV, GRID_PHI_ION, GRID_TEMP, GRID_XH, GRID_XH_INTERMED = range(6)
+OPT_FORTRAN_CONSTANTS, OPT_GREY_NOTABLES, OPT_TIMING, OPT_Z_TRANSPOSED = range(4)
+KERNEL_RAYTRACE, KERNEL_CHEMISTRY, KERNEL_PREP, KERNEL_FINISH = range(4)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+#: every symbol include/asora_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "asora_device_init": (C.c_int, [C.c_int, C.c_int]),
+    "asora_device_init_ex": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "asora_device_close": (C.c_int, []),
+    "asora_density_to_device": (C.c_int, [_dp, C.c_int]),
+    "asora_photo_table_to_device": (C.c_int, [_dp, _dp, C.c_int]),
+    "asora_source_data_to_device": (C.c_int, [_ip, _dp, C.c_int]),
+    "asora_do_all_sources": (C.c_int, [C.c_double, _dp, C.c_double, C.c_double, _dp, _dp, _dp, C.c_int, C.c_int,
+                                       C.c_double, C.c_double, C.c_int]),
+    "c2ray_global_pass": (C.c_int, [C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double,
+                                    C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "asora_last_error": (C.c_char_p, []),
+    "asora_grid_to_device": (C.c_int, [C.c_int, _dp, C.c_int, C.c_char]),
+    "asora_grid_to_host": (C.c_int, [C.c_int, _dp, C.c_int, C.c_char]),
+    "asora_grid_copy": (C.c_int, [C.c_int, C.c_int]),
+    "asora_device_ptr": (C.c_void_p, [C.c_int]),
+    "asora_raytrace_device": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double,
+                                        C.c_double, C.c_int]),
+    "asora_chemistry_device": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                         C.POINTER(C.c_int), _dp, _dp]),
+    "asora_set_option": (C.c_int, [C.c_int, C.c_int]),
+    "asora_get_option": (C.c_int, [C.c_int]),
+    "asora_kernel_time_ms": (C.c_int, [C.c_int, _dp, C.POINTER(C.c_long)]),
+    "asora_kernel_time_reset": (C.c_int, []),
+    "asora_synchronize": (C.c_int, []),
+    "asora_last_raytrace_counts": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "asora_debug_coldens": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int, _dp, C.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Open libasora_hip.so once.  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"pyc2ray_amd: HIP library not found at {LIB_PATH}. Build it with "
+            "`make -C pyc2ray_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no CPU fallback.")
+    # One HIP runtime per process.  torch bundles its own libamdhip64 (same SONAME as /opt/rocm's);
+    # if torch were imported AFTER this library had pulled in /opt/rocm's copy, the process would
+    # hold two runtimes and a device pointer of one would be unknown to the other (RCCL through
+    # torch.distributed on our phi_ion grid).  Importing torch first makes both resolve to one copy.
+    # PYC2RAY_AMD_NO_TORCH=1 skips this for torch-free single-GPU use.
+    if os.environ.get("PYC2RAY_AMD_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:  # pragma: no cover
+            pass
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the header and the build disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().asora_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else 'unknown error'}")
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return a.ctypes.data_as(_ip)

@@ -1,0 +1,450 @@
+// api.hip -- device-state manager and the extern "C" boundary of libasora_hip.so.
+// The reference counterparts are src/asora/memory.cu (state) and
+// src/asora/python_module.cu (CPython wrappers); see include/asora_hip.h for the mapping.
+#include "asora_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace asora {
+
+static State g_state;
+static std::string g_error;
+
+State &state() { return g_state; }
+int fail(int code, const std::string &msg) { g_error = msg; return code; }
+void clear_error() { g_error.clear(); }
+
+KernelTimer::KernelTimer(int w) : which(w), on(g_state.opt[ASORA_OPT_TIMING] != 0 && g_state.ev0 != nullptr)
+{
+    if (on) (void)hipEventRecord(g_state.ev0, g_state.stream);
+}
+KernelTimer::~KernelTimer()
+{
+    if (!on) return;
+    (void)hipEventRecord(g_state.ev1, g_state.stream);
+    (void)hipEventSynchronize(g_state.ev1);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_state.ev0, g_state.ev1) == hipSuccess) {
+        g_state.k_ms[which] += (double)ms;
+        g_state.k_n[which] += 1;
+    }
+}
+
+// stream, events and the chemistry reduction buffers: needed with or without device_init
+static int ensure_runtime()
+{
+    State &st = g_state;
+    if (st.stream) return 0;
+    ASORA_HIP_TRY(hipSetDevice(st.device));
+    hipDeviceProp_t prop;
+    ASORA_HIP_TRY(hipGetDeviceProperties(&prop, st.device));
+    st.cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ASORA_HIP_TRY(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
+    ASORA_HIP_TRY(hipEventCreate(&st.ev0));
+    ASORA_HIP_TRY(hipEventCreate(&st.ev1));
+    st.red_blocks = chemistry_reduction_blocks(st);
+    ASORA_HIP_TRY(hipMalloc(&st.red_partial, sizeof(double) * 3 * st.red_blocks));
+    ASORA_HIP_TRY(hipMalloc(&st.red_final, sizeof(double) * 3));
+    ASORA_HIP_TRY(hipHostMalloc(&st.red_host, sizeof(double) * 3, hipHostMallocDefault));
+    ASORA_HIP_TRY(hipMalloc(&st.counters, sizeof(unsigned long long) * 2));
+    ASORA_HIP_TRY(hipMemset(st.counters, 0, sizeof(unsigned long long) * 2));
+    return 0;
+}
+
+static int release_all()
+{
+    State &st = g_state;
+    auto drop = [](auto *&ptr) { if (ptr) { (void)hipFree(ptr); ptr = nullptr; } };
+    for (int g = 0; g < ASORA_GRID_COUNT; ++g) { drop(st.grid[g]); st.grid_valid[g] = false; }
+    drop(st.nhi); drop(st.nhi_t); drop(st.phi_t); drop(st.staging);
+    drop(st.thin); drop(st.thick); st.table_len = 0;
+    drop(st.src_pos); drop(st.src_flux); st.num_src = 0;
+    drop(st.shell_scratch); st.shell_scratch_bytes = 0;
+    st.init = false; st.N = 0; st.ncell = 0;
+    return 0;
+}
+
+static int require_init(const char *who)
+{
+    if (!g_state.init) return fail(2, std::string(who) + ": device not initialised (call asora_device_init first)");
+    return 0;
+}
+
+static int check_N(const char *who, int N)
+{
+    if (N != g_state.N)
+        return fail(3, std::string(who) + ": mesh size " + std::to_string(N) + " does not match device_init(" +
+                           std::to_string(g_state.N) + ")");
+    return 0;
+}
+
+static int do_raytrace(double R, double sig, double dr, int src_begin, int src_count, double minlogtau,
+                       double dlogtau, int NumTau, double *dump)
+{
+    State &st = g_state;
+    if (!st.grid_valid[ASORA_GRID_NDENS]) return fail(4, "raytrace: density not on device (density_to_device)");
+    if (!st.grid_valid[ASORA_GRID_XH_AV]) return fail(4, "raytrace: xh_av not on device");
+    if (!st.opt[ASORA_OPT_GREY_NOTABLES] && (!st.thin || !st.thick))
+        return fail(4, "raytrace: radiation tables not on device (photo_table_to_device)");
+    if (src_begin < 0 || src_count < 0 || src_begin + src_count > st.num_src)
+        return fail(4, "raytrace: source range [" + std::to_string(src_begin) + "," +
+                           std::to_string(src_begin + src_count) + ") outside the " + std::to_string(st.num_src) +
+                           " uploaded sources (source_data_to_device)");
+    if (!(R >= 0.0)) return fail(4, "raytrace: R must be >= 0");
+    if (NumTau < 1 && !st.opt[ASORA_OPT_GREY_NOTABLES]) return fail(4, "raytrace: NumTau must be >= 1");
+
+    const bool zt = st.opt[ASORA_OPT_Z_TRANSPOSED] != 0;
+    const size_t bytes = st.ncell * sizeof(double);
+    ASORA_HIP_TRY(hipMemsetAsync(st.grid[ASORA_GRID_PHI_ION], 0, bytes, st.stream));      // raytracing.cu:113
+    if (zt) ASORA_HIP_TRY(hipMemsetAsync(st.phi_t, 0, bytes, st.stream));
+    ASORA_HIP_TRY(hipMemsetAsync(st.counters, 0, sizeof(unsigned long long) * 2, st.stream));
+    if (int rc = launch_prepare_nhi(st, zt)) return rc;
+
+    RtParams p;
+    std::memset(&p, 0, sizeof p);
+    p.N = st.N;
+    p.R = R; p.sig = sig; p.dr = dr;
+    p.minlogtau = minlogtau; p.dlogtau = dlogtau;
+    p.NumTau = NumTau; p.numtau_f = (double)(float)NumTau;     // min(float(NumTau), ...) rates.cu:79
+    p.table_len = st.table_len > 0 ? st.table_len : 1;
+    p.fortran_consts = st.opt[ASORA_OPT_FORTRAN_CONSTANTS];
+    p.grey = st.opt[ASORA_OPT_GREY_NOTABLES];
+    p.z_transposed = zt ? 1 : 0;
+    p.src_begin = src_begin; p.src_count = src_count;
+    p.nhi = st.nhi; p.nhi_t = st.nhi_t;
+    p.phi = st.grid[ASORA_GRID_PHI_ION]; p.phi_t = st.phi_t;
+    p.thin = st.thin; p.thick = st.thick;
+    p.src_pos = st.src_pos; p.src_flux = st.src_flux;
+    p.dump = dump;
+    p.counters = st.counters;
+    if (int rc = launch_raytrace(st, p, dump != nullptr)) return rc;
+    if (zt)
+        if (int rc = launch_finish_phi(st)) return rc;
+    st.grid_valid[ASORA_GRID_PHI_ION] = true;
+    return 0;
+}
+
+} // namespace asora
+
+using namespace asora;
+
+extern "C" {
+
+const char *asora_last_error(void) { return g_error.c_str(); }
+
+int asora_device_init_ex(int N, int num_src_par, int device_id)
+{
+    clear_error();
+    State &st = g_state;
+    if (N < 2) return fail(1, "device_init: N must be >= 2");
+    if (st.init) release_all();
+    if (st.stream && device_id != st.device) return fail(1, "device_init: the device cannot change within a process");
+    st.device = device_id;
+    if (int rc = ensure_runtime()) return rc;
+    st.N = N;
+    st.ncell = (size_t)N * N * N;
+    st.num_src_par = num_src_par;
+    const size_t bytes = st.ncell * sizeof(double);
+    for (int g = 0; g < ASORA_GRID_COUNT; ++g) ASORA_HIP_TRY(hipMalloc(&st.grid[g], bytes));
+    ASORA_HIP_TRY(hipMalloc(&st.nhi, bytes));
+    ASORA_HIP_TRY(hipMalloc(&st.nhi_t, bytes));
+    ASORA_HIP_TRY(hipMalloc(&st.phi_t, bytes));
+    ASORA_HIP_TRY(hipMalloc(&st.staging, bytes));
+    st.init = true;
+    return 0;
+}
+
+int asora_device_init(int N, int num_src_par)
+{
+    int dev = g_state.stream ? g_state.device : 0;
+    if (!g_state.stream) {
+        // the reference uses the current device (memory.cu:39)
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    return asora_device_init_ex(N, num_src_par, dev);
+}
+
+int asora_device_close(void)
+{
+    clear_error();
+    if (int rc = require_init("device_close")) return rc;
+    ASORA_HIP_TRY(hipStreamSynchronize(g_state.stream));
+    return release_all();
+}
+
+int asora_grid_to_device(int which, const double *host, int N, char order)
+{
+    clear_error();
+    if (int rc = require_init("grid_to_device")) return rc;
+    if (int rc = check_N("grid_to_device", N)) return rc;
+    if (which < 0 || which >= ASORA_GRID_COUNT) return fail(3, "grid_to_device: bad grid selector");
+    if (!host) return fail(3, "grid_to_device: null host pointer");
+    State &st = g_state;
+    const size_t bytes = st.ncell * sizeof(double);
+    if (order == 'C' || order == 'c') {
+        ASORA_HIP_TRY(hipMemcpyAsync(st.grid[which], host, bytes, hipMemcpyHostToDevice, st.stream));
+    } else if (order == 'F' || order == 'f') {
+        ASORA_HIP_TRY(hipMemcpyAsync(st.staging, host, bytes, hipMemcpyHostToDevice, st.stream));
+        if (int rc = launch_transpose(st, st.staging, st.grid[which], N)) return rc;
+    } else
+        return fail(3, "grid_to_device: order must be 'C' or 'F'");
+    ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    st.grid_valid[which] = true;
+    return 0;
+}
+
+int asora_grid_to_host(int which, double *host, int N, char order)
+{
+    clear_error();
+    if (int rc = require_init("grid_to_host")) return rc;
+    if (int rc = check_N("grid_to_host", N)) return rc;
+    if (which < 0 || which >= ASORA_GRID_COUNT) return fail(3, "grid_to_host: bad grid selector");
+    if (!host) return fail(3, "grid_to_host: null host pointer");
+    State &st = g_state;
+    if (!st.grid_valid[which]) return fail(3, "grid_to_host: grid " + std::to_string(which) + " holds no data");
+    const size_t bytes = st.ncell * sizeof(double);
+    if (order == 'C' || order == 'c') {
+        ASORA_HIP_TRY(hipMemcpyAsync(host, st.grid[which], bytes, hipMemcpyDeviceToHost, st.stream));
+    } else if (order == 'F' || order == 'f') {
+        if (int rc = launch_transpose(st, st.grid[which], st.staging, N)) return rc;
+        ASORA_HIP_TRY(hipMemcpyAsync(host, st.staging, bytes, hipMemcpyDeviceToHost, st.stream));
+    } else
+        return fail(3, "grid_to_host: order must be 'C' or 'F'");
+    ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    return 0;
+}
+
+int asora_grid_copy(int dst, int src)
+{
+    clear_error();
+    if (int rc = require_init("grid_copy")) return rc;
+    if (dst < 0 || dst >= ASORA_GRID_COUNT || src < 0 || src >= ASORA_GRID_COUNT || dst == src)
+        return fail(3, "grid_copy: bad grid selectors");
+    State &st = g_state;
+    if (!st.grid_valid[src]) return fail(3, "grid_copy: source grid holds no data");
+    ASORA_HIP_TRY(hipMemcpyAsync(st.grid[dst], st.grid[src], st.ncell * sizeof(double), hipMemcpyDeviceToDevice,
+                                 st.stream));
+    st.grid_valid[dst] = true;
+    return 0;
+}
+
+void *asora_device_ptr(int which)
+{
+    if (!g_state.init || which < 0 || which >= ASORA_GRID_COUNT) return nullptr;
+    return g_state.grid[which];
+}
+
+int asora_density_to_device(const double *ndens, int N)
+{
+    return asora_grid_to_device(ASORA_GRID_NDENS, ndens, N, 'C');
+}
+
+int asora_photo_table_to_device(const double *thin_table, const double *thick_table, int NumTau)
+{
+    clear_error();
+    if (int rc = require_init("photo_table_to_device")) return rc;
+    if (NumTau < 1 || !thin_table || !thick_table) return fail(3, "photo_table_to_device: empty table");
+    State &st = g_state;
+    if (st.thin) { (void)hipFree(st.thin); st.thin = nullptr; }
+    if (st.thick) { (void)hipFree(st.thick); st.thick = nullptr; }
+    const size_t bytes = sizeof(double) * (size_t)NumTau;
+    ASORA_HIP_TRY(hipMalloc(&st.thin, bytes));
+    ASORA_HIP_TRY(hipMalloc(&st.thick, bytes));
+    ASORA_HIP_TRY(hipMemcpy(st.thin, thin_table, bytes, hipMemcpyHostToDevice));
+    ASORA_HIP_TRY(hipMemcpy(st.thick, thick_table, bytes, hipMemcpyHostToDevice));
+    st.table_len = NumTau;
+    return 0;
+}
+
+int asora_source_data_to_device(const int32_t *pos, const double *flux, int NumSrc)
+{
+    clear_error();
+    if (int rc = require_init("source_data_to_device")) return rc;
+    if (NumSrc < 0 || (NumSrc > 0 && (!pos || !flux))) return fail(3, "source_data_to_device: bad arguments");
+    State &st = g_state;
+    // validate on the host before anything reaches a kernel: positions index the grid directly
+    for (int s = 0; s < NumSrc; ++s)
+        for (int ax = 0; ax < 3; ++ax)
+            if (pos[3 * s + ax] < 0 || pos[3 * s + ax] >= st.N)
+                return fail(3, "source_data_to_device: source " + std::to_string(s) + " lies outside the mesh (0-based " +
+                                   std::to_string(pos[3 * s + ax]) + " on axis " + std::to_string(ax) + ")");
+    if (st.src_pos) { (void)hipFree(st.src_pos); st.src_pos = nullptr; }          // memory.cu:102-103
+    if (st.src_flux) { (void)hipFree(st.src_flux); st.src_flux = nullptr; }
+    st.num_src = 0;
+    if (NumSrc == 0) return 0;
+    ASORA_HIP_TRY(hipMalloc(&st.src_pos, sizeof(int32_t) * 3 * (size_t)NumSrc));
+    ASORA_HIP_TRY(hipMalloc(&st.src_flux, sizeof(double) * (size_t)NumSrc));
+    ASORA_HIP_TRY(hipMemcpy(st.src_pos, pos, sizeof(int32_t) * 3 * (size_t)NumSrc, hipMemcpyHostToDevice));
+    ASORA_HIP_TRY(hipMemcpy(st.src_flux, flux, sizeof(double) * (size_t)NumSrc, hipMemcpyHostToDevice));
+    st.num_src = NumSrc;
+    return 0;
+}
+
+int asora_raytrace_device(double R, double sig, double dr, int src_begin, int src_count, double minlogtau,
+                          double dlogtau, int NumTau)
+{
+    clear_error();
+    if (int rc = require_init("raytrace_device")) return rc;
+    return do_raytrace(R, sig, dr, src_begin, src_count, minlogtau, dlogtau, NumTau, nullptr);
+}
+
+int asora_do_all_sources(double R, double *coldensh_out, double sig, double dr, const double *ndens,
+                         const double *xh_av, double *phi_ion, int NumSrc, int m1, double minlogtau,
+                         double dlogtau, int NumTau)
+{
+    (void)coldensh_out; (void)ndens;      // ignored by the reference too (raytracing.cu:116)
+    clear_error();
+    if (int rc = require_init("do_all_sources")) return rc;
+    if (int rc = check_N("do_all_sources", m1)) return rc;
+    if (!xh_av || !phi_ion) return fail(3, "do_all_sources: null xh_av / phi_ion");
+    State &st = g_state;
+    if (NumSrc > st.num_src)
+        return fail(3, "do_all_sources: NumSrc=" + std::to_string(NumSrc) + " exceeds the " +
+                           std::to_string(st.num_src) + " sources on the device");
+    const size_t bytes = st.ncell * sizeof(double);
+    ASORA_HIP_TRY(hipMemcpyAsync(st.grid[ASORA_GRID_XH_AV], xh_av, bytes, hipMemcpyHostToDevice, st.stream)); // cu:117
+    st.grid_valid[ASORA_GRID_XH_AV] = true;
+    if (int rc = do_raytrace(R, sig, dr, 0, NumSrc, minlogtau, dlogtau, NumTau, nullptr)) return rc;
+    ASORA_HIP_TRY(hipMemcpyAsync(phi_ion, st.grid[ASORA_GRID_PHI_ION], bytes, hipMemcpyDeviceToHost, st.stream)); // cu:146
+    ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    return 0;
+}
+
+int asora_chemistry_device(double dt, double bh00, double albpow, double colh0, double temph0, double abu_c,
+                           int *conv_flag, double *sum_xh1, double *sum_xh0)
+{
+    clear_error();
+    if (int rc = require_init("chemistry_device")) return rc;
+    State &st = g_state;
+    static const int need[] = {ASORA_GRID_NDENS, ASORA_GRID_TEMP, ASORA_GRID_XH, ASORA_GRID_XH_AV,
+                               ASORA_GRID_XH_INTERMED, ASORA_GRID_PHI_ION};
+    for (int g : need)
+        if (!st.grid_valid[g]) return fail(4, "chemistry_device: grid " + std::to_string(g) + " holds no data");
+    ChemParams p;
+    p.ncell = st.ncell;
+    p.dt = dt; p.bh00 = bh00; p.albpow = albpow; p.colh0 = colh0; p.temph0 = temph0; p.abu_c = abu_c;
+    p.ndens = st.grid[ASORA_GRID_NDENS]; p.temp = st.grid[ASORA_GRID_TEMP]; p.xh = st.grid[ASORA_GRID_XH];
+    p.phi = st.grid[ASORA_GRID_PHI_ION];
+    p.xh_av = st.grid[ASORA_GRID_XH_AV]; p.xh_intermed = st.grid[ASORA_GRID_XH_INTERMED];
+    p.red_partial = st.red_partial; p.red_final = st.red_final; p.red_blocks = st.red_blocks;
+    if (int rc = launch_chemistry(st, p, st.stream)) return rc;
+    ASORA_HIP_TRY(hipMemcpyAsync(st.red_host, st.red_final, sizeof(double) * 3, hipMemcpyDeviceToHost, st.stream));
+    ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    if (sum_xh1) *sum_xh1 = st.red_host[0];
+    if (sum_xh0) *sum_xh0 = st.red_host[1];
+    if (conv_flag) *conv_flag = (int)st.red_host[2];
+    return 0;
+}
+
+int c2ray_global_pass(double dt, const double *ndens, const double *temp, const double *xh, double *xh_av,
+                      double *xh_intermed, const double *phi_ion, double bh00, double albpow, double colh0,
+                      double temph0, double abu_c, int m1, int m2, int m3, int *conv_flag)
+{
+    clear_error();
+    if (m1 < 1 || m2 < 1 || m3 < 1) return fail(3, "global_pass: bad mesh size");
+    if (!ndens || !temp || !xh || !xh_av || !xh_intermed || !phi_ion) return fail(3, "global_pass: null grid");
+    if (int rc = ensure_runtime()) return rc;
+    State &st = g_state;
+    const size_t ncell = (size_t)m1 * m2 * m3, bytes = ncell * sizeof(double);
+    double *d[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const double *h[6] = {ndens, temp, xh, xh_av, xh_intermed, phi_ion};
+    int rc = 0;
+    auto cleanup = [&]() { for (auto *q : d) if (q) (void)hipFree(q); };
+    for (int g = 0; g < 6 && !rc; ++g) {
+        hipError_t e = hipMalloc(&d[g], bytes);
+        if (e == hipSuccess) e = hipMemcpyAsync(d[g], h[g], bytes, hipMemcpyHostToDevice, st.stream);
+        if (e != hipSuccess) rc = fail(10, std::string("global_pass: ") + hipGetErrorString(e));
+    }
+    if (rc) { cleanup(); return rc; }
+    ChemParams p;
+    p.ncell = ncell;
+    p.dt = dt; p.bh00 = bh00; p.albpow = albpow; p.colh0 = colh0; p.temph0 = temph0; p.abu_c = abu_c;
+    p.ndens = d[0]; p.temp = d[1]; p.xh = d[2]; p.xh_av = d[3]; p.xh_intermed = d[4]; p.phi = d[5];
+    p.red_partial = st.red_partial; p.red_final = st.red_final; p.red_blocks = st.red_blocks;
+    rc = launch_chemistry(st, p, st.stream);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(xh_av, d[3], bytes, hipMemcpyDeviceToHost, st.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(xh_intermed, d[4], bytes, hipMemcpyDeviceToHost, st.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(st.red_host, st.red_final, sizeof(double) * 3, hipMemcpyDeviceToHost, st.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(st.stream);
+        if (e != hipSuccess) rc = fail(10, std::string("global_pass: ") + hipGetErrorString(e));
+    }
+    if (!rc && conv_flag) *conv_flag = (int)st.red_host[2];
+    cleanup();
+    return rc;
+}
+
+int asora_set_option(int option, int value)
+{
+    clear_error();
+    if (option < 0 || option >= ASORA_OPT_COUNT) return fail(3, "set_option: unknown option");
+    g_state.opt[option] = value;
+    return 0;
+}
+
+int asora_get_option(int option)
+{
+    if (option < 0 || option >= ASORA_OPT_COUNT) return -1;
+    return g_state.opt[option];
+}
+
+int asora_kernel_time_ms(int kernel, double *total_ms, long *launches)
+{
+    clear_error();
+    if (kernel < 0 || kernel >= ASORA_KERNEL_COUNT) return fail(3, "kernel_time_ms: unknown kernel");
+    if (total_ms) *total_ms = g_state.k_ms[kernel];
+    if (launches) *launches = g_state.k_n[kernel];
+    return 0;
+}
+
+int asora_kernel_time_reset(void)
+{
+    for (int k = 0; k < ASORA_KERNEL_COUNT; ++k) { g_state.k_ms[k] = 0.0; g_state.k_n[k] = 0; }
+    return 0;
+}
+
+int asora_synchronize(void)
+{
+    clear_error();
+    if (!g_state.stream) return 0;
+    ASORA_HIP_TRY(hipStreamSynchronize(g_state.stream));
+    ASORA_HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+int asora_last_raytrace_counts(long long *gamma_cells, long long *evaluated_cells)
+{
+    clear_error();
+    if (int rc = require_init("last_raytrace_counts")) return rc;
+    unsigned long long h[2] = {0, 0};
+    ASORA_HIP_TRY(hipStreamSynchronize(g_state.stream));
+    ASORA_HIP_TRY(hipMemcpy(h, g_state.counters, sizeof h, hipMemcpyDeviceToHost));
+    if (gamma_cells) *gamma_cells = (long long)h[0];
+    if (evaluated_cells) *evaluated_cells = (long long)h[1];
+    return 0;
+}
+
+int asora_debug_coldens(double R, double sig, double dr, int source_index, double *coldens_out, int N)
+{
+    clear_error();
+    if (int rc = require_init("debug_coldens")) return rc;
+    if (int rc = check_N("debug_coldens", N)) return rc;
+    if (!coldens_out) return fail(3, "debug_coldens: null output");
+    State &st = g_state;
+    const size_t bytes = st.ncell * sizeof(double);
+    ASORA_HIP_TRY(hipMemsetAsync(st.staging, 0, bytes, st.stream));
+    // the column density does not depend on the tables: trace with whatever is loaded
+    const int numtau = st.table_len > 0 ? st.table_len : 1;
+    const int grey_save = st.opt[ASORA_OPT_GREY_NOTABLES];
+    if (!st.thin) st.opt[ASORA_OPT_GREY_NOTABLES] = 1;
+    int rc = do_raytrace(R, sig, dr, source_index, 1, -20.0, 1.0, numtau, st.staging);
+    st.opt[ASORA_OPT_GREY_NOTABLES] = grey_save;
+    if (rc) return rc;
+    ASORA_HIP_TRY(hipMemcpyAsync(coldens_out, st.staging, bytes, hipMemcpyDeviceToHost, st.stream));
+    ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,123 @@
+// Internal declarations shared by the translation units of libasora_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/asora_hip.h"
+
+namespace asora {
+
+// ---------------------------------------------------------------------------------------------
+// Process-global device state (the role of src/asora/memory.cu:20-29)
+// ---------------------------------------------------------------------------------------------
+struct State {
+    bool init = false;
+    int device = 0;
+    int N = 0;
+    size_t ncell = 0;
+    int num_src_par = 0;           // accepted, unused (no per-source N^3 scratch in this build)
+    int cu_count = 256;
+
+    double *grid[ASORA_GRID_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool grid_valid[ASORA_GRID_COUNT] = {false, false, false, false, false, false};
+
+    // derived per raytrace call
+    double *nhi = nullptr;     // ndens*(1-xh_av), [i][j][k]
+    double *nhi_t = nullptr;   // same, transposed [k][j][i]
+    double *phi_t = nullptr;   // rate accumulator for z-faces, transposed [k][j][i]
+    double *staging = nullptr; // N^3 staging grid for 'F'-order transfers / debug dumps
+
+    double *thin = nullptr, *thick = nullptr;
+    int table_len = 0;
+
+    int32_t *src_pos = nullptr;
+    double *src_flux = nullptr;
+    int num_src = 0;
+
+    // shell scratch for traces whose shell buffers exceed LDS
+    double *shell_scratch = nullptr;
+    size_t shell_scratch_bytes = 0;
+
+    // chemistry reductions
+    double *red_partial = nullptr; // [3][red_blocks]
+    double *red_final = nullptr;   // [3]
+    double *red_host = nullptr;    // pinned [3]
+    int red_blocks = 0;
+
+    unsigned long long *counters = nullptr; // [2] device: gamma cells, evaluated cells
+    long long last_gamma_cells = 0, last_eval_cells = 0;
+
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1};
+    double k_ms[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
+    long k_n[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
+};
+
+State &state();
+int fail(int code, const std::string &msg);   // records the message, returns code
+void clear_error();
+
+#define ASORA_HIP_TRY(expr)                                                                     \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return ::asora::fail(10, std::string(#expr) + ": " + hipGetErrorName(e__) + " - " + \
+                                         hipGetErrorString(e__));                               \
+    } while (0)
+
+// Scoped HIP-event timer around kernel launches on the library stream.
+struct KernelTimer {
+    int which;
+    bool on;
+    explicit KernelTimer(int w);
+    ~KernelTimer();
+};
+
+// ---------------------------------------------------------------------------------------------
+// Raytracing (raytrace.hip)
+// ---------------------------------------------------------------------------------------------
+struct RtParams {
+    int N;
+    int S;                 // last Chebyshev shell to process
+    int W;                 // row stride of a face in the shell buffers
+    int q_max;             // octahedral cut of the reference (raytracing.cu:101)
+    int ext_pos, ext_neg;  // periodic window: +side last_r, -side -last_l (raytracing.cu:122-123)
+    double R, R2;          // Rmax_LLS and its square as the reference forms it
+    double sig, dr;
+    double minlogtau, dlogtau, numtau_f;
+    int NumTau, table_len;
+    int fortran_consts, grey, z_transposed;
+    int src_begin, src_count;
+    const double *nhi, *nhi_t;
+    double *phi, *phi_t;
+    const double *thin, *thick;
+    const int32_t *src_pos;
+    const double *src_flux;
+    double *dump;               // debug: outgoing column density (N^3) or nullptr
+    double *shell_scratch;      // global shell buffers when they do not fit LDS, else nullptr
+    unsigned long long *counters;
+};
+
+int launch_prepare_nhi(State &st, bool need_transposed);
+int launch_finish_phi(State &st);
+int launch_raytrace(State &st, RtParams &p, bool dump);
+int launch_transpose(State &st, const double *src, double *dst, int N);   // dst[k][j][i] = src[i][j][k]
+
+// ---------------------------------------------------------------------------------------------
+// Chemistry (chemistry.hip)
+// ---------------------------------------------------------------------------------------------
+struct ChemParams {
+    size_t ncell;
+    double dt, bh00, albpow, colh0, temph0, abu_c;
+    const double *ndens, *temp, *xh, *phi;
+    double *xh_av, *xh_intermed;
+    double *red_partial, *red_final;
+    int red_blocks;
+};
+int launch_chemistry(State &st, ChemParams &p, hipStream_t stream);
+int chemistry_reduction_blocks(const State &st);
+
+} // namespace asora

@@ -1,0 +1,200 @@
+"""One C2-Ray time step: raytrace all sources, solve the chemistry, iterate to convergence.
+
+Same two entry points, argument lists, return values, log lines and convergence logic as the
+reference (pyc2ray/evolve.py:38-245 ``evolve3D``, :249-498 ``evolve3D_MPI``).  What differs is where
+the data lives: the reference re-uploads xh_av, downloads phi_ion, runs the chemistry on one CPU core
+and transposes xh_av back on every iteration (evolve.py:187,200,210,240); here ndens, temp, xh, xh_av,
+xh_intermed and phi_ion stay on the MI355X for the whole step, the chemistry is a HIP kernel, and
+three scalars (conv_flag, sum x, sum 1-x) cross PCIe per iteration.
+"""
+import time
+
+import numpy as np
+
+from . import _capi
+from .asora_core import cuda_is_init
+from .load_extensions import load_asora, load_c2ray
+from .utils import printlog
+from .utils.sourceutils import format_sources
+
+__all__ = ['evolve3D', 'evolve3D_MPI']
+
+
+def _host_cpu_step_unavailable():
+    # use_gpu=False selects the reference's Fortran CPU raytracer (evolve.py:190-194)
+    load_c2ray().raytracing.do_all_sources()
+
+
+def _allreduce_phi(libasora, N, use_mpi, comm, rank):
+    """Sum the per-rank photo-ionisation rate grids (evolve.py:433-437: Reduce to root + Bcast)."""
+    if hasattr(comm, "allreduce_device_grid"):
+        # pyc2ray_amd.dist.TorchComm: RCCL all-reduce on the device-resident grid (or gloo via host)
+        comm.allreduce_device_grid(libasora, _capi.GRID_PHI_ION, N)
+        return
+    # mpi4py communicator, host-staged like the reference
+    phi = libasora.grid_to_host(_capi.GRID_PHI_ION, np.empty((N, N, N)))
+    if rank == 0:
+        comm.Reduce(use_mpi.IN_PLACE, [phi, use_mpi.DOUBLE], op=use_mpi.SUM, root=0)
+    else:
+        comm.Reduce([phi, use_mpi.DOUBLE], None, op=use_mpi.SUM, root=0)
+    comm.Bcast([phi, use_mpi.DOUBLE], root=0)
+    libasora.grid_to_device(_capi.GRID_PHI_ION, phi)
+
+
+def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_table, minlogtau, dlogtau,
+            R_max_LLS, convergence_fraction, sig, bh00, albpow, colh0, temph0, abu_c, logfile, quiet,
+            use_mpi=None, comm=None, rank=0, nprocs=1):
+    if use_gpu and not cuda_is_init():
+        raise RuntimeError("GPU not initialized. Please initialize it by calling device_init(N)")
+    if not use_gpu:
+        _host_cpu_step_unavailable()
+
+    distributed = bool(use_mpi) and comm is not None and nprocs > 1
+    libasora = load_asora()
+
+    NumSrc = src_flux.shape[0]          # number of sources
+    N = temp.shape[0]                   # mesh size
+    NumCells = N * N * N
+    NumTau = photo_thin_table.shape[0]  # evolve.py:124 (the table LENGTH is what the reference passes)
+
+    # Convergence criterion, evolve.py:127 (computed from the TOTAL source count, evolve.py:346)
+    conv_criterion = min(int(convergence_fraction * NumCells), (NumSrc - 1) / 3)
+
+    prev_sum_xh1_int = 2 * NumCells
+    prev_sum_xh0_int = 2 * NumCells
+    converged = False
+    niter = 0
+
+    # source shard of this rank, evolve.py:360-371
+    if distributed:
+        perrank = NumSrc // nprocs
+        i_start = int(rank * perrank)
+        i_end = int((rank + 1) * perrank) if rank != nprocs - 1 else NumSrc
+    else:
+        i_start, i_end = 0, NumSrc
+    NumSrc_local = i_end - i_start
+    srcpos_flat, normflux_flat = format_sources(np.asarray(src_pos)[:, i_start:i_end], src_flux[i_start:i_end])
+    if distributed:
+        printlog(f"...rank={rank:n} has {NumSrc_local:n} sources.", logfile, quiet)
+
+    # Everything the step needs goes to the device once (evolve.py:136-155 keeps host copies instead)
+    libasora.source_data_to_device(srcpos_flat, normflux_flat, NumSrc_local)
+    libasora.grid_to_device(_capi.GRID_NDENS, ndens)
+    libasora.grid_to_device(_capi.GRID_TEMP, temp)
+    libasora.grid_to_device(_capi.GRID_XH, xh)
+    libasora.grid_copy(_capi.GRID_XH_AV, _capi.GRID_XH)          # xh_av = copy(xh)        evolve.py:136
+    libasora.grid_copy(_capi.GRID_XH_INTERMED, _capi.GRID_XH)    # xh_intermed = copy(xh)  evolve.py:137
+    if not distributed:
+        printlog("Copied source data to device.", logfile, quiet)
+
+    if rank == 0:
+        if distributed:
+            printlog(f"Calling evolve3D with {nprocs:n} MPI-processors...", logfile, quiet)
+        else:
+            printlog("Calling evolve3D...", logfile, quiet)
+        printlog(f"dr [Mpc]: {dr/3.086e24:.3e}", logfile, quiet)
+        printlog(f"dt [years]: {dt/3.15576E+07:.3e}", logfile, quiet)
+        printlog(f"Running on {NumSrc:n} source(s), total normalized ionizing flux: {src_flux.sum():.2e}", logfile, quiet)
+        printlog(f"Mean density (cgs): {ndens.mean():.3e}, Mean ionized fraction: {xh.mean():.3e}", logfile, quiet)
+        printlog(f"Convergence Criterion (Number of points): {conv_criterion : n}", logfile, quiet, end='\n\n')
+
+    while not converged:
+        niter += 1
+
+        # (1) raytracing, evolve.py:174-196
+        trt0 = time.time()
+        if distributed:
+            printlog(f"Doing Raytracing (rank={rank:n})...", logfile, quiet, ' ')
+        else:
+            printlog("Doing Raytracing...", logfile, quiet, ' ')
+        libasora.raytrace_device(R_max_LLS, sig, dr, 0, NumSrc_local, minlogtau, dlogtau, NumTau)
+        if distributed:
+            libasora.synchronize()
+            printlog(f"rank={rank:n} took {(time.time()-trt0) : .1e} s.", logfile, quiet)
+            _allreduce_phi(libasora, N, use_mpi, comm, rank)
+        else:
+            libasora.synchronize()
+            printlog(f"took {(time.time()-trt0) : .1f} s.", logfile, quiet)
+
+        # (2) chemistry, evolve.py:207-211.  Every rank runs it on the identical summed rates
+        # (the reference runs it on rank 0 and broadcasts two N^3 grids, evolve.py:439-481).
+        tch0 = time.time()
+        if rank == 0:
+            printlog("Doing Chemistry...", logfile, quiet, ' ')
+        conv_flag, sum_xh1_int, sum_xh0_int = libasora.chemistry_device(dt, bh00, albpow, colh0, temph0, abu_c)
+        if rank == 0:
+            printlog(f"took {(time.time()-tch0) : .1f} s.", logfile, quiet)
+
+        # (3) global convergence, evolve.py:216-236
+        if sum_xh1_int > 0.0:
+            rel_change_xh1 = np.abs((sum_xh1_int - prev_sum_xh1_int) / sum_xh1_int)
+        else:
+            rel_change_xh1 = 1.0
+        if sum_xh0_int > 0.0:
+            rel_change_xh0 = np.abs((sum_xh0_int - prev_sum_xh0_int) / sum_xh0_int)
+        else:
+            rel_change_xh0 = 1.0
+
+        if rank == 0:
+            printlog(f"Number of non-converged points: {conv_flag} of {NumCells} ({conv_flag / NumCells * 100 : .3f} % ), "
+                     f"Relative change in ionfrac: {rel_change_xh1 : .2e}", logfile, quiet)
+
+        converged = (conv_flag < conv_criterion) or ((rel_change_xh1 < convergence_fraction) and
+                                                     (rel_change_xh0 < convergence_fraction))
+        prev_sum_xh1_int = sum_xh1_int
+        prev_sum_xh0_int = sum_xh0_int
+
+    if rank == 0:
+        printlog("Multiple source convergence reached.", logfile, quiet)
+    xh_new = libasora.grid_to_host(_capi.GRID_XH_INTERMED, np.empty_like(xh, dtype=np.float64))
+    phi_ion = libasora.grid_to_host(_capi.GRID_PHI_ION, np.empty((N, N, N)))
+    _evolve.last_niter = niter
+    return xh_new, phi_ion
+
+
+def evolve3D(dt, dr,
+             src_flux, src_pos,
+             use_gpu, max_subbox, subboxsize, loss_fraction,
+             temp, ndens, xh,
+             photo_thin_table, photo_thick_table,
+             minlogtau, dlogtau,
+             R_max_LLS, convergence_fraction,
+             sig, bh00, albpow, colh0, temph0, abu_c,
+             logfile="pyC2Ray.log", quiet=False):
+    """Evolve the ionised fraction of the whole grid over one time step.
+
+    Parameters have the reference's meaning (pyc2ray/evolve.py:49-109): dt [s], dr [cm],
+    src_flux (numsrc) in units of 1e48 s^-1, src_pos (3,numsrc) 1-based, temp/ndens/xh (N,N,N),
+    tables as copied to the GPU beforehand with photo_table_to_device(), R_max_LLS in cells.
+    max_subbox, subboxsize and loss_fraction only concern the reference's CPU raytracer and have no
+    effect with use_gpu=True; use_gpu=False raises (no CPU compute path in this build).
+
+    Returns (xh_new, phi_ion): end-of-step ionised fraction (laid out like `xh`) and the summed
+    photo-ionisation rate (C-ordered), as the reference's GPU branch does (evolve.py:200,244-245).
+    """
+    return _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_table, minlogtau, dlogtau,
+                   R_max_LLS, convergence_fraction, sig, bh00, albpow, colh0, temph0, abu_c, logfile, quiet)
+
+
+def evolve3D_MPI(dt, dr,
+                 src_flux, src_pos,
+                 use_gpu, max_subbox, subboxsize, loss_fraction,
+                 use_mpi, comm, rank, nprocs,
+                 temp, ndens, xh,
+                 photo_thin_table, photo_thick_table,
+                 minlogtau, dlogtau,
+                 R_max_LLS, convergence_fraction,
+                 sig, bh00, albpow, colh0, temph0, abu_c,
+                 logfile="pyC2Ray.log", quiet=False):
+    """Source-sharded variant (pyc2ray/evolve.py:249-498): rank r traces the contiguous block
+    [r*(Ns//nprocs), (r+1)*(Ns//nprocs)) of the source list, the last rank to the end
+    (evolve.py:362-367); the per-rank rate grids are summed across ranks each iteration.
+
+    `use_mpi`/`comm` may be mpi4py's ``MPI`` module and a communicator, exactly as the reference takes
+    them (host-staged Reduce+Bcast), or ``pyc2ray_amd.dist.MPI`` and a ``pyc2ray_amd.dist.TorchComm``
+    (one process per GPU under torch.distributed: RCCL all-reduce over xGMI directly on the
+    device-resident grid).  All ranks return the same (xh_new, phi_ion).
+    """
+    return _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_table, minlogtau, dlogtau,
+                   R_max_LLS, convergence_fraction, sig, bh00, albpow, colh0, temph0, abu_c, logfile, quiet,
+                   use_mpi=use_mpi, comm=comm, rank=rank, nprocs=nprocs)

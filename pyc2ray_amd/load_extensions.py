@@ -1,0 +1,247 @@
+"""Extension loader with the reference's names (pyc2ray/load_extensions.py:9-48).
+
+The reference imports two CPython extension modules, ``pyc2ray.lib.libasora`` (CUDA) and
+``pyc2ray.lib.libc2ray`` (f2py Fortran).  Here both are thin objects over ONE ctypes-loaded
+shared library, ``pyc2ray_amd/lib/libasora_hip.so``; their methods keep the reference's names,
+argument order and in-place conventions, so code written against the reference's extension
+modules (pyc2ray/evolve.py:147-210, raytracing_benchmark/run_test.py:66-85) runs unchanged.
+
+Differences, all deliberate:
+  * a missing library raises RuntimeError for BOTH loaders (the reference makes ASORA optional and
+    prints an "Info" line, load_extensions.py:41-44).  This build has no CPU path to fall back to.
+  * errors inside the library come back as RuntimeError carrying the library's message instead of
+    an uncaught C++ exception.
+  * array arguments are validated (dtype float64 / int32, contiguity, size) instead of being
+    trusted (src/asora/python_module.cu:60-63).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+__all__ = ["load_c2ray", "load_asora"]
+
+
+def _flat_f64(a, n, name):
+    if not isinstance(a, np.ndarray) or a.dtype != np.float64:
+        raise TypeError(f"{name} must be Array of type double")       # python_module.cu:55
+    if not (a.flags.c_contiguous or a.flags.f_contiguous):
+        raise ValueError(f"{name} must be contiguous")
+    if a.size != n:
+        raise ValueError(f"{name} has {a.size} elements, expected {n}")
+    return a
+
+
+class _LibAsora:
+    """Stand-in for the reference's ``libasora`` module (src/asora/python_module.cu:153-161)."""
+
+    def __init__(self, lib):
+        self._lib = lib
+        self._N = None
+
+    # ---- the six reference methods --------------------------------------------------------
+    def device_init(self, N, num_src_par, device_id=None):
+        if device_id is None:
+            _capi.check(self._lib.asora_device_init(int(N), int(num_src_par)), "device_init")
+        else:
+            _capi.check(self._lib.asora_device_init_ex(int(N), int(num_src_par), int(device_id)), "device_init")
+        self._N = int(N)
+
+    def device_close(self):
+        _capi.check(self._lib.asora_device_close(), "device_close")
+        self._N = None
+
+    def density_to_device(self, ndens, N):
+        a = _flat_f64(ndens, int(N) ** 3, "ndens")
+        _capi.check(self._lib.asora_density_to_device(_capi.dptr(a), int(N)), "density_to_device")
+
+    def photo_table_to_device(self, thin_table, thick_table, NumTau):
+        t0 = np.ascontiguousarray(thin_table, dtype=np.float64)
+        t1 = np.ascontiguousarray(thick_table, dtype=np.float64)
+        if t0.size < NumTau or t1.size < NumTau:
+            raise ValueError("photo_table_to_device: NumTau exceeds the table length")
+        _capi.check(self._lib.asora_photo_table_to_device(_capi.dptr(t0), _capi.dptr(t1), int(NumTau)),
+                    "photo_table_to_device")
+
+    def source_data_to_device(self, pos, flux, NumSrc):
+        p = np.ascontiguousarray(pos)
+        if p.dtype != np.int32:
+            raise TypeError("source positions must be int32 (use format_sources)")
+        f = np.ascontiguousarray(flux, dtype=np.float64)
+        if p.size < 3 * NumSrc or f.size < NumSrc:
+            raise ValueError("source_data_to_device: arrays shorter than NumSrc")
+        _capi.check(self._lib.asora_source_data_to_device(_capi.iptr(p), _capi.dptr(f), int(NumSrc)),
+                    "source_data_to_device")
+
+    def do_all_sources(self, R, coldensh_out, sig, dr, ndens, xh_av, phi_ion, NumSrc, m1,
+                       minlogtau, dlogtau, NumTau):
+        n = int(m1) ** 3
+        if not isinstance(coldensh_out, np.ndarray) or coldensh_out.dtype != np.float64:
+            raise TypeError("coldensh_out must be Array of type double")   # python_module.cu:53-57
+        x = _flat_f64(xh_av, n, "xh_av")
+        ph = _flat_f64(phi_ion, n, "phi_ion")
+        if not ph.flags.writeable:
+            raise ValueError("phi_ion must be writeable (it is filled in place)")
+        _capi.check(self._lib.asora_do_all_sources(float(R), None, float(sig), float(dr), None, _capi.dptr(x),
+                                                   _capi.dptr(ph), int(NumSrc), int(m1), float(minlogtau),
+                                                   float(dlogtau), int(NumTau)), "do_all_sources")
+        return None
+
+    # ---- device-resident extension (include/asora_hip.h section B/C) ------------------------
+    def grid_to_device(self, which, a):
+        N = a.shape[0]
+        if a.ndim != 3 or a.shape != (N, N, N):
+            raise ValueError("grid must have shape (N,N,N)")
+        a = np.asarray(a, dtype=np.float64)
+        if a.flags.c_contiguous:
+            order = b'C'
+        elif a.flags.f_contiguous:
+            order = b'F'
+        else:
+            a, order = np.ascontiguousarray(a), b'C'
+        _capi.check(self._lib.asora_grid_to_device(int(which), _capi.dptr(a), int(N), order), "grid_to_device")
+
+    def grid_to_host(self, which, out):
+        N = out.shape[0]
+        if out.dtype != np.float64 or out.shape != (N, N, N):
+            raise ValueError("output grid must be float64 of shape (N,N,N)")
+        if out.flags.c_contiguous:
+            _capi.check(self._lib.asora_grid_to_host(int(which), _capi.dptr(out), int(N), b'C'), "grid_to_host")
+        elif out.flags.f_contiguous:
+            _capi.check(self._lib.asora_grid_to_host(int(which), _capi.dptr(out), int(N), b'F'), "grid_to_host")
+        else:
+            tmp = np.empty((N, N, N))
+            _capi.check(self._lib.asora_grid_to_host(int(which), _capi.dptr(tmp), int(N), b'C'), "grid_to_host")
+            out[...] = tmp
+        return out
+
+    def grid_copy(self, dst, src):
+        _capi.check(self._lib.asora_grid_copy(int(dst), int(src)), "grid_copy")
+
+    def device_ptr(self, which):
+        return self._lib.asora_device_ptr(int(which))
+
+    def raytrace_device(self, R, sig, dr, src_begin, src_count, minlogtau, dlogtau, NumTau):
+        _capi.check(self._lib.asora_raytrace_device(float(R), float(sig), float(dr), int(src_begin), int(src_count),
+                                                    float(minlogtau), float(dlogtau), int(NumTau)),
+                    "raytrace_device")
+
+    def chemistry_device(self, dt, bh00, albpow, colh0, temph0, abu_c):
+        conv = C.c_int(0)
+        s1 = C.c_double(0.0)
+        s0 = C.c_double(0.0)
+        _capi.check(self._lib.asora_chemistry_device(float(dt), float(bh00), float(albpow), float(colh0),
+                                                     float(temph0), float(abu_c), C.byref(conv), C.byref(s1),
+                                                     C.byref(s0)), "chemistry_device")
+        return conv.value, s1.value, s0.value
+
+    def set_option(self, option, value):
+        _capi.check(self._lib.asora_set_option(int(option), int(value)), "set_option")
+
+    def get_option(self, option):
+        return self._lib.asora_get_option(int(option))
+
+    def kernel_time_ms(self, kernel):
+        ms = C.c_double(0.0)
+        n = C.c_long(0)
+        _capi.check(self._lib.asora_kernel_time_ms(int(kernel), C.byref(ms), C.byref(n)), "kernel_time_ms")
+        return ms.value, n.value
+
+    def kernel_time_reset(self):
+        self._lib.asora_kernel_time_reset()
+
+    def synchronize(self):
+        _capi.check(self._lib.asora_synchronize(), "synchronize")
+
+    def last_raytrace_counts(self):
+        g = C.c_longlong(0)
+        e = C.c_longlong(0)
+        _capi.check(self._lib.asora_last_raytrace_counts(C.byref(g), C.byref(e)), "last_raytrace_counts")
+        return g.value, e.value
+
+    def debug_coldens(self, R, sig, dr, source_index, N):
+        out = np.zeros((N, N, N))
+        _capi.check(self._lib.asora_debug_coldens(float(R), float(sig), float(dr), int(source_index),
+                                                  _capi.dptr(out), int(N)), "debug_coldens")
+        return out
+
+
+class _Chemistry:
+    """Stand-in for ``libc2ray.chemistry`` (f2py wrapper of src/c2ray/chemistry.f90)."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def global_pass(self, dt, ndens, temp, xh, xh_av, xh_intermed, phi_ion, bh00, albpow, colh0, temph0, abu_c):
+        """conv_flag = global_pass(...); xh_av and xh_intermed are updated IN PLACE, xh is not
+        modified (chemistry.f90:13-48,107-108).  The pass is elementwise, so all grids are brought to
+        the storage order of xh_av; like f2py's intent(inout), xh_av and xh_intermed must be
+        float64 arrays."""
+        for name, a in (("xh_av", xh_av), ("xh_intermed", xh_intermed)):
+            if not isinstance(a, np.ndarray) or a.dtype != np.float64:
+                raise ValueError(f"{name} must be a float64 array (updated in place)")
+        shape = np.shape(xh_av)
+        if len(shape) != 3:
+            raise ValueError("grids must be 3-dimensional")
+        order = 'F' if (xh_av.flags.f_contiguous and not xh_av.flags.c_contiguous) else 'C'
+        req = lambda a: np.require(np.broadcast_to(np.asarray(a, dtype=np.float64), shape), np.float64, [order])
+        nd, tp, x0, ph = req(ndens), req(temp), req(xh), req(phi_ion)
+        xa = np.require(xh_av, np.float64, [order, 'W'])
+        xi = np.require(xh_intermed, np.float64, [order, 'W'])
+        if xi is xh_intermed and np.shares_memory(xa, xi):
+            xi = xi.copy(order=order)          # aliased in/out grids (hydrogenODE): keep them apart
+        if np.shares_memory(x0, xa) or np.shares_memory(x0, xi):
+            x0 = x0.copy(order=order)
+        conv = C.c_int(0)
+        _capi.check(self._lib.c2ray_global_pass(float(dt), _capi.dptr(nd), _capi.dptr(tp), _capi.dptr(x0),
+                                                _capi.dptr(xa), _capi.dptr(xi), _capi.dptr(ph), float(bh00),
+                                                float(albpow), float(colh0), float(temph0), float(abu_c),
+                                                int(shape[0]), int(shape[1]), int(shape[2]), C.byref(conv)),
+                    "global_pass")
+        if xa is not xh_av:
+            xh_av[...] = xa
+        if xi is not xh_intermed:
+            xh_intermed[...] = xi
+        return conv.value
+
+
+class _Raytracing:
+    """Stand-in for ``libc2ray.raytracing`` (f2py wrapper of src/c2ray/raytracing.f90)."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def do_all_sources(self, *args, **kwargs):
+        raise RuntimeError(
+            "libc2ray.raytracing.do_all_sources (the reference's single-threaded Fortran CPU raytracer, "
+            "src/c2ray/raytracing.f90:52) is not part of this build: pyc2ray_amd ships no CPU compute path. "
+            "Call with use_gpu=True (ASORA path on the MI355X).")
+
+
+class _LibC2Ray:
+    """Stand-in for the reference's f2py module ``libc2ray`` (sub-modules chemistry, raytracing)."""
+
+    def __init__(self, lib):
+        self.chemistry = _Chemistry(lib)
+        self.raytracing = _Raytracing(lib)
+
+
+_c2ray_lib = None
+_asora_lib = None
+
+
+def load_c2ray():
+    """pyc2ray/load_extensions.py:9-29.  Raises RuntimeError when the library is missing."""
+    global _c2ray_lib
+    if _c2ray_lib is None:
+        _c2ray_lib = _LibC2Ray(_capi.load())
+    return _c2ray_lib
+
+
+def load_asora():
+    """pyc2ray/load_extensions.py:31-48.  Unlike the reference, a missing library is an error."""
+    global _asora_lib
+    if _asora_lib is None:
+        _asora_lib = _LibAsora(_capi.load())
+    return _asora_lib

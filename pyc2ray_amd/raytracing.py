@@ -1,0 +1,63 @@
+"""Standalone raytracing entry point, as pyc2ray/raytracing.py:34-108."""
+import time
+
+import numpy as np
+
+from . import _capi
+from .asora_core import cuda_is_init
+from .load_extensions import load_asora, load_c2ray
+from .utils import printlog
+from .utils.sourceutils import format_sources
+
+__all__ = ['do_raytracing']
+
+
+def do_raytracing(dr,
+                  src_flux, src_pos,
+                  use_gpu, max_subbox, subboxsize, loss_fraction,
+                  ndens, xh_av,
+                  photo_thin_table, photo_thick_table,
+                  heat_thin_table, heat_thick_table,
+                  minlogtau, dlogtau,
+                  R_max_LLS,
+                  sig,
+                  logfile="pyC2Ray.log", quiet=False, stats=False):
+    """Raytrace all sources once and return the photo-ionisation rate grid.
+
+    Same 17 positional arguments as the reference (pyc2ray/raytracing.py:34-43).  Returns
+    ``(phi_ion, phi_heat)``; on the GPU path the reference's return statement refers to an
+    undefined ``phi_heat`` (raytracing.py:108, NameError) -- here it is ``None`` (the reference lists
+    GPU heating as TODO, c2ray_base.py:424-426).  ``use_gpu=False`` selects the reference's Fortran
+    CPU raytracer, which this build does not ship: RuntimeError.
+    """
+    if use_gpu and not cuda_is_init():
+        raise RuntimeError("GPU not initialized. Please initialize it by calling device_init(N)")
+
+    NumSrc = src_flux.shape[0]
+    N = ndens.shape[0]
+    NumTau = photo_thin_table.shape[0]
+
+    printlog(f"dr [Mpc]: {dr/3.086e24:.3e}", logfile, quiet)
+    printlog(f"Running on {NumSrc:n} source(s), total normalized ionizing flux: {src_flux.sum():.2e}", logfile, quiet)
+    printlog(f"Mean density (cgs): {ndens.mean():.3e}, Mean ionized fraction: {xh_av.mean():.3e}", logfile, quiet)
+
+    if not use_gpu:
+        # raises: no CPU compute path in this build
+        load_c2ray().raytracing.do_all_sources(src_flux, src_pos, max_subbox, subboxsize, None, sig, dr, ndens,
+                                               xh_av, None, None, loss_fraction, photo_thin_table,
+                                               photo_thick_table, heat_thin_table, heat_thick_table,
+                                               minlogtau, dlogtau, R_max_LLS)
+
+    libasora = load_asora()
+    srcpos_flat, normflux_flat = format_sources(src_pos, src_flux)
+    libasora.source_data_to_device(srcpos_flat, normflux_flat, NumSrc)
+    libasora.grid_to_device(_capi.GRID_NDENS, ndens)
+    libasora.grid_to_device(_capi.GRID_XH_AV, xh_av)
+    printlog("Copied source data to device.", logfile, quiet)
+
+    trt0 = time.time()
+    printlog("Doing Raytracing...", logfile, quiet, ' ')
+    libasora.raytrace_device(R_max_LLS, sig, dr, 0, NumSrc, minlogtau, dlogtau, NumTau)
+    phi_ion = libasora.grid_to_host(_capi.GRID_PHI_ION, np.empty((N, N, N)))
+    printlog(f"took {(time.time()-trt0) : .1f} s.", logfile, quiet)
+    return phi_ion, None

@@ -1,0 +1,340 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu).  Everything goes through the product
+API, i.e. through the C-ABI of libasora_hip.so; the oracle and the golden vectors are the checkers.
+
+Tolerances (float64 path; north star bar: 1e-5 relative on ionised fraction and column density):
+  * column density vs oracle ............ 1e-12  (pure interpolation arithmetic, no cancellation)
+  * Gamma vs oracle, same constants ..... 1e-9   (Gamma = prefactor*(T(tau_in)-T(tau_out)) cancels;
+                                                  FMA contraction and libm log10 differ by ulps)
+  * Gamma vs the reference Fortran golden, CUDA constants ... 1e-5 (documented ~1e-7 differences)
+  * chemistry vs golden ................. 1e-12
+"""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def asora():
+    import pyc2ray_amd as p
+    from pyc2ray_amd import _capi
+    from pyc2ray_amd.load_extensions import load_asora
+    lib = load_asora()
+    yield p, lib, _capi
+    if p.cuda_is_init():
+        p.device_close()
+
+
+def _setup(p, lib, c, N):
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 8)
+    p.photo_table_to_device(c["thin"], c["thick"])
+    pos0, flux = cases.flat_sources(c["pos"], c["flux"])
+    lib.source_data_to_device(pos0, flux, flux.shape[0])
+    lib.density_to_device(np.ravel(c["ndens"]).astype("float64", copy=True), N)
+    return pos0, flux
+
+
+def _asora_call(lib, c, N, numtau):
+    xh_flat = np.ravel(c["xh"]).astype("float64", copy=True)
+    phi_flat = np.ravel(np.zeros((N, N, N)))
+    cd_flat = np.ravel(np.zeros((N, N, N)))
+    nd_flat = np.ravel(c["ndens"]).astype("float64", copy=True)
+    r = lib.do_all_sources(c["R"], cd_flat, c["sig"], c["dr"], nd_flat, xh_flat, phi_flat, c["flux"].shape[0], N,
+                           c["minlogtau"], c["dlogtau"], numtau)
+    assert r is None
+    return phi_flat.reshape(N, N, N)
+
+
+@pytest.mark.parametrize("name", list(cases.RT_CASES))
+@pytest.mark.parametrize("tables", ["grey", "soft"])
+def test_raytrace_matches_oracle_and_reference(asora, name, tables):
+    p, lib, capi = asora
+    c = cases.rt_case(name, tables)
+    N = c["N"]
+    numtau = c["thin"].shape[0] - 1
+    pos0, flux = _setup(p, lib, c, N)
+    g = np.load(os.path.join(G, "raytrace.npz"))
+    gold = g[f"{name}__{tables}__phi"]
+
+    # default constants = the CUDA library being replaced
+    lib.set_option(capi.OPT_FORTRAN_CONSTANTS, 0)
+    phi = _asora_call(lib, c, N, numtau)
+    ref = O.asora_do_all_sources(c["R"], c["sig"], c["dr"], c["ndens"], c["xh"], pos0, flux, c["thin"], c["thick"],
+                                 c["minlogtau"], c["dlogtau"], NumTau=numtau, flags=O.ASORA_MODE)
+    np.testing.assert_allclose(phi, ref["phi_ion"], rtol=1e-9, atol=0)
+    np.testing.assert_allclose(phi, gold, rtol=1e-5, atol=0)            # north-star bar vs the Fortran
+    gam, ev = lib.last_raytrace_counts()
+    assert gam == int((ref["phi_ion"] != 0).sum()) or flux.shape[0] > 1
+    assert ev >= gam
+
+    # Fortran constants: agrees with the reference Fortran output to rounding
+    lib.set_option(capi.OPT_FORTRAN_CONSTANTS, 1)
+    phi_f = _asora_call(lib, c, N, numtau)
+    lib.set_option(capi.OPT_FORTRAN_CONSTANTS, 0)
+    np.testing.assert_allclose(phi_f, gold, rtol=1e-9, atol=0)
+
+
+@pytest.mark.parametrize("name", ["u16_1src_R8", "l16_7src_R5.5", "l17_3src_Rbox", "l32_5src_R10"])
+def test_column_density_matches_oracle_and_reference(asora, name):
+    p, lib, capi = asora
+    c = cases.rt_case(name, "grey")
+    N = c["N"]
+    pos0, flux = _setup(p, lib, c, N)
+    lib.grid_to_device(capi.GRID_XH_AV, c["xh"])
+    last = flux.shape[0] - 1
+    cd = lib.debug_coldens(c["R"], c["sig"], c["dr"], last, N)
+    ref = O.asora_do_all_sources(c["R"], c["sig"], c["dr"], c["ndens"], c["xh"], pos0, flux, c["thin"], c["thick"],
+                                 c["minlogtau"], c["dlogtau"], NumTau=c["thin"].shape[0] - 1, flags=O.ASORA_MODE,
+                                 want_coldens=True)["coldens"]
+    w = cd != 0
+    assert w.sum() > 0
+    np.testing.assert_allclose(cd[w], ref[w], rtol=1e-12)
+    # every cell that received a rate from this source has a column density
+    only = O.asora_do_all_sources(c["R"], c["sig"], c["dr"], c["ndens"], c["xh"], pos0[3 * last:], flux[last:],
+                                  c["thin"], c["thick"], c["minlogtau"], c["dlogtau"],
+                                  NumTau=c["thin"].shape[0] - 1, flags=O.ASORA_MODE)["phi_ion"]
+    assert np.array_equal(w, only != 0)
+    # and against the reference Fortran's scratch of its last source (sqrt literals differ by 1.8e-8)
+    gold = np.load(os.path.join(G, "raytrace.npz"))[f"{name}__grey__cd"]
+    np.testing.assert_allclose(cd[w], gold[w], rtol=1e-5)
+
+
+def test_numtau_equal_table_length_is_clamped(asora):
+    """evolve3D passes NumTau = len(table) (pyc2ray/evolve.py:124); the reference then reads one
+    element past the table for tau >= 10^maxlogtau.  This build clamps; the oracle does the same."""
+    p, lib, capi = asora
+    c = cases.rt_case("l16_thick", "soft")
+    N = c["N"]
+    pos0, flux = _setup(p, lib, c, N)
+    L = c["thin"].shape[0]
+    phi = _asora_call(lib, c, N, L)
+    ref = O.asora_do_all_sources(c["R"], c["sig"], c["dr"], c["ndens"], c["xh"], pos0, flux, c["thin"], c["thick"],
+                                 c["minlogtau"], c["dlogtau"], NumTau=L, flags=O.ASORA_MODE)["phi_ion"]
+    assert np.isfinite(phi).all()
+    np.testing.assert_allclose(phi, ref, rtol=1e-9, atol=0)
+
+
+def test_z_transposed_layout_is_only_a_layout(asora):
+    p, lib, capi = asora
+    c = cases.rt_case("l32_5src_R10", "soft")
+    N = c["N"]
+    _setup(p, lib, c, N)
+    lib.set_option(capi.OPT_Z_TRANSPOSED, 1)
+    a = _asora_call(lib, c, N, c["thin"].shape[0] - 1)
+    lib.set_option(capi.OPT_Z_TRANSPOSED, 0)
+    b = _asora_call(lib, c, N, c["thin"].shape[0] - 1)
+    lib.set_option(capi.OPT_Z_TRANSPOSED, 1)
+    np.testing.assert_allclose(a, b, rtol=1e-13, atol=0)
+
+
+def test_grey_notables_option(asora):
+    p, lib, capi = asora
+    c = cases.rt_case("l16_7src_R5.5", "grey")
+    N = c["N"]
+    pos0, flux = _setup(p, lib, c, N)
+    lib.set_option(capi.OPT_GREY_NOTABLES, 1)
+    try:
+        phi = _asora_call(lib, c, N, c["thin"].shape[0] - 1)
+    finally:
+        lib.set_option(capi.OPT_GREY_NOTABLES, 0)
+    ref = O.asora_do_all_sources(c["R"], c["sig"], c["dr"], c["ndens"], c["xh"], pos0, flux, c["thin"], c["thick"],
+                                 c["minlogtau"], c["dlogtau"], flags=O.ASORA_MODE | O.GREY)["phi_ion"]
+    np.testing.assert_allclose(phi, ref, rtol=1e-9, atol=0)
+
+
+@pytest.mark.parametrize("N,R", [(48, 1000.0), (40, 17.3)])
+def test_large_radius_and_window_clipping(asora, N, R):
+    """R beyond the box: the trace is cut by the periodic window (raytracing.cu:122-123,241) and by
+    q_max (raytracing.cu:101).  N=48 full box needs 6*25^2*8 B = 30 KB of LDS shells."""
+    p, lib, capi = asora
+    nd, xh, dr = cases.grid(N, "lognormal", 31, 0.04)
+    pos, flux = cases.sources(N, 2, 32, flux=2.0)
+    thin, thick, dlog = cases.soft_tables()
+    c = dict(N=N, ndens=nd, xh=xh, dr=dr, pos=pos, flux=flux, R=R, thin=thin, thick=thick, dlogtau=dlog,
+             minlogtau=cases.MINLOGTAU, sig=cases.SIG)
+    pos0, fl = _setup(p, lib, c, N)
+    phi = _asora_call(lib, c, N, thin.shape[0] - 1)
+    ref = O.asora_do_all_sources(R, cases.SIG, dr, nd, xh, pos0, fl, thin, thick, cases.MINLOGTAU, dlog,
+                                 NumTau=thin.shape[0] - 1, flags=O.ASORA_MODE)["phi_ion"]
+    assert (ref != 0).sum() == (phi != 0).sum()
+    np.testing.assert_allclose(phi, ref, rtol=1e-9, atol=0)
+
+
+def test_shells_beyond_lds_use_global_scratch(asora):
+    """N=168 full box: shell buffers 6*85^2*8 B = 347 KB > 160 KB LDS -> global-scratch variant."""
+    p, lib, capi = asora
+    N = 168
+    nd, xh, dr = cases.grid(N, "lognormal", 41, 0.02)
+    pos, flux = cases.sources(N, 1, 42, flux=5.0)
+    thin, thick, dlog = cases.grey_tables()
+    c = dict(N=N, ndens=nd, xh=xh, dr=dr, pos=pos, flux=flux, R=1000.0, thin=thin, thick=thick, dlogtau=dlog,
+             minlogtau=cases.MINLOGTAU, sig=cases.SIG)
+    pos0, fl = _setup(p, lib, c, N)
+    phi = _asora_call(lib, c, N, thin.shape[0] - 1)
+    ref = O.asora_do_all_sources(1000.0, cases.SIG, dr, nd, xh, pos0, fl, thin, thick, cases.MINLOGTAU, dlog,
+                                 NumTau=thin.shape[0] - 1, flags=O.ASORA_MODE)["phi_ion"]
+    np.testing.assert_allclose(phi, ref, rtol=1e-9, atol=0)
+
+
+# ---- chemistry -------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,seed", [(16, 21), (12, 22)])
+@pytest.mark.parametrize("order", ["F", "C"])
+def test_global_pass_matches_reference(asora, N, seed, order):
+    from pyc2ray_amd.load_extensions import load_c2ray
+    g = np.load(os.path.join(G, "global_pass.npz"))
+    c = cases.chem_case(N, seed)
+    mk = lambda a: np.array(a, order=order, copy=True)
+    xh_av, xh_int, xh0 = mk(c["xh_av"]), mk(c["xh_intermed"]), mk(c["xh"])
+    conv = load_c2ray().chemistry.global_pass(c["dt"], mk(c["ndens"]), mk(c["temp"]), xh0, xh_av, xh_int,
+                                              mk(c["phi_ion"]), c["bh00"], c["albpow"], c["colh0"], c["temph0"],
+                                              c["abu_c"])
+    np.testing.assert_allclose(xh_av, g[f"n{N}_xh_av"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(xh_int, g[f"n{N}_xh_intermed"], rtol=1e-12, atol=0)
+    assert conv == int(g[f"n{N}_conv"])
+    assert np.array_equal(xh0, c["xh"])                       # xh itself is not modified
+
+
+def test_chemistry_tutorial_known_answer_on_gpu(asora):
+    import pyc2ray_amd as p
+    mesh = (10, 10, 10)
+    np.random.seed(2023)
+    ndens = np.random.normal(loc=1e-7, scale=1e-8, size=mesh)
+    temp = np.ones(mesh) * 1e4
+    xh = np.random.uniform(low=0, high=0.1, size=mesh)
+    phi = np.random.uniform(low=1e-13, high=1e-12, size=mesh)
+    assert round(xh.mean(), 3) == 0.050
+    for _ in range(100):
+        xh = p.hydrogenODE(dt=50 * 3.15576e7, ndens=ndens, temp=temp, xh=xh, phi_ion=phi)
+    assert round(xh.mean(), 3) == 0.127                       # tutorials/chemistry_solver.ipynb cell 5
+
+
+# ---- the whole step --------------------------------------------------------------------------
+@pytest.mark.parametrize("order", ["F", "C"])
+def test_evolve3D_matches_oracle_loop(asora, order, tmp_path):
+    from evolve_oracle import evolve3D_oracle
+    p, lib, capi = asora
+    N = 24
+    nd, xh, dr = cases.grid(N, "lognormal", 51, 0.15, xlo=1e-4, xhi=2e-3)
+    temp = np.full((N, N, N), 1e4)
+    pos, flux = cases.sources(N, 4, 52, flux=30.0)
+    thin, thick, dlog = cases.soft_tables()
+    mk = lambda a: np.array(a, order=order, copy=True)
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 8)
+    p.photo_table_to_device(thin, thick)
+    dt = 3.15576e13 * 5
+    args = dict(dt=dt, dr=dr, src_flux=flux, src_pos=pos, use_gpu=True, max_subbox=1000, subboxsize=N,
+                loss_fraction=1e-2, temp=mk(temp), ndens=mk(nd), xh=mk(xh), photo_thin_table=thin,
+                photo_thick_table=thick, minlogtau=cases.MINLOGTAU, dlogtau=dlog, R_max_LLS=9.0,
+                convergence_fraction=1e-4, sig=cases.SIG, bh00=cases.BH00, albpow=cases.ALBPOW, colh0=cases.COLH0,
+                temph0=cases.TEMPH0, abu_c=cases.ABU_C, logfile=str(tmp_path / "log.txt"), quiet=True)
+    xh_new, phi = p.evolve3D(**args)
+    niter = p.evolve._evolve.last_niter
+    x_ref, phi_ref, niter_ref, hist = evolve3D_oracle(dt, dr, flux, pos, temp, nd, xh, thin, thick, cases.MINLOGTAU,
+                                                      dlog, 9.0, 1e-4, cases.SIG, cases.BH00, cases.ALBPOW,
+                                                      cases.COLH0, cases.TEMPH0, cases.ABU_C)
+    assert niter == niter_ref and niter >= 2
+    assert xh_new.shape == (N, N, N) and xh_new.flags[f"{order}_CONTIGUOUS"]
+    np.testing.assert_allclose(xh_new, x_ref, rtol=1e-8, atol=0)
+    np.testing.assert_allclose(phi, phi_ref, rtol=1e-7, atol=0)
+    assert xh_new.max() > 0.5                                  # the sources did ionise their surroundings
+    assert "Multiple source convergence reached." in open(tmp_path / "log.txt").read()
+
+
+# ---- size-independent properties at the benchmark size ------------------------------------------
+def test_full_size_properties_256(asora):
+    """256^3, 64 sources, R=32: linearity in flux, superposition over sources, and the exact count of
+    rate-receiving (source,cell) pairs."""
+    p, lib, capi = asora
+    N, Ns, R = 256, 64, 32.0
+    nd, xh, dr = cases.grid(N, "lognormal", 61, 0.02)
+    pos, flux = cases.sources(N, Ns, 100, flux=1.0)
+    thin, thick, dlog = cases.soft_tables(20000)
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 64)
+    p.photo_table_to_device(thin, thick)
+    lib.grid_to_device(capi.GRID_NDENS, nd)
+    lib.grid_to_device(capi.GRID_XH_AV, xh)
+    numtau = thin.shape[0] - 1
+
+    def trace(pos1, fl):
+        p0, f0 = cases.flat_sources(pos1, fl)
+        lib.source_data_to_device(p0, f0, f0.shape[0])
+        lib.raytrace_device(R, cases.SIG, dr, 0, f0.shape[0], cases.MINLOGTAU, dlog, numtau)
+        return lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+
+    full = trace(pos, flux)
+    gam, ev = lib.last_raytrace_counts()
+    # number of lattice points with |d|^2 <= R^2 (R < N/2: no clipping)
+    r = np.arange(-32, 33)
+    inside = int(((r[:, None, None] ** 2 + r[None, :, None] ** 2 + r[None, None, :] ** 2) <= R * R).sum())
+    assert gam == Ns * inside
+    assert ev >= gam and ev < 1.15 * gam
+    assert np.isfinite(full).all() and (full >= 0).all()
+    # linearity: tripling every flux triples Gamma
+    np.testing.assert_allclose(trace(pos, 3.0 * flux), 3.0 * full, rtol=1e-12, atol=0)
+    # superposition: two halves of the source list add up (atomic summation order aside)
+    a = trace(pos[:, :Ns // 2], flux[:Ns // 2])
+    b = trace(pos[:, Ns // 2:], flux[Ns // 2:])
+    np.testing.assert_allclose(a + b, full, rtol=1e-11, atol=0)
+    # sub-range tracing equals tracing the sub-list
+    p0, f0 = cases.flat_sources(pos, flux)
+    lib.source_data_to_device(p0, f0, Ns)
+    lib.raytrace_device(R, cases.SIG, dr, Ns // 2, Ns - Ns // 2, cases.MINLOGTAU, dlog, numtau)
+    b2 = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+    np.testing.assert_allclose(b2, b, rtol=1e-11, atol=0)
+    # one source of the list against the oracle on the full-size grid (R=32: ~0.1 s of CPU)
+    ref1 = O.asora_do_all_sources(R, cases.SIG, dr, nd, xh, p0[:3], f0[:1], thin, thick, cases.MINLOGTAU, dlog,
+                                  NumTau=numtau, flags=O.ASORA_MODE)["phi_ion"]
+    np.testing.assert_allclose(trace(pos[:, :1], flux[:1]), ref1, rtol=1e-9, atol=0)
+
+
+def test_uniform_medium_is_mirror_symmetric(asora):
+    """Uniform density, one central source: Gamma is symmetric under every reflection through the
+    source (the 8 octants are computed by 8 different workgroups)."""
+    p, lib, capi = asora
+    N = 64
+    nd, xh, dr = cases.grid(N, "uniform", 0, 0.1)
+    pos = np.array([[32], [32], [32]])
+    flux = np.array([1e3])
+    thin, thick, dlog = cases.grey_tables()
+    c = dict(N=N, ndens=nd, xh=xh, dr=dr, pos=pos, flux=flux, R=25.0, thin=thin, thick=thick, dlogtau=dlog,
+             minlogtau=cases.MINLOGTAU, sig=cases.SIG)
+    _setup(p, lib, c, N)
+    phi = _asora_call(lib, c, N, thin.shape[0] - 1)
+    s = 31                                                      # 0-based source index
+    blk = phi[s - 25:s + 26, s - 25:s + 26, s - 25:s + 26]
+    for ax in range(3):
+        np.testing.assert_allclose(blk, np.flip(blk, axis=ax), rtol=1e-13, atol=0)
+    np.testing.assert_allclose(blk, blk.transpose(1, 0, 2), rtol=1e-13, atol=0)
+    np.testing.assert_allclose(blk, blk.transpose(2, 1, 0), rtol=1e-13, atol=0)
+
+
+def test_error_behaviour(asora):
+    p, lib, capi = asora
+    if p.cuda_is_init():
+        p.device_close()
+    with pytest.raises(RuntimeError):
+        p.device_close()                                        # asora_core.py:46-47
+    with pytest.raises(RuntimeError):
+        p.photo_table_to_device(np.ones(4), np.ones(4))         # asora_core.py:57
+    p.device_init(16, 8)
+    with pytest.raises(RuntimeError, match="outside the mesh"):
+        lib.source_data_to_device(np.array([0, 0, 16], dtype=np.int32), np.ones(1), 1)
+    with pytest.raises(TypeError, match="coldensh_out must be Array of type double"):
+        lib.do_all_sources(4.0, np.zeros(16 ** 3, dtype=np.float32), 1.0, 1.0, np.zeros(16 ** 3), np.zeros(16 ** 3),
+                           np.zeros(16 ** 3), 1, 16, -20.0, 0.01, 10)
+    with pytest.raises(RuntimeError, match="does not match"):
+        lib.density_to_device(np.zeros(8 ** 3), 8)
+    p.device_close()

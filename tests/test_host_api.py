@@ -1,0 +1,113 @@
+"""CPU: host-side logic of the product package and the C-ABI surface (no GPU compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    from pyc2ray_amd import _capi
+    return _capi
+
+
+def test_library_exports_every_declared_symbol(built):
+    header = open(os.path.join(ROOT, "include", "asora_hip.h")).read()
+    declared = set(re.findall(r"\b((?:asora|c2ray)_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(built.SIGNATURES), declared ^ set(built.SIGNATURES)
+    lib = ctypes.CDLL(built.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_library_is_built_for_gfx950(built):
+    blob = open(built.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    assert b"raytrace_octant_kernel" in blob and b"chemistry_kernel" in blob
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "pyc2ray_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_guards_before_device_init(built):
+    import pyc2ray_amd as p
+    assert not p.cuda_is_init()
+    with pytest.raises(RuntimeError, match="GPU not initialized"):
+        p.device_close()
+    with pytest.raises(RuntimeError, match="GPU not initialized"):
+        p.photo_table_to_device(np.ones(3), np.ones(3))
+    N = 8
+    g = np.ones((N, N, N))
+    with pytest.raises(RuntimeError, match="GPU not initialized"):
+        p.evolve3D(1.0, 1.0, np.ones(1), np.ones((3, 1)), True, 10, 4, 0.01, g, g, g, np.ones(5), np.ones(5),
+                   -20.0, 0.1, 4.0, 1e-4, 1e-18, 1.0, 1.0, 1.0, 1.0, 1.0, quiet=True, logfile=None)
+    with pytest.raises(RuntimeError, match="GPU not initialized"):
+        p.do_raytracing(1.0, np.ones(1), np.ones((3, 1)), True, 10, 4, 0.01, g, g, np.ones(5), np.ones(5),
+                        np.ones(5), np.ones(5), -20.0, 0.1, 4.0, 1e-18, quiet=True, logfile=None)
+
+
+def test_cpu_path_is_refused_loudly(built):
+    import pyc2ray_amd as p
+    N = 8
+    g = np.ones((N, N, N))
+    with pytest.raises(RuntimeError, match="no CPU compute path"):
+        p.evolve3D(1.0, 1.0, np.ones(1), np.ones((3, 1)), False, 10, 4, 0.01, g, g, g, np.ones(5), np.ones(5),
+                   -20.0, 0.1, 4.0, 1e-4, 1e-18, 1.0, 1.0, 1.0, 1.0, 1.0, quiet=True, logfile=None)
+
+
+def test_errors_come_back_as_runtime_errors_with_message(built):
+    from pyc2ray_amd.load_extensions import load_asora
+    lib = load_asora()
+    with pytest.raises(RuntimeError, match="not initialised"):
+        lib.density_to_device(np.zeros(8), 2)
+    with pytest.raises(RuntimeError):          # no GPU here: hipSetDevice fails, message carried over
+        lib.device_init(8, 1)
+
+
+def test_format_sources_layout():
+    from pyc2ray_amd.utils.sourceutils import format_sources
+    pos = np.array([[1, 4], [2, 5], [3, 6]], dtype=float)          # (3, 2), 1-based
+    flat, flux = format_sources(pos, np.array([1, 2]))
+    assert flat.dtype == np.int32 and flux.dtype == np.float64
+    assert flat.tolist() == [0, 1, 2, 3, 4, 5]                     # x0,y0,z0,x1,y1,z1 zero-based
+    with pytest.raises(ValueError):
+        format_sources(np.ones((2, 3)), np.ones(3))
+
+
+def test_source_file_round_trip(tmp_path):
+    from pyc2ray_amd.utils.sourceutils import generate_test_sourcefile, read_test_sources
+    fn = str(tmp_path / "src.txt")
+    generate_test_sourcefile(fn, 64, 7, 5e52, seed=100)
+    pos, flux = read_test_sources(fn, 5)
+    rng = np.random.RandomState(100)
+    want = (1 + rng.randint(0, 64, size=21)).reshape(7, 3)[:5].T
+    assert np.array_equal(pos, want) and np.allclose(flux, 5e4)
+    with pytest.raises(ValueError):
+        read_test_sources(fn, 8)
+
+
+def test_tau_and_blackbody_tables():
+    from pyc2ray_amd.radiation import BlackBodySource, make_tau_table
+    tau, dlog = make_tau_table(-20.0, 4.0, 200)
+    assert tau.shape == (201,) and tau[0] == 0.0 and np.isclose(tau[1], 1e-20) and np.isclose(dlog, 0.12)
+    ev2fr = 0.241838e15
+    grey = BlackBodySource(5e4, True, ev2fr * 13.598, 2.8)
+    thin, thick = grey.make_photo_table(tau, ev2fr * 13.598, 10 * ev2fr * 54.416, 1e48)
+    # grey opacity: both tables are S_star * exp(-tau) in closed form
+    np.testing.assert_allclose(thick, 1e48 * np.exp(-tau), rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(thin, 1e48 * np.exp(-tau), rtol=1e-9, atol=1e-300)
+    pl = BlackBodySource(1e5, False, ev2fr * 13.598, 2.8)
+    thin, thick = pl.make_photo_table(tau, ev2fr * 13.598, 10 * ev2fr * 54.416, 1e48)
+    assert np.isclose(thick[0], 1e48) and np.all(np.diff(thick) <= 1e-9 * thick[0]) and thin[0] < thick[0]
