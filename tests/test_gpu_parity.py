@@ -6,7 +6,7 @@ Tolerances (float64 path; north star bar: 1e-5 relative on ionised fraction and 
   * Gamma vs oracle, same constants ..... 1e-9   (Gamma = prefactor*(T(tau_in)-T(tau_out)) cancels;
                                                   FMA contraction and libm log10 differ by ulps)
   * Gamma vs the reference Fortran golden, CUDA constants ... 1e-5 (documented ~1e-7 differences)
-  * chemistry vs golden ................. 1e-12
+  * chemistry vs golden ................. 1e-9   (device exp/pow vs libm, amplified by |delth*dt|)
 """
 import os
 
@@ -197,8 +197,8 @@ def test_global_pass_matches_reference(asora, N, seed, order):
     conv = load_c2ray().chemistry.global_pass(c["dt"], mk(c["ndens"]), mk(c["temp"]), xh0, xh_av, xh_int,
                                               mk(c["phi_ion"]), c["bh00"], c["albpow"], c["colh0"], c["temph0"],
                                               c["abu_c"])
-    np.testing.assert_allclose(xh_av, g[f"n{N}_xh_av"], rtol=1e-12, atol=0)
-    np.testing.assert_allclose(xh_int, g[f"n{N}_xh_intermed"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(xh_av, g[f"n{N}_xh_av"], rtol=1e-9, atol=0)
+    np.testing.assert_allclose(xh_int, g[f"n{N}_xh_intermed"], rtol=1e-9, atol=0)
     assert conv == int(g[f"n{N}_conv"])
     assert np.array_equal(xh0, c["xh"])                       # xh itself is not modified
 
@@ -283,7 +283,8 @@ def test_full_size_properties_256(asora):
     assert ev >= gam and ev < 1.15 * gam
     assert np.isfinite(full).all() and (full >= 0).all()
     # linearity: tripling every flux triples Gamma
-    np.testing.assert_allclose(trace(pos, 3.0 * flux), 3.0 * full, rtol=1e-12, atol=0)
+    # (prefactor*T_in - prefactor*T_out rounds differently for 3x the prefactor: cancellation ~1e4 ulps)
+    np.testing.assert_allclose(trace(pos, 3.0 * flux), 3.0 * full, rtol=1e-10, atol=0)
     # superposition: two halves of the source list add up (atomic summation order aside)
     a = trace(pos[:, :Ns // 2], flux[:Ns // 2])
     b = trace(pos[:, Ns // 2:], flux[Ns // 2:])
@@ -317,8 +318,9 @@ def test_uniform_medium_is_mirror_symmetric(asora):
     blk = phi[s - 25:s + 26, s - 25:s + 26, s - 25:s + 26]
     for ax in range(3):
         np.testing.assert_allclose(blk, np.flip(blk, axis=ax), rtol=1e-13, atol=0)
-    np.testing.assert_allclose(blk, blk.transpose(1, 0, 2), rtol=1e-13, atol=0)
-    np.testing.assert_allclose(blk, blk.transpose(2, 1, 0), rtol=1e-13, atol=0)
+    # axis swaps change the order of a few sums (dist2, weights): equal to rounding, not bitwise
+    np.testing.assert_allclose(blk, blk.transpose(1, 0, 2), rtol=1e-10, atol=0)
+    np.testing.assert_allclose(blk, blk.transpose(2, 1, 0), rtol=1e-10, atol=0)
 
 
 def test_error_behaviour(asora):
