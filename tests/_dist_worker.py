@@ -1,0 +1,58 @@
+"""Worker of tests/test_dist_gloo.py: one rank of a world_size-N gloo job on the CPU."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    import cases
+    from fake_backend import OracleAsora
+    import pyc2ray_amd.evolve as ev
+    from pyc2ray_amd import dist as pd
+
+    r, w, _ = pd.init_process_group_from_env("gloo")
+    assert (r, w) == (rank, world)
+    comm = pd.TorchComm()
+    assert comm.Get_rank() == rank and comm.Get_size() == world
+
+    # mpi4py-flavoured surface
+    buf = np.full(5, float(rank + 1))
+    comm.Allreduce(pd.MPI.IN_PLACE, [buf, pd.MPI.DOUBLE], op=pd.MPI.SUM)
+    assert np.all(buf == sum(range(1, world + 1)))
+    b2 = np.arange(4.0) if rank == 0 else np.zeros(4)
+    comm.Bcast([b2, pd.MPI.DOUBLE], root=0)
+    assert np.array_equal(b2, np.arange(4.0))
+    b3 = np.full(3, float(rank + 1))
+    if rank == 0:
+        comm.Reduce(pd.MPI.IN_PLACE, [b3, pd.MPI.DOUBLE], op=pd.MPI.SUM, root=0)
+        assert np.all(b3 == sum(range(1, world + 1)))
+    else:
+        comm.Reduce([b3, pd.MPI.DOUBLE], None, op=pd.MPI.SUM, root=0)
+
+    # the sharded evolve step on the oracle-backed stand-in
+    N = 16
+    nd, xh, dr = cases.grid(N, "lognormal", 51, 0.15, xlo=1e-4, xhi=2e-3)
+    temp = np.full((N, N, N), 1e4)
+    pos, flux = cases.sources(N, 5, 52, flux=30.0)       # 5 sources over 2 ranks: 2 + 3
+    thin, thick, dlog = cases.soft_tables()
+    fake = OracleAsora(thin, thick)
+    ev.load_asora = lambda: fake
+    ev.cuda_is_init = lambda: True
+    xh_new, phi = ev.evolve3D_MPI(3.15576e13 * 5, dr, flux, pos, True, 1000, N, 1e-2, pd.MPI, comm, rank, world,
+                                  temp, nd, xh, thin, thick, cases.MINLOGTAU, dlog, 6.0, 1e-4, cases.SIG,
+                                  cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C,
+                                  logfile=None, quiet=True)
+    np.savez(out, xh=xh_new, phi=phi, niter=ev._evolve.last_niter, nsrc=fake.flux.shape[0])
+    comm.Barrier()
+
+
+if __name__ == "__main__":
+    main()

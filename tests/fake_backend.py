@@ -1,0 +1,49 @@
+"""TEST INFRASTRUCTURE: a host-memory stand-in for the ctypes `libasora` object, backed by the CPU
+oracle.  It lets the world_size-2 gloo tests exercise the product's source sharding, all-reduce and
+convergence logic (pyc2ray_amd/evolve.py, pyc2ray_amd/dist.py) on a machine without a GPU.  It is
+injected by monkeypatching inside tests only; the product never imports it."""
+import numpy as np
+
+from oracle import oracle as O
+
+
+class OracleAsora:
+    def __init__(self, thin, thick):
+        self.thin, self.thick = thin, thick
+        self.g = {}
+        self.pos = self.flux = None
+
+    def source_data_to_device(self, pos, flux, n):
+        self.pos, self.flux = np.array(pos[:3 * n]), np.array(flux[:n])
+
+    def grid_to_device(self, which, a):
+        self.g[which] = np.ascontiguousarray(a, dtype=np.float64).copy()
+
+    def grid_copy(self, dst, src):
+        self.g[dst] = self.g[src].copy()
+
+    def grid_to_host(self, which, out):
+        out[...] = self.g[which]
+        return out
+
+    def device_ptr(self, which):
+        return 0
+
+    def synchronize(self):
+        pass
+
+    def raytrace_device(self, R, sig, dr, src_begin, src_count, minlogtau, dlogtau, NumTau):
+        N = self.g[0].shape[0]
+        if src_count == 0:
+            self.g[2] = np.zeros((N, N, N))
+            return
+        sl = slice(3 * src_begin, 3 * (src_begin + src_count))
+        self.g[2] = O.asora_do_all_sources(R, sig, dr, self.g[0], self.g[1], self.pos[sl],
+                                           self.flux[src_begin:src_begin + src_count], self.thin, self.thick,
+                                           minlogtau, dlogtau, NumTau=NumTau, flags=O.ASORA_MODE)["phi_ion"]
+
+    def chemistry_device(self, dt, bh00, albpow, colh0, temph0, abu_c):
+        xa, xi, conv, _ = O.global_pass(dt, self.g[0], self.g[3], self.g[4], self.g[1], self.g[5], self.g[2],
+                                        bh00, albpow, colh0, temph0, abu_c)
+        self.g[1], self.g[5] = xa, xi
+        return conv, float(np.sum(xi)), float(np.sum(1.0 - xi))

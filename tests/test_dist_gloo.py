@@ -1,0 +1,54 @@
+"""CPU: the multi-rank path (source sharding + all-reduce of the rate grid + replicated chemistry)
+with world_size 2 over gloo.  The per-rank compute is the oracle-backed stand-in of
+tests/fake_backend.py; what is under test is pyc2ray_amd/evolve.py::evolve3D_MPI and
+pyc2ray_amd/dist.py::TorchComm."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+import cases
+from evolve_oracle import evolve3D_oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return str(port)
+
+
+def test_two_ranks_match_single_process(tmp_path):
+    world = 2
+    port = _free_port()
+    outs = [str(tmp_path / f"r{r}.npz") for r in range(world)]
+    env = dict(os.environ, PYC2RAY_AMD_NO_TORCH="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), str(r), str(world), port,
+                               outs[r]], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    logs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log
+    res = [np.load(o) for o in outs]
+    # contiguous source blocks, last rank takes the remainder (pyc2ray/evolve.py:362-367)
+    assert [int(r["nsrc"]) for r in res] == [2, 3]
+    # every rank returns the same fields
+    assert np.array_equal(res[0]["xh"], res[1]["xh"]) and np.array_equal(res[0]["phi"], res[1]["phi"])
+    assert int(res[0]["niter"]) == int(res[1]["niter"])
+
+    N = 16
+    nd, xh, dr = cases.grid(N, "lognormal", 51, 0.15, xlo=1e-4, xhi=2e-3)
+    temp = np.full((N, N, N), 1e4)
+    pos, flux = cases.sources(N, 5, 52, flux=30.0)
+    thin, thick, dlog = cases.soft_tables()
+    x_ref, phi_ref, niter_ref, _ = evolve3D_oracle(3.15576e13 * 5, dr, flux, pos, temp, nd, xh, thin, thick,
+                                                   cases.MINLOGTAU, dlog, 6.0, 1e-4, cases.SIG, cases.BH00,
+                                                   cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C)
+    assert int(res[0]["niter"]) == niter_ref
+    np.testing.assert_allclose(res[0]["xh"], x_ref, rtol=1e-10, atol=0)
+    np.testing.assert_allclose(res[0]["phi"], phi_ref, rtol=1e-10, atol=0)
