@@ -62,6 +62,7 @@ static int release_all()
     drop(st.thin); drop(st.thick); st.table_len = 0;
     drop(st.src_pos); drop(st.src_flux); st.num_src = 0;
     drop(st.shell_scratch); st.shell_scratch_bytes = 0;
+    release_geometry(st);
     st.init = false; st.N = 0; st.ncell = 0;
     return 0;
 }
@@ -138,7 +139,7 @@ int asora_device_init_ex(int N, int num_src_par, int device_id)
 {
     clear_error();
     State &st = g_state;
-    if (N < 2) return fail(1, "device_init: N must be >= 2");
+    if (N < 2 || N > 1600) return fail(1, "device_init: N must be in [2, 1600] (32-bit cell indices)");
     if (st.init) release_all();
     if (st.stream && device_id != st.device) return fail(1, "device_init: the device cannot change within a process");
     st.device = device_id;

@@ -4,10 +4,23 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "../../include/asora_hip.h"
 
 namespace asora {
+
+// Source-independent geometry of one octant, tabulated on the host (raytrace.hip), device pointers.
+// Cells of Chebyshev shell s are entries [shell_off[s], shell_off[s+1]) of the per-cell arrays.
+struct OctGeomDev {
+    int S;                       // last shell
+    const uint32_t *shell_off;   // S+2 entries
+    const uint32_t *abc;         // |di| | |dj|<<10 | |dk|<<20 | face<<30   (face 2: dk=s, 1: dj=s, 0: di=s)
+    const double *w1, *w2, *w3, *w4;   // bilinear weights of the four upstream corners (cinterp s1..s4)
+    const double *path;          // path length through the cell, in cell units (cinterp)
+    const double *n2;            // |d|^2 in cell units
+    const uint4 *nbr;            // shell-buffer slots of the four corners in shell s-1
+};
 
 // ---------------------------------------------------------------------------------------------
 // Process-global device state (the role of src/asora/memory.cu:20-29)
@@ -35,6 +48,14 @@ struct State {
     int32_t *src_pos = nullptr;
     double *src_flux = nullptr;
     int num_src = 0;
+
+    // raytracing geometry tables (built once per (N, R, dr), see raytrace.hip)
+    std::vector<void *> geom_owned;
+    const OctGeomDev *geom_dev = nullptr;   // [8]
+    const double2 *logtab_dev = nullptr;
+    bool geom_valid = false;
+    int geom_N = 0, geom_S = 0, geom_max_cells = 0;
+    double geom_R = 0.0, geom_dr = 0.0;
 
     // shell scratch for traces whose shell buffers exceed LDS
     double *shell_scratch = nullptr;
@@ -81,16 +102,17 @@ struct KernelTimer {
 // ---------------------------------------------------------------------------------------------
 struct RtParams {
     int N;
-    int S;                 // last Chebyshev shell to process
-    int W;                 // row stride of a face in the shell buffers
-    int q_max;             // octahedral cut of the reference (raytracing.cu:101)
-    int ext_pos, ext_neg;  // periodic window: +side last_r, -side -last_l (raytracing.cu:122-123)
-    double R, R2;          // Rmax_LLS and its square as the reference forms it
+    int S;                 // last Chebyshev shell over all octants
+    int max_cells;         // largest shell; slot max_cells of a shell buffer holds 0.0
+    double R;
     double sig, dr;
     double minlogtau, dlogtau, numtau_f;
+    double lut_k1, lut_k0; // table index = 1 + (log10 tau - minlogtau)/dlogtau = lut_k1*log2(tau) + lut_k0
     int NumTau, table_len;
     int fortran_consts, grey, z_transposed;
     int src_begin, src_count;
+    const OctGeomDev *geom;     // [8]
+    const double2 *logtab;      // 128 x {1/c, log2 c}
     const double *nhi, *nhi_t;
     double *phi, *phi_t;
     const double *thin, *thick;
@@ -101,6 +123,7 @@ struct RtParams {
     unsigned long long *counters;
 };
 
+void release_geometry(State &st);
 int launch_prepare_nhi(State &st, bool need_transposed);
 int launch_finish_phi(State &st);
 int launch_raytrace(State &st, RtParams &p, bool dump);

@@ -3,8 +3,11 @@ API, i.e. through the C-ABI of libasora_hip.so; the oracle and the golden vector
 
 Tolerances (float64 path; north star bar: 1e-5 relative on ionised fraction and column density):
   * column density vs oracle ............ 1e-12  (pure interpolation arithmetic, no cancellation)
-  * Gamma vs oracle, same constants ..... 1e-9   (Gamma = prefactor*(T(tau_in)-T(tau_out)) cancels;
-                                                  FMA contraction and libm log10 differ by ulps)
+  * Gamma vs oracle, same constants ..... 1e-8   (Gamma = prefactor*(T(tau_in)-T(tau_out)) cancels: an
+                                                  ulp of log10(tau) -- libm vs the kernel's log2 --
+                                                  moves the table index by ~1e-12 and Gamma by
+                                                  ~1e-12*T/dT; the reference's own two paths differ
+                                                  by the same mechanism)
   * Gamma vs the reference Fortran golden, CUDA constants ... 1e-5 (documented ~1e-7 differences)
   * chemistry vs golden ................. 1e-9   (device exp/pow vs libm, amplified by |delth*dt|)
 """
@@ -19,6 +22,7 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GAMMA_RTOL = 1e-8
 
 
 @pytest.fixture(scope="module")
@@ -70,7 +74,7 @@ def test_raytrace_matches_oracle_and_reference(asora, name, tables):
     phi = _asora_call(lib, c, N, numtau)
     ref = O.asora_do_all_sources(c["R"], c["sig"], c["dr"], c["ndens"], c["xh"], pos0, flux, c["thin"], c["thick"],
                                  c["minlogtau"], c["dlogtau"], NumTau=numtau, flags=O.ASORA_MODE)
-    np.testing.assert_allclose(phi, ref["phi_ion"], rtol=1e-9, atol=0)
+    np.testing.assert_allclose(phi, ref["phi_ion"], rtol=GAMMA_RTOL, atol=0)
     np.testing.assert_allclose(phi, gold, rtol=1e-5, atol=0)            # north-star bar vs the Fortran
     gam, ev = lib.last_raytrace_counts()
     assert gam == int((ref["phi_ion"] != 0).sum()) or flux.shape[0] > 1
@@ -80,7 +84,7 @@ def test_raytrace_matches_oracle_and_reference(asora, name, tables):
     lib.set_option(capi.OPT_FORTRAN_CONSTANTS, 1)
     phi_f = _asora_call(lib, c, N, numtau)
     lib.set_option(capi.OPT_FORTRAN_CONSTANTS, 0)
-    np.testing.assert_allclose(phi_f, gold, rtol=1e-9, atol=0)
+    np.testing.assert_allclose(phi_f, gold, rtol=GAMMA_RTOL, atol=0)
 
 
 @pytest.mark.parametrize("name", ["u16_1src_R8", "l16_7src_R5.5", "l17_3src_Rbox", "l32_5src_R10"])
@@ -120,7 +124,7 @@ def test_numtau_equal_table_length_is_clamped(asora):
     ref = O.asora_do_all_sources(c["R"], c["sig"], c["dr"], c["ndens"], c["xh"], pos0, flux, c["thin"], c["thick"],
                                  c["minlogtau"], c["dlogtau"], NumTau=L, flags=O.ASORA_MODE)["phi_ion"]
     assert np.isfinite(phi).all()
-    np.testing.assert_allclose(phi, ref, rtol=1e-9, atol=0)
+    np.testing.assert_allclose(phi, ref, rtol=GAMMA_RTOL, atol=0)
 
 
 def test_z_transposed_layout_is_only_a_layout(asora):
@@ -148,7 +152,7 @@ def test_grey_notables_option(asora):
         lib.set_option(capi.OPT_GREY_NOTABLES, 0)
     ref = O.asora_do_all_sources(c["R"], c["sig"], c["dr"], c["ndens"], c["xh"], pos0, flux, c["thin"], c["thick"],
                                  c["minlogtau"], c["dlogtau"], flags=O.ASORA_MODE | O.GREY)["phi_ion"]
-    np.testing.assert_allclose(phi, ref, rtol=1e-9, atol=0)
+    np.testing.assert_allclose(phi, ref, rtol=GAMMA_RTOL, atol=0)
 
 
 @pytest.mark.parametrize("N,R", [(48, 1000.0), (40, 17.3)])
@@ -166,7 +170,7 @@ def test_large_radius_and_window_clipping(asora, N, R):
     ref = O.asora_do_all_sources(R, cases.SIG, dr, nd, xh, pos0, fl, thin, thick, cases.MINLOGTAU, dlog,
                                  NumTau=thin.shape[0] - 1, flags=O.ASORA_MODE)["phi_ion"]
     assert (ref != 0).sum() == (phi != 0).sum()
-    np.testing.assert_allclose(phi, ref, rtol=1e-9, atol=0)
+    np.testing.assert_allclose(phi, ref, rtol=GAMMA_RTOL, atol=0)
 
 
 def test_shells_beyond_lds_use_global_scratch(asora):
@@ -182,7 +186,7 @@ def test_shells_beyond_lds_use_global_scratch(asora):
     phi = _asora_call(lib, c, N, thin.shape[0] - 1)
     ref = O.asora_do_all_sources(1000.0, cases.SIG, dr, nd, xh, pos0, fl, thin, thick, cases.MINLOGTAU, dlog,
                                  NumTau=thin.shape[0] - 1, flags=O.ASORA_MODE)["phi_ion"]
-    np.testing.assert_allclose(phi, ref, rtol=1e-9, atol=0)
+    np.testing.assert_allclose(phi, ref, rtol=GAMMA_RTOL, atol=0)
 
 
 # ---- chemistry -------------------------------------------------------------------------------
@@ -298,7 +302,7 @@ def test_full_size_properties_256(asora):
     # one source of the list against the oracle on the full-size grid (R=32: ~0.1 s of CPU)
     ref1 = O.asora_do_all_sources(R, cases.SIG, dr, nd, xh, p0[:3], f0[:1], thin, thick, cases.MINLOGTAU, dlog,
                                   NumTau=numtau, flags=O.ASORA_MODE)["phi_ion"]
-    np.testing.assert_allclose(trace(pos[:, :1], flux[:1]), ref1, rtol=1e-9, atol=0)
+    np.testing.assert_allclose(trace(pos[:, :1], flux[:1]), ref1, rtol=GAMMA_RTOL, atol=0)
 
 
 def test_uniform_medium_is_mirror_symmetric(asora):
