@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 namespace asora {
 
@@ -59,7 +60,7 @@ static int release_all()
     auto drop = [](auto *&ptr) { if (ptr) { (void)hipFree(ptr); ptr = nullptr; } };
     for (int g = 0; g < ASORA_GRID_COUNT; ++g) { drop(st.grid[g]); st.grid_valid[g] = false; }
     drop(st.nhi); drop(st.nhi_t); drop(st.phi_t); drop(st.staging);
-    drop(st.thin); drop(st.thick); st.table_len = 0;
+    drop(st.tables); st.table_len = 0;
     drop(st.src_pos); drop(st.src_flux); st.num_src = 0;
     drop(st.shell_scratch); st.shell_scratch_bytes = 0;
     release_geometry(st);
@@ -87,7 +88,7 @@ static int do_raytrace(double R, double sig, double dr, int src_begin, int src_c
     State &st = g_state;
     if (!st.grid_valid[ASORA_GRID_NDENS]) return fail(4, "raytrace: density not on device (density_to_device)");
     if (!st.grid_valid[ASORA_GRID_XH_AV]) return fail(4, "raytrace: xh_av not on device");
-    if (!st.opt[ASORA_OPT_GREY_NOTABLES] && (!st.thin || !st.thick))
+    if (!st.opt[ASORA_OPT_GREY_NOTABLES] && !st.tables)
         return fail(4, "raytrace: radiation tables not on device (photo_table_to_device)");
     if (src_begin < 0 || src_count < 0 || src_begin + src_count > st.num_src)
         return fail(4, "raytrace: source range [" + std::to_string(src_begin) + "," +
@@ -114,12 +115,15 @@ static int do_raytrace(double R, double sig, double dr, int src_begin, int src_c
     p.grey = st.opt[ASORA_OPT_GREY_NOTABLES];
     p.z_transposed = zt ? 1 : 0;
     p.src_begin = src_begin; p.src_count = src_count;
-    p.nhi = st.nhi; p.nhi_t = st.nhi_t;
-    p.phi = st.grid[ASORA_GRID_PHI_ION]; p.phi_t = st.phi_t;
-    p.thin = st.thin; p.thick = st.thick;
+    p.nhi = st.nhi;
+    p.nhi_t_off = (long long)(((intptr_t)st.nhi_t - (intptr_t)st.nhi) / (intptr_t)sizeof(double));
+    p.phi = st.grid[ASORA_GRID_PHI_ION];
+    p.phi_t_off = (long long)(((intptr_t)st.phi_t - (intptr_t)st.grid[ASORA_GRID_PHI_ION]) / (intptr_t)sizeof(double));
+    p.tables = st.tables;
     p.src_pos = st.src_pos; p.src_flux = st.src_flux;
     p.dump = dump;
     p.counters = st.counters;
+    { const char *ab = getenv("ASORA_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
     if (int rc = launch_raytrace(st, p, dump != nullptr)) return rc;
     if (zt)
         if (int rc = launch_finish_phi(st)) return rc;
@@ -248,13 +252,11 @@ int asora_photo_table_to_device(const double *thin_table, const double *thick_ta
     if (int rc = require_init("photo_table_to_device")) return rc;
     if (NumTau < 1 || !thin_table || !thick_table) return fail(3, "photo_table_to_device: empty table");
     State &st = g_state;
-    if (st.thin) { (void)hipFree(st.thin); st.thin = nullptr; }
-    if (st.thick) { (void)hipFree(st.thick); st.thick = nullptr; }
+    if (st.tables) { (void)hipFree(st.tables); st.tables = nullptr; }
     const size_t bytes = sizeof(double) * (size_t)NumTau;
-    ASORA_HIP_TRY(hipMalloc(&st.thin, bytes));
-    ASORA_HIP_TRY(hipMalloc(&st.thick, bytes));
-    ASORA_HIP_TRY(hipMemcpy(st.thin, thin_table, bytes, hipMemcpyHostToDevice));
-    ASORA_HIP_TRY(hipMemcpy(st.thick, thick_table, bytes, hipMemcpyHostToDevice));
+    ASORA_HIP_TRY(hipMalloc(&st.tables, 2 * bytes));
+    ASORA_HIP_TRY(hipMemcpy(st.tables, thick_table, bytes, hipMemcpyHostToDevice));
+    ASORA_HIP_TRY(hipMemcpy(st.tables + NumTau, thin_table, bytes, hipMemcpyHostToDevice));
     st.table_len = NumTau;
     return 0;
 }
@@ -439,7 +441,7 @@ int asora_debug_coldens(double R, double sig, double dr, int source_index, doubl
     // the column density does not depend on the tables: trace with whatever is loaded
     const int numtau = st.table_len > 0 ? st.table_len : 1;
     const int grey_save = st.opt[ASORA_OPT_GREY_NOTABLES];
-    if (!st.thin) st.opt[ASORA_OPT_GREY_NOTABLES] = 1;
+    if (!st.tables) st.opt[ASORA_OPT_GREY_NOTABLES] = 1;
     int rc = do_raytrace(R, sig, dr, source_index, 1, -20.0, 1.0, numtau, st.staging);
     st.opt[ASORA_OPT_GREY_NOTABLES] = grey_save;
     if (rc) return rc;

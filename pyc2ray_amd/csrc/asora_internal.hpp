@@ -11,15 +11,12 @@
 namespace asora {
 
 // Source-independent geometry of one octant, tabulated on the host (raytrace.hip), device pointers.
-// Cells of Chebyshev shell s are entries [shell_off[s], shell_off[s+1]) of the per-cell arrays.
+// A flat sequence of steps of 256 entries; see the table description above the kernel.
 struct OctGeomDev {
-    int S;                       // last shell
-    const uint32_t *shell_off;   // S+2 entries
-    const uint32_t *abc;         // |di| | |dj|<<10 | |dk|<<20 | face<<30   (face 2: dk=s, 1: dj=s, 0: di=s)
-    const double *w1, *w2, *w3, *w4;   // bilinear weights of the four upstream corners (cinterp s1..s4)
-    const double *path;          // path length through the cell, in cell units (cinterp)
-    const double *n2;            // |d|^2 in cell units
-    const uint4 *nbr;            // shell-buffer slots of the four corners in shell s-1
+    const uint4 *cellA;          // { |di| | |dj|<<10 | |dk|<<20 | face<<30, own slot | flags, path (double) }
+    const uint4 *cellB;          // shell-buffer slots of the four upstream corners in shell s-1
+    int nsteps;
+    int pad_;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -42,7 +39,7 @@ struct State {
     double *phi_t = nullptr;   // rate accumulator for z-faces, transposed [k][j][i]
     double *staging = nullptr; // N^3 staging grid for 'F'-order transfers / debug dumps
 
-    double *thin = nullptr, *thick = nullptr;
+    double *tables = nullptr;      // [thick | thin], each table_len long
     int table_len = 0;
 
     int32_t *src_pos = nullptr;
@@ -51,7 +48,7 @@ struct State {
 
     // raytracing geometry tables (built once per (N, R, dr), see raytrace.hip)
     std::vector<void *> geom_owned;
-    const OctGeomDev *geom_dev = nullptr;   // [8]
+    OctGeomDev geom_host[8];                // device pointers of the eight octant tables
     const double2 *logtab_dev = nullptr;
     bool geom_valid = false;
     int geom_N = 0, geom_S = 0, geom_max_cells = 0;
@@ -111,11 +108,14 @@ struct RtParams {
     int NumTau, table_len;
     int fortran_consts, grey, z_transposed;
     int src_begin, src_count;
-    const OctGeomDev *geom;     // [8]
+    int ablate;            // diagnostics only (env ASORA_ABLATE): 1 = no rate atomics, 2 = no rates
+    OctGeomDev geom[8];         // by value: pointers read from the kernarg segment are known-global to the compiler
     const double2 *logtab;      // 128 x {1/c, log2 c}
-    const double *nhi, *nhi_t;
-    double *phi, *phi_t;
-    const double *thin, *thick;
+    const double *nhi;          // nHI [i][j][k]; the [k][j][i] copy sits nhi_t_off elements further
+    long long nhi_t_off;
+    double *phi;                // Gamma accumulator [i][j][k]; the transposed one phi_t_off elements further
+    long long phi_t_off;
+    const double *tables;       // thick table at [0, table_len), thin at [table_len, 2*table_len)
     const int32_t *src_pos;
     const double *src_flux;
     double *dump;               // debug: outgoing column density (N^3) or nullptr

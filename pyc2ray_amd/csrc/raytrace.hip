@@ -26,12 +26,10 @@
 //     is strictly closer to the source, so the pruned cells never feed a kept one and phi_ion is
 //     unchanged (the reference evaluates them into scratch and then discards them,
 //     raytracing.cu:311-315).
-//   * everything about a cell that does not depend on the source or on the medium -- which cells
-//     a shell holds, their bilinear interpolation weights, their path length, |d|^2 and the
-//     shell-buffer slots of their four upstream corners -- is the same for all sources.  It is
-//     tabulated ONCE per (N, R) on the host (build_octant_geometry below, with the reference's
-//     own expressions) and streamed from L2 by every workgroup; the kernel does the
-//     medium-dependent arithmetic only.
+//   * what does not depend on the source or on the medium -- which cells a shell holds, their
+//     path length and the shell-buffer slots of their four upstream corners -- is the same for
+//     all sources.  It is tabulated ONCE per (N, R) on the host (build_octant_geometry below,
+//     28 B per cell) and streamed from L2 by every workgroup, two steps ahead of its use.
 //   * faces dj=s and di=s are rows along k, contiguous in the [i][j][k] grid.  Faces dk=s are
 //     rows along i, so they read nHI and accumulate Gamma through [k][j][i] transposed copies
 //     (rows contiguous again); the transposed accumulator is folded back once per call.
@@ -40,6 +38,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 namespace asora {
@@ -72,48 +71,80 @@ __device__ __forceinline__ double log2_pos(double x, const double2 *__restrict__
     return (double)e + (t.y + p);
 }
 
-// photo_lookuptable, rates.cu:70-83 (== photorates.f90:130-147).  The reference forms
+// photo_lookuptable, rates.cu:70-83 (== photorates.f90:130-147), in two halves so that the two
+// dependent table loads can be in flight while other work is done.  The reference forms
 // 1 + (log10(tau) - minlogtau)/dlogtau; here that is one fused multiply-add on log2(tau) with
 // k1 = log10(2)/dlogtau, k0 = 1 - minlogtau/dlogtau.  Indices are clamped to the last table
 // element (the reference reads one past the end when NumTau == len(table), tau >= 10^maxlogtau).
-__device__ __forceinline__ double table_lookup(const double *__restrict__ table, double tau, const RtParams &p,
+struct Lookup { double t0, t1, residual; };
+__device__ __forceinline__ Lookup lookup_issue(const double *__restrict__ table, double tau, const RtParams &p,
                                                const double2 *__restrict__ logtab)
 {
     const double l2 = log2_pos(fmax(1.0e-20, tau), logtab);
     const double real_i = fmin(p.numtau_f, fmax(0.0, fma(l2, p.lut_k1, p.lut_k0)));
     int i0 = (int)real_i;
     int i1 = min(p.NumTau, i0 + 1);
-    const double residual = real_i - (double)i0;
+    Lookup L;
+    L.residual = real_i - (double)i0;
     const int last = p.table_len - 1;
     i0 = min(i0, last);
     i1 = min(i1, last);
-    const double t0 = table[i0];
-    const double t1 = table[i1];
-    return fma(residual, t1 - t0, t0);
+    L.t0 = table[i0];
+    L.t1 = table[i1];
+    return L;
 }
+__device__ __forceinline__ double lookup_value(const Lookup &L) { return fma(L.residual, L.t1 - L.t0, L.t0); }
 
-// photoion_rates_gpu rates.cu:16-41 / photoion_rates_test_gpu rates.cu:48-64, divided by nHI
-// (raytracing.cu:324): pref = flux/(vol*nHI) replaces the reference's two divisions by one.
-__device__ __forceinline__ double photo_rate_per_atom(double flux, double cd_in, double cd_out, double vol_nhi,
-                                                      const RtParams &p, const double2 *__restrict__ logtab)
+// photoion_rates_gpu rates.cu:16-41 divided by nHI (raytracing.cu:324), also in two halves.
+// pref = flux/(vol*nHI) replaces the reference's two divisions by one.  A cell is "thick" when
+// |tau_out - tau_in| > TAU_PHOTO_LIMIT: Gamma = pref*(T_thick(tau_in) - T_thick(tau_out)); else
+// Gamma = pref*(tau_out - tau_in)*T_thin(tau_out) [rates.cu:37; photorates.f90:121 uses tau_in].
+struct RateJob {
+    double pref, dtau;       // dtau = tau_out - tau_in for thin cells, unused (0) for thick ones
+    Lookup A, B;             // thick: T(tau_in), T(tau_out);  thin: T_thin(tau*), unused
+    bool thick;
+};
+__device__ __forceinline__ RateJob rate_issue(double flux, double cd_in, double cd_out, double vol_nhi,
+                                              const RtParams &p, const double2 *__restrict__ logtab)
 {
     const double tau_in = cd_in * p.sig;
     const double tau_out = cd_out * p.sig;
     // TAU_PHOTO_LIMIT: rates.cu:7 (double 1e-7) or photorates.f90:69 (single 1e-7 promoted)
     const double limit = p.fortran_consts ? (double)1.0e-7f : 1.0e-7;
-    if (p.grey) {
-        const double pref = flux * 1e48 / vol_nhi;
-        if (fabs(tau_out - tau_in) > limit) return pref * (exp(-tau_in) - exp(-tau_out));
-        return pref * (tau_out - tau_in) * exp(-tau_in);
-    }
-    const double pref = flux / vol_nhi;
-    if (fabs(tau_out - tau_in) > limit) {
-        const double t_in = table_lookup(p.thick, tau_in, p, logtab);
-        const double t_out = table_lookup(p.thick, tau_out, p, logtab);
-        return pref * t_in - pref * t_out;
-    }
-    // rates.cu:37 uses tau_out, photorates.f90:121 uses tau_in
-    return pref * (tau_out - tau_in) * table_lookup(p.thin, p.fortran_consts ? tau_in : tau_out, p, logtab);
+    RateJob J;
+    J.pref = flux / vol_nhi;
+    J.thick = fabs(tau_out - tau_in) > limit;
+    J.dtau = tau_out - tau_in;
+    const double tau_thin = p.fortran_consts ? tau_in : tau_out;
+    // one code path for both kinds of cell: per-lane table and arguments
+    // thick table at [0, table_len), thin table at [table_len, 2*table_len) of one allocation
+    const double *tab = p.tables + (J.thick ? 0 : p.table_len);
+    J.A = lookup_issue(tab, J.thick ? tau_in : tau_thin, p, logtab);
+    J.B = lookup_issue(tab, J.thick ? tau_out : tau_thin, p, logtab);
+    return J;
+}
+__device__ __forceinline__ double rate_value(const RateJob &J)
+{
+    const double a = lookup_value(J.A), b = lookup_value(J.B);
+    return J.thick ? J.pref * a - J.pref * b : J.pref * J.dtau * a;
+}
+
+// photoion_rates_test_gpu rates.cu:48-64 (analytic grey rates, GREY_NOTABLES builds), per atom
+__device__ __forceinline__ double grey_rate_per_atom(double flux, double cd_in, double cd_out, double vol_nhi,
+                                                     const RtParams &p)
+{
+    const double tau_in = cd_in * p.sig, tau_out = cd_out * p.sig;
+    const double limit = p.fortran_consts ? (double)1.0e-7f : 1.0e-7;
+    const double pref = flux * 1e48 / vol_nhi;
+    if (fabs(tau_out - tau_in) > limit) return pref * (exp(-tau_in) - exp(-tau_out));
+    return pref * (tau_out - tau_in) * exp(-tau_in);
+}
+
+__device__ __forceinline__ double photo_rate_per_atom(double flux, double cd_in, double cd_out, double vol_nhi,
+                                                      const RtParams &p, const double2 *__restrict__ logtab)
+{
+    if (p.grey) return grey_rate_per_atom(flux, cd_in, cd_out, vol_nhi, p);
+    return rate_value(rate_issue(flux, cd_in, cd_out, vol_nhi, p, logtab));
 }
 
 __device__ __forceinline__ int wrap_once(int x, int N)
@@ -124,9 +155,16 @@ __device__ __forceinline__ int wrap_once(int x, int N)
 // ---------------------------------------------------------------------------------------------
 // The octant kernel
 // ---------------------------------------------------------------------------------------------
+// Per-octant cell tables (built by build_octant_geometry): a flat sequence of "steps" of RT_THREADS
+// entries; the cells of a shell fill whole steps (the last one padded with invalid entries), so
+// entry k*RT_THREADS + lane is what `lane` does in step k and the tables can be prefetched blindly.
+//   cellA[e] = { abc, own slot | VALID | LAST_OF_SHELL, path (double, 2 words) }
+//   cellB[e] = { slots of the four upstream corners in the previous shell's buffer }
 // Dynamic LDS: [shell buffer 0: max_cells+1 doubles][shell buffer 1: same]   (unless GLOBAL_SCRATCH)
-//              [log table: 128 x {1/c, log2 c}][wrapped i(a), j(b), k(c): 3*(S+1) ints]
+//              [log table: 128 x {1/c, log2 c}][1/s: S+1 doubles][wrapped i(a), j(b), k(c): 3*(S+1) ints]
 // Slot max_cells of each shell buffer holds 0.0: upstream corners of weight 0 point there.
+constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_SLOT_MASK = (1u << 30) - 1;
+
 template <bool GLOBAL_SCRATCH, bool DUMP>
 __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtParams p)
 {
@@ -140,7 +178,9 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
     if (src_local >= p.src_count) return;
     const int ns = p.src_begin + src_local;
 
-    const OctGeomDev G = p.geom[oct];
+    const uint4 *__restrict__ cellA = p.geom[oct].cellA;
+    const uint4 *__restrict__ cellB = p.geom[oct].cellB;
+    const int nsteps = p.geom[oct].nsteps;
     const int N = p.N;
     const int i0 = p.src_pos[3 * ns + 0];
     const int j0 = p.src_pos[3 * ns + 1];
@@ -160,12 +200,14 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
         after = cur + slots;
     }
     double2 *logtab = reinterpret_cast<double2 *>(after);
-    int *wi = reinterpret_cast<int *>(logtab + LOG_TABLE_SIZE);
+    double *inv_s = reinterpret_cast<double *>(logtab + LOG_TABLE_SIZE);
+    int *wi = reinterpret_cast<int *>(inv_s + (p.S + 1));
     int *wj = wi + (p.S + 1);
     int *wk = wj + (p.S + 1);
 
     for (int t = threadIdx.x; t < LOG_TABLE_SIZE; t += RT_THREADS) logtab[t] = p.logtab[t];
     for (int t = threadIdx.x; t <= p.S; t += RT_THREADS) {
+        inv_s[t] = 1.0 / (double)max(t, 1);
         wi[t] = wrap_once(i0 + sa * t, N);      // periodic position of offset t along each axis
         wj[t] = wrap_once(j0 + sb * t, N);      // (|offset| <= N/2: one wrap suffices, raytracing.cu:270-272)
         wk[t] = wrap_once(k0 + sc * t, N);
@@ -173,11 +215,10 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
     if (threadIdx.x == 0) { prev[p.max_cells] = 0.0; cur[p.max_cells] = 0.0; }
     __syncthreads();
 
-    const double sig = p.sig, dr = p.dr, dr2 = dr * dr;
-    const double maxcd = p.fortran_consts ? (double)2e30f : 2e30;                    // raytracing.cu:15
-    const double r3 = p.fortran_consts ? (double)1.7320507764816284 : 1.73205080757; // f90:608 / cu:435
-    const double r2 = p.fortran_consts ? (double)1.4142135381698608 : 1.41421356237; // f90:609 / cu:439
+    const double sig = p.sig, dr = p.dr;
     const unsigned negmask = (sa < 0 ? 1u : 0u) | (sb < 0 ? 2u : 0u) | (sc < 0 ? 4u : 0u);
+    const bool ztr = p.z_transposed != 0;
+    const bool grey = p.grey != 0;
 
     unsigned int n_gamma = 0, n_eval = 0;
 
@@ -198,58 +239,105 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
     }
     __syncthreads();
 
-    for (int s = 1; s <= G.S; ++s) {
-        const unsigned off = G.shell_off[s];
-        const int ncell = (int)(G.shell_off[s + 1] - off);
-        if (ncell == 0) break;                               // uniform: nothing further out either
+    // ---- shells 1..S, software-pipelined ------------------------------------------------------
+    // The tables of a step do not depend on the medium, and the address of a cell's nHI only on
+    // its table entry, so both are fetched ahead of the dependent arithmetic: tables two steps
+    // ahead, nHI one step ahead.  Rate evaluation trails the sweep by one step: the table lookups
+    // of step k are issued in step k and consumed (and the atomic issued) in step k+1, so their
+    // latency is covered by the next interpolation and never holds up the shell barrier.
+    // (The tables carry two all-invalid steps of padding at the end: prefetches stay in bounds.)
+    auto nhi_address = [&](unsigned abc, unsigned &idx) -> const double * {
+        const unsigned i = wi[abc & 1023], j = wj[(abc >> 10) & 1023], k = wk[(abc >> 20) & 1023];
+        const bool zt = ztr && (abc >> 30) == 2;
+        idx = zt ? (k * N + j) * N + i : (i * N + j) * N + k;
+        return p.nhi + ((long long)idx + (zt ? p.nhi_t_off : 0ll));
+    };
 
-        for (int t = threadIdx.x; t < ncell; t += RT_THREADS) {
-            const unsigned g = off + t;
-            const unsigned abc = G.abc[g];
+    unsigned e = threadIdx.x;
+    uint4 A0 = cellA[e], B0 = cellB[e];
+    uint4 A1 = cellA[e + RT_THREADS], B1 = cellB[e + RT_THREADS];
+    unsigned idx0, idx1 = 0;
+    double nhi0 = *nhi_address(A0.x, idx0);
+
+    bool pend = false;            // this lane has a rate in flight
+    RateJob job;
+    double *pend_dst = nullptr;
+    job.pref = 0.0; job.dtau = 0.0; job.thick = false;
+    job.A.t0 = job.A.t1 = job.A.residual = 0.0; job.B = job.A;
+
+    for (int k = 0; k < nsteps; ++k, e += RT_THREADS) {
+        const uint4 A2 = cellA[e + 2 * RT_THREADS], B2 = cellB[e + 2 * RT_THREADS];   // two steps ahead
+        const double nhi1 = *nhi_address(A1.x, idx1);                                   // one step ahead
+
+        bool rated = false;
+        double cd_in = 0.0, cd_out = 0.0, vol_nhi = 1.0;
+        double *dst = nullptr;
+        if (A0.y & CELL_VALID) {
+            const unsigned abc = A0.x;
             const int a = abc & 1023, b = (abc >> 10) & 1023, c = (abc >> 20) & 1023;
             const unsigned face = abc >> 30;                 // 2: dk = s, 1: dj = s, 0: di = s
-            const uint4 nb = G.nbr[g];
+            const int s = max(a, max(b, c));
 
             // ---- cinterp_gpu, raytracing.cu:345-535 ------------------------------------------
+            // Bilinear weights: with alam = (s-1/2)/s the reference's dx = 2|alam*u - (u - 1/2)|
+            // (raytracing.cu:397-403, source-relative) is 1 - u/s, so
+            // s1..s4 = fu*fv, fv*(1-fu), fu*(1-fv), (1-fu)*(1-fv) with fu = u/s (raytracing.cu:405-408).
+            // fu = 0 (resp. 1) makes the weights of the corners that do not exist in shell s-1 exactly 0.
+            const int U = face == 0 ? b : a, V = face == 2 ? b : c;
+            const double is = inv_s[s];
+            const double fu = U == s ? 1.0 : (double)U * is, fv = V == s ? 1.0 : (double)V * is;
+            const double gu = 1.0 - fu, gv = 1.0 - fv;
             // w_n = s_n / max(0.6, c_n*sig) (raytracing.cu:33,422-425) and
             // cdensi = sum(c_n w_n)/sum(w_n) (raytracing.cu:428), with numerator and denominator
             // multiplied through by the four max() terms: one division instead of five.
-            const double c1 = prev[nb.x], c2 = prev[nb.y], c3 = prev[nb.z], c4 = prev[nb.w];
-            const double m1 = fmax(0.6, c1 * sig), m2 = fmax(0.6, c2 * sig);
-            const double m3 = fmax(0.6, c3 * sig), m4 = fmax(0.6, c4 * sig);
+            const double x1 = prev[B0.x], x2 = prev[B0.y], x3 = prev[B0.z], x4 = prev[B0.w];
+            const double m1 = fmax(0.6, x1 * sig), m2 = fmax(0.6, x2 * sig);
+            const double m3 = fmax(0.6, x3 * sig), m4 = fmax(0.6, x4 * sig);
             const double m12 = m1 * m2, m34 = m3 * m4;
-            const double q1 = G.w1[g] * (m2 * m34), q2 = G.w2[g] * (m1 * m34);
-            const double q3 = G.w3[g] * (m12 * m4), q4 = G.w4[g] * (m12 * m3);
-            double cd_in = (c1 * q1 + c2 * q2 + c3 * q3 + c4 * q4) / (q1 + q2 + q3 + q4);
+            const double q1 = (fu * fv) * (m2 * m34), q2 = (fv * gu) * (m1 * m34);
+            const double q3 = (fu * gv) * (m12 * m4), q4 = (gu * gv) * (m12 * m3);
+            cd_in = (x1 * q1 + x2 * q2 + x3 * q3 + x4 * q4) / (q1 + q2 + q3 + q4);
             if (s == 1) {                                    // diagonal neighbours of the source, cu:431-441
                 const int nz = (a == 0) + (b == 0) + (c == 0);
+                const double r3 = p.fortran_consts ? (double)1.7320507764816284 : 1.73205080757; // f90:608 / cu:435
+                const double r2 = p.fortran_consts ? (double)1.4142135381698608 : 1.41421356237; // f90:609 / cu:439
                 if (nz < 2) cd_in = (nz == 0 ? r3 : r2) * cd_in;
             }
-            const double path = G.path[g] * dr;
+            const double path = __hiloint2double((int)A0.w, (int)A0.z) * dr;
 
             // ---- the cell itself, raytracing.cu:270-276,311-328 -----------------------------
-            const unsigned i = wi[a], j = wj[b], k = wk[c];
-            const bool zt = p.z_transposed && face == 2;
-            const unsigned idx = zt ? (k * N + j) * N + i : (i * N + j) * N + k;
-            const double nHI = (zt ? p.nhi_t : p.nhi)[idx];
-            const double cd_out = fma(nHI, path, cd_in);
-            cur[t] = cd_out;
+            const double nHI = nhi0;
+            cd_out = fma(nHI, path, cd_in);
+            cur[A0.y & CELL_SLOT_MASK] = cd_out;
             ++n_eval;
             // a cell on an octant-boundary plane is rated by the octant with the + sign there
             const unsigned zmask = (a == 0 ? 1u : 0u) | (b == 0 ? 2u : 0u) | (c == 0 ? 4u : 0u);
             if ((zmask & negmask) == 0) {
-                if (DUMP) p.dump[(i * N + j) * N + k] = cd_out;
+                if (DUMP) p.dump[(wi[a] * N + wj[b]) * N + wk[c]] = cd_out;
+                const double maxcd = p.fortran_consts ? (double)2e30f : 2e30;            // raytracing.cu:15
                 if (cd_in <= maxcd) {
-                    const double vol_nhi = G.n2[g] * dr2 * path * FOURPI * nHI;          // raytracing.cu:302-307
-                    const double phi = photo_rate_per_atom(flux, cd_in, cd_out, vol_nhi, p, logtab);
-                    unsafeAtomicAdd((zt ? p.phi_t : p.phi) + idx, phi);
+                    const double n2 = (double)(a * a + b * b + c * c);
+                    vol_nhi = n2 * (dr * dr * FOURPI) * path * nHI;                      // raytracing.cu:302-307
+                    dst = p.phi + ((long long)idx0 + ((ztr && face == 2) ? p.phi_t_off : 0ll));
+                    rated = !(p.ablate & 2);
                     ++n_gamma;
                 }
             }
         }
-        __syncthreads();
-        double *tmp = prev; prev = cur; cur = tmp;
+        if (__builtin_amdgcn_readfirstlane(A0.y) & CELL_LAST) {   // shell finished: publish it
+            if (!(p.ablate & 4)) __syncthreads();
+            double *tmp = prev; prev = cur; cur = tmp;
+        }
+        // retire the rate of the previous step, then start this step's
+        if (pend) { const double v = rate_value(job); if (!(p.ablate & 1)) unsafeAtomicAdd(pend_dst, v); else if (v == 1.2345e-300) pend_dst[0] = v; }
+        pend = false;
+        if (rated) {
+            if (grey) unsafeAtomicAdd(dst, grey_rate_per_atom(flux, cd_in, cd_out, vol_nhi, p));
+            else { job = rate_issue(flux, cd_in, cd_out, vol_nhi, p, logtab); pend_dst = dst; pend = true; }
+        }
+        A0 = A1; B0 = B1; A1 = A2; B1 = B2; nhi0 = nhi1; idx0 = idx1;
     }
+    if (pend) { const double v = rate_value(job); if (!(p.ablate & 1)) unsafeAtomicAdd(pend_dst, v); else if (v == 1.2345e-300) pend_dst[0] = v; }
 
     // work accounting: one atomic per wave
     for (int o = 32; o > 0; o >>= 1) {
@@ -268,17 +356,16 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
 // Faces of shell s follow the reference's branch order z, y, x (raytracing.cu:394,446,491; ties go
 // to z, then y):  z-face dk = s: (a,b,s), a,b <= s;  y-face dj = s: (a,s,c), c < s;  x-face di = s:
 // (s,b,c), b,c < s.  Inside a face the fastest index is the one that is contiguous in memory
-// (a for the transposed z-face, c otherwise).  The weights are the reference's expressions
-// (raytracing.cu:397-408,444) in source-relative coordinates |d|; corners that would step across
-// a zero offset or keep a transverse offset equal to s get weight exactly 0 from those
-// expressions and are given the buffer's zero slot.
+// (a for the transposed z-face, c otherwise).  Tabulated per cell: packed offsets + face, the path
+// length (raytracing.cu:444) and the shell-buffer slots of the four upstream corners; corners
+// that would step across a zero offset or keep a transverse offset equal to s have bilinear weight
+// exactly 0 (raytracing.cu:397-408) and are given the buffer's zero slot.
 namespace {
 
 struct HostGeom {
-    std::vector<uint32_t> shell_off, abc;
-    std::vector<double> w1, w2, w3, w4, path, n2;
-    std::vector<uint4> nbr;
+    std::vector<uint4> cellA, cellB;      // step-padded, see the kernel's table description
     int S = 0;
+    int nsteps = 0;
     uint32_t max_cells = 1;
 };
 
@@ -301,9 +388,6 @@ void build_octant_geometry(HostGeom &h, int Ea, int Eb, int Ec, double R, double
     int S = Emax;
     if (std::isfinite(R2hi)) S = (int)std::min((double)Emax, std::floor(std::sqrt(R2hi)));
     h.S = S;
-    h.shell_off.assign(S + 2, 0);
-    h.shell_off[0] = 0;
-    h.shell_off[1] = 0;           // shell 0 (the source cell) is handled by the kernel prologue
     // slot maps of the previous / current shell: face*(P*P) + u*P + v with P = S+1
     const size_t P = (size_t)S + 1;
     std::vector<uint32_t> slot_prev(3 * P * P, zero_slot_marker), slot_cur(3 * P * P, zero_slot_marker);
@@ -321,17 +405,16 @@ void build_octant_geometry(HostGeom &h, int Ea, int Eb, int Ec, double R, double
         if (n2 < R2 * (1.0 - 1e-9) - 1e-9) return true;
         return inside_radius_reference(a, b, c, dr, R2);
     };
+    const uint4 pad_a = {0u, 0u, 0u, 0u};
+    const uint4 pad_b = {zero_slot_marker, zero_slot_marker, zero_slot_marker, zero_slot_marker};
     for (int s = 1; s <= S; ++s) {
         std::fill(slot_cur.begin(), slot_cur.end(), zero_slot_marker);
         const double sd = (double)s;
-        const double alam = (sd - 0.5) / sd;                                   // raytracing.cu:397
+        const size_t first = h.cellA.size();
         uint32_t count = 0;
         auto emit = [&](int a, int b, int c, int face, int U, int V) {
             if (!in_sphere(a, b, c)) return;
             const double u = (double)U, v = (double)V;
-            const double de = 2.0 * std::fabs(alam * u - (u - 0.5));           // raytracing.cu:399-403
-            const double df = 2.0 * std::fabs(alam * v - (v - 0.5));
-            double s1 = (1. - de) * (1. - df), s2 = (1. - df) * de, s3 = (1. - de) * df, s4 = de * df;
             const bool em = U >= 1, e0 = U <= s - 1, fm = V >= 1, f0 = V <= s - 1;
             auto corner = [&](int uu, int vv) -> uint32_t {
                 int aa, bb, cc;
@@ -345,15 +428,16 @@ void build_octant_geometry(HostGeom &h, int Ea, int Eb, int Ec, double R, double
             nb.y = (e0 && fm) ? corner(U, V - 1) : zero_slot_marker;
             nb.z = (em && f0) ? corner(U - 1, V) : zero_slot_marker;
             nb.w = (e0 && f0) ? corner(U, V) : zero_slot_marker;
-            if (nb.x == zero_slot_marker) s1 = 0.0;
-            if (nb.y == zero_slot_marker) s2 = 0.0;
-            if (nb.z == zero_slot_marker) s3 = 0.0;
-            if (nb.w == zero_slot_marker) s4 = 0.0;
-            h.abc.push_back((uint32_t)a | ((uint32_t)b << 10) | ((uint32_t)c << 20) | ((uint32_t)face << 30));
-            h.w1.push_back(s1); h.w2.push_back(s2); h.w3.push_back(s3); h.w4.push_back(s4);
-            h.path.push_back(std::sqrt((u * u + v * v) / (sd * sd) + 1.0));    // raytracing.cu:444
-            h.n2.push_back((double)a * a + (double)b * b + (double)c * c);
-            h.nbr.push_back(nb);
+            const double path = std::sqrt((u * u + v * v) / (sd * sd) + 1.0);  // raytracing.cu:444
+            uint64_t pbits;
+            std::memcpy(&pbits, &path, sizeof pbits);
+            uint4 ca;
+            ca.x = (uint32_t)a | ((uint32_t)b << 10) | ((uint32_t)c << 20) | ((uint32_t)face << 30);
+            ca.y = count | CELL_VALID;
+            ca.z = (uint32_t)(pbits & 0xffffffffu);
+            ca.w = (uint32_t)(pbits >> 32);
+            h.cellA.push_back(ca);
+            h.cellB.push_back(nb);
             size_t key = face == 2 ? (0 * P * P + (size_t)b * P + a)
                        : face == 1 ? (1 * P * P + (size_t)a * P + c) : (2 * P * P + (size_t)b * P + c);
             slot_cur[key] = count++;
@@ -367,10 +451,17 @@ void build_octant_geometry(HostGeom &h, int Ea, int Eb, int Ec, double R, double
         if (s <= Ea)
             for (int b = 0; b <= std::min(s - 1, Eb); ++b)
                 for (int c = 0; c <= std::min(s - 1, Ec); ++c) emit(s, b, c, 0, b, c);
-        h.shell_off[s + 1] = h.shell_off[s] + count;
+        if (count == 0) break;                        // nothing further out either
+        // pad the shell to whole steps and flag every entry of its last step
+        while (h.cellA.size() % RT_THREADS) { h.cellA.push_back(pad_a); h.cellB.push_back(pad_b); }
+        for (size_t q = h.cellA.size() - RT_THREADS; q < h.cellA.size(); ++q) h.cellA[q].y |= CELL_LAST;
+        (void)first;
         h.max_cells = std::max(h.max_cells, count);
         slot_prev.swap(slot_cur);
     }
+    h.nsteps = (int)(h.cellA.size() / RT_THREADS);
+    // two all-invalid steps so that the kernel's look-ahead loads stay inside the tables
+    for (int q = 0; q < 2 * RT_THREADS; ++q) { h.cellA.push_back(pad_a); h.cellB.push_back(pad_b); }
 }
 
 template <typename T>
@@ -391,7 +482,6 @@ void release_geometry(State &st)
 {
     for (void *q : st.geom_owned) (void)hipFree(q);
     st.geom_owned.clear();
-    st.geom_dev = nullptr;
     st.logtab_dev = nullptr;
     st.geom_valid = false;
 }
@@ -405,7 +495,8 @@ static int ensure_geometry(State &st, RtParams &p)
     const int ext_pos = N / 2 - 1 + (N % 2);                                                      // raytracing.cu:122
     const int ext_neg = N / 2;                                                                    // raytracing.cu:123
     if (st.geom_valid && st.geom_N == N && st.geom_R == p.R && st.geom_dr == p.dr) {
-        p.geom = st.geom_dev; p.logtab = st.logtab_dev; p.S = st.geom_S; p.max_cells = st.geom_max_cells;
+        for (int o = 0; o < 8; ++o) p.geom[o] = st.geom_host[o];
+        p.logtab = st.logtab_dev; p.S = st.geom_S; p.max_cells = st.geom_max_cells;
         return 0;
     }
     release_geometry(st);
@@ -439,29 +530,19 @@ static int ensure_geometry(State &st, RtParams &p)
     for (int oct = 0; oct < 8; ++oct) {
         if (owner[oct] != oct) continue;
         HostGeom &h = hg[oct];
-        for (auto &nb : h.nbr) {
+        for (auto &nb : h.cellB) {
             if (nb.x == MARK) nb.x = max_cells;
             if (nb.y == MARK) nb.y = max_cells;
             if (nb.z == MARK) nb.z = max_cells;
             if (nb.w == MARK) nb.w = max_cells;
         }
         OctGeomDev d;
-        d.S = h.S;
-        if (int rc = upload(h.shell_off, d.shell_off, st.geom_owned)) return rc;
-        if (int rc = upload(h.abc, d.abc, st.geom_owned)) return rc;
-        if (int rc = upload(h.w1, d.w1, st.geom_owned)) return rc;
-        if (int rc = upload(h.w2, d.w2, st.geom_owned)) return rc;
-        if (int rc = upload(h.w3, d.w3, st.geom_owned)) return rc;
-        if (int rc = upload(h.w4, d.w4, st.geom_owned)) return rc;
-        if (int rc = upload(h.path, d.path, st.geom_owned)) return rc;
-        if (int rc = upload(h.n2, d.n2, st.geom_owned)) return rc;
-        if (int rc = upload(h.nbr, d.nbr, st.geom_owned)) return rc;
+        d.nsteps = h.nsteps;
+        if (int rc = upload(h.cellA, d.cellA, st.geom_owned)) return rc;
+        if (int rc = upload(h.cellB, d.cellB, st.geom_owned)) return rc;
         od[oct] = d;
     }
     for (int oct = 0; oct < 8; ++oct) od[oct] = od[owner[oct]];
-    std::vector<OctGeomDev> odv(od, od + 8);
-    const OctGeomDev *gd = nullptr;
-    if (int rc = upload(odv, gd, st.geom_owned)) return rc;
 
     // log2 table: interval centres c = 1 + (i + 1/2)/128, entries {1/c, log2 c}
     std::vector<double2> lt(LOG_TABLE_SIZE);
@@ -473,10 +554,12 @@ static int ensure_geometry(State &st, RtParams &p)
     const double2 *ltd = nullptr;
     if (int rc = upload(lt, ltd, st.geom_owned)) return rc;
 
-    st.geom_dev = gd; st.logtab_dev = ltd;
+    for (int o = 0; o < 8; ++o) st.geom_host[o] = od[o];
+    st.logtab_dev = ltd;
     st.geom_N = N; st.geom_R = p.R; st.geom_dr = p.dr; st.geom_S = Smax; st.geom_max_cells = (int)max_cells;
     st.geom_valid = true;
-    p.geom = gd; p.logtab = ltd; p.S = Smax; p.max_cells = (int)max_cells;
+    for (int o = 0; o < 8; ++o) p.geom[o] = od[o];
+    p.logtab = ltd; p.S = Smax; p.max_cells = (int)max_cells;
     return 0;
 }
 
