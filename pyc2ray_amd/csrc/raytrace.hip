@@ -253,91 +253,133 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
         return p.nhi + ((long long)idx + (zt ? p.nhi_t_off : 0ll));
     };
 
-    unsigned e = threadIdx.x;
-    uint4 A0 = cellA[e], B0 = cellB[e];
-    uint4 A1 = cellA[e + RT_THREADS], B1 = cellB[e + RT_THREADS];
-    unsigned idx0, idx1 = 0;
-    double nhi0 = *nhi_address(A0.x, idx0);
+    // One step of one lane, straight-line (whole-wave instruction count is what matters, so
+    // inactive lanes run the arithmetic on harmless padding values and only the LDS store and
+    // the atomic are predicated).  `cur_*` is this step's table entry / nHI, `nxt_*` the next
+    // step's (its nHI is requested here), `pf_*` the register set the entry two steps ahead is
+    // loaded into.  The loop below is unrolled three times with the three register sets rotating,
+    // so the pipeline needs no register-to-register copies.
+    bool pend = false;
+    double pend_pref = 0.0, pend_dtau = 0.0;
+    bool pend_thick = false;
+    Lookup pend_A, pend_B;
+    pend_A.t0 = pend_A.t1 = pend_A.residual = 0.0; pend_B = pend_A;
+    double *pend_dst = p.phi;
 
-    bool pend = false;            // this lane has a rate in flight
-    RateJob job;
-    double *pend_dst = nullptr;
-    job.pref = 0.0; job.dtau = 0.0; job.thick = false;
-    job.A.t0 = job.A.t1 = job.A.residual = 0.0; job.B = job.A;
+    auto step = [&](unsigned e_pf, const uint4 &cur_A, const uint4 &cur_B, const double cur_nhi, const unsigned cur_idx,
+                    const uint4 &nxt_A, double &nxt_nhi, unsigned &nxt_idx, uint4 &pf_A, uint4 &pf_B) {
+        pf_A = cellA[e_pf];                                         // two steps ahead
+        pf_B = cellB[e_pf];
+        nxt_nhi = *nhi_address(nxt_A.x, nxt_idx);                   // one step ahead
 
-    for (int k = 0; k < nsteps; ++k, e += RT_THREADS) {
-        const uint4 A2 = cellA[e + 2 * RT_THREADS], B2 = cellB[e + 2 * RT_THREADS];   // two steps ahead
-        const double nhi1 = *nhi_address(A1.x, idx1);                                   // one step ahead
-
+        const bool valid = (cur_A.y & CELL_VALID) != 0;
+        // waves whose 64 entries are all padding skip the arithmetic (wave-uniform branch)
+        const bool wave_has_work = __builtin_amdgcn_readfirstlane((int)__any(valid)) != 0;
         bool rated = false;
         double cd_in = 0.0, cd_out = 0.0, vol_nhi = 1.0;
-        double *dst = nullptr;
-        if (A0.y & CELL_VALID) {
-            const unsigned abc = A0.x;
-            const int a = abc & 1023, b = (abc >> 10) & 1023, c = (abc >> 20) & 1023;
-            const unsigned face = abc >> 30;                 // 2: dk = s, 1: dj = s, 0: di = s
-            const int s = max(a, max(b, c));
+        double *dst = p.phi;
+        if (wave_has_work) {
+        const unsigned abc = cur_A.x;
+        const int a = abc & 1023, b = (abc >> 10) & 1023, c = (abc >> 20) & 1023;
+        const unsigned face = abc >> 30;                 // 2: dk = s, 1: dj = s, 0: di = s
+        const int s = max(a, max(b, c));
 
-            // ---- cinterp_gpu, raytracing.cu:345-535 ------------------------------------------
-            // Bilinear weights: with alam = (s-1/2)/s the reference's dx = 2|alam*u - (u - 1/2)|
-            // (raytracing.cu:397-403, source-relative) is 1 - u/s, so
-            // s1..s4 = fu*fv, fv*(1-fu), fu*(1-fv), (1-fu)*(1-fv) with fu = u/s (raytracing.cu:405-408).
-            // fu = 0 (resp. 1) makes the weights of the corners that do not exist in shell s-1 exactly 0.
-            const int U = face == 0 ? b : a, V = face == 2 ? b : c;
-            const double is = inv_s[s];
-            const double fu = U == s ? 1.0 : (double)U * is, fv = V == s ? 1.0 : (double)V * is;
-            const double gu = 1.0 - fu, gv = 1.0 - fv;
-            // w_n = s_n / max(0.6, c_n*sig) (raytracing.cu:33,422-425) and
-            // cdensi = sum(c_n w_n)/sum(w_n) (raytracing.cu:428), with numerator and denominator
-            // multiplied through by the four max() terms: one division instead of five.
-            const double x1 = prev[B0.x], x2 = prev[B0.y], x3 = prev[B0.z], x4 = prev[B0.w];
-            const double m1 = fmax(0.6, x1 * sig), m2 = fmax(0.6, x2 * sig);
-            const double m3 = fmax(0.6, x3 * sig), m4 = fmax(0.6, x4 * sig);
-            const double m12 = m1 * m2, m34 = m3 * m4;
-            const double q1 = (fu * fv) * (m2 * m34), q2 = (fv * gu) * (m1 * m34);
-            const double q3 = (fu * gv) * (m12 * m4), q4 = (gu * gv) * (m12 * m3);
-            cd_in = (x1 * q1 + x2 * q2 + x3 * q3 + x4 * q4) / (q1 + q2 + q3 + q4);
-            if (s == 1) {                                    // diagonal neighbours of the source, cu:431-441
-                const int nz = (a == 0) + (b == 0) + (c == 0);
-                const double r3 = p.fortran_consts ? (double)1.7320507764816284 : 1.73205080757; // f90:608 / cu:435
-                const double r2 = p.fortran_consts ? (double)1.4142135381698608 : 1.41421356237; // f90:609 / cu:439
-                if (nz < 2) cd_in = (nz == 0 ? r3 : r2) * cd_in;
-            }
-            const double path = __hiloint2double((int)A0.w, (int)A0.z) * dr;
-
-            // ---- the cell itself, raytracing.cu:270-276,311-328 -----------------------------
-            const double nHI = nhi0;
-            cd_out = fma(nHI, path, cd_in);
-            cur[A0.y & CELL_SLOT_MASK] = cd_out;
-            ++n_eval;
-            // a cell on an octant-boundary plane is rated by the octant with the + sign there
-            const unsigned zmask = (a == 0 ? 1u : 0u) | (b == 0 ? 2u : 0u) | (c == 0 ? 4u : 0u);
-            if ((zmask & negmask) == 0) {
-                if (DUMP) p.dump[(wi[a] * N + wj[b]) * N + wk[c]] = cd_out;
-                const double maxcd = p.fortran_consts ? (double)2e30f : 2e30;            // raytracing.cu:15
-                if (cd_in <= maxcd) {
-                    const double n2 = (double)(a * a + b * b + c * c);
-                    vol_nhi = n2 * (dr * dr * FOURPI) * path * nHI;                      // raytracing.cu:302-307
-                    dst = p.phi + ((long long)idx0 + ((ztr && face == 2) ? p.phi_t_off : 0ll));
-                    rated = !(p.ablate & 2);
-                    ++n_gamma;
-                }
-            }
+        // ---- cinterp_gpu, raytracing.cu:345-535 ------------------------------------------
+        // Bilinear weights: with alam = (s-1/2)/s the reference's dx = 2|alam*u - (u - 1/2)|
+        // (raytracing.cu:397-403, source-relative) is 1 - u/s, so
+        // s1..s4 = fu*fv, fv*(1-fu), fu*(1-fv), (1-fu)*(1-fv) with fu = u/s (raytracing.cu:405-408).
+        // fu = 0 (resp. 1) makes the weights of the corners that do not exist in shell s-1 exactly 0.
+        const int U = face == 0 ? b : a, V = face == 2 ? b : c;
+        const double is = inv_s[s];
+        const double fu = U == s ? 1.0 : (double)U * is, fv = V == s ? 1.0 : (double)V * is;
+        const double gu = 1.0 - fu, gv = 1.0 - fv;
+        // w_n = s_n / max(0.6, c_n*sig) (raytracing.cu:33,422-425) and
+        // cdensi = sum(c_n w_n)/sum(w_n) (raytracing.cu:428), with numerator and denominator
+        // multiplied through by the four max() terms: one division instead of five.
+        const double x1 = prev[cur_B.x], x2 = prev[cur_B.y], x3 = prev[cur_B.z], x4 = prev[cur_B.w];
+        const double m1 = fmax(0.6, x1 * sig), m2 = fmax(0.6, x2 * sig);
+        const double m3 = fmax(0.6, x3 * sig), m4 = fmax(0.6, x4 * sig);
+        const double m12 = m1 * m2, m34 = m3 * m4;
+        const double q1 = (fu * fv) * (m2 * m34), q2 = (fv * gu) * (m1 * m34);
+        const double q3 = (fu * gv) * (m12 * m4), q4 = (gu * gv) * (m12 * m3);
+        cd_in = (x1 * q1 + x2 * q2 + x3 * q3 + x4 * q4) / (q1 + q2 + q3 + q4);
+        if (s == 1) {                                    // diagonal neighbours of the source, cu:431-441
+            const int nz = (a == 0) + (b == 0) + (c == 0);
+            const double r3 = p.fortran_consts ? (double)1.7320507764816284 : 1.73205080757; // f90:608 / cu:435
+            const double r2 = p.fortran_consts ? (double)1.4142135381698608 : 1.41421356237; // f90:609 / cu:439
+            if (nz < 2) cd_in = (nz == 0 ? r3 : r2) * cd_in;
         }
-        if (__builtin_amdgcn_readfirstlane(A0.y) & CELL_LAST) {   // shell finished: publish it
+        const double path = __hiloint2double((int)cur_A.w, (int)cur_A.z) * dr;
+
+        // ---- the cell itself, raytracing.cu:270-276,311-328 -----------------------------
+        const double nHI = cur_nhi;
+        cd_out = fma(nHI, path, cd_in);
+        if (valid) cur[cur_A.y & CELL_SLOT_MASK] = cd_out;
+        n_eval += valid ? 1u : 0u;
+        // a cell on an octant-boundary plane is rated by the octant with the + sign there
+        const unsigned zmask = (a == 0 ? 1u : 0u) | (b == 0 ? 2u : 0u) | (c == 0 ? 4u : 0u);
+        const double maxcd = p.fortran_consts ? (double)2e30f : 2e30;                    // raytracing.cu:15
+        const bool owner = valid && (zmask & negmask) == 0;
+        if (DUMP) { if (owner) p.dump[(wi[a] * N + wj[b]) * N + wk[c]] = cd_out; }
+        rated = owner && cd_in <= maxcd && !(p.ablate & 2);
+        n_gamma += (owner && cd_in <= maxcd) ? 1u : 0u;
+        const double n2 = (double)(a * a + b * b + c * c);
+        vol_nhi = rated ? n2 * (dr * dr * FOURPI) * path * nHI : 1.0;       // raytracing.cu:302-307
+        dst = p.phi + ((long long)cur_idx + ((ztr && face == 2) ? p.phi_t_off : 0ll));
+        }
+
+        if (__builtin_amdgcn_readfirstlane(cur_A.y) & CELL_LAST) {   // shell finished: publish it
             if (!(p.ablate & 4)) __syncthreads();
             double *tmp = prev; prev = cur; cur = tmp;
         }
-        // retire the rate of the previous step, then start this step's
-        if (pend) { const double v = rate_value(job); if (!(p.ablate & 1)) unsafeAtomicAdd(pend_dst, v); else if (v == 1.2345e-300) pend_dst[0] = v; }
-        pend = false;
-        if (rated) {
-            if (grey) unsafeAtomicAdd(dst, grey_rate_per_atom(flux, cd_in, cd_out, vol_nhi, p));
-            else { job = rate_issue(flux, cd_in, cd_out, vol_nhi, p, logtab); pend_dst = dst; pend = true; }
+
+        // ---- rates, raytracing.cu:315-328 + rates.cu:16-41: retire the previous step's lookups,
+        // then issue this step's (consumed one step later)
+        if (pend) {
+            const double ta = lookup_value(pend_A), tb = lookup_value(pend_B);
+            const double v = pend_thick ? pend_pref * ta - pend_pref * tb : pend_pref * pend_dtau * ta;
+            if (!(p.ablate & 1)) unsafeAtomicAdd(pend_dst, v); else if (v == 1.2345e-300) pend_dst[0] = v;
         }
-        A0 = A1; B0 = B1; A1 = A2; B1 = B2; nhi0 = nhi1; idx0 = idx1;
+        if (grey) {
+            if (rated) unsafeAtomicAdd(dst, grey_rate_per_atom(flux, cd_in, cd_out, vol_nhi, p));
+            pend = false;
+        } else if (!wave_has_work) {
+            pend = false;
+        } else {
+            const double tau_in = (rated ? cd_in : 1.0) * sig, tau_out = (rated ? cd_out : 1.0) * sig;
+            // TAU_PHOTO_LIMIT: rates.cu:7 (double 1e-7) or photorates.f90:69 (single 1e-7 promoted)
+            const double limit = p.fortran_consts ? (double)1.0e-7f : 1.0e-7;
+            pend_pref = flux / vol_nhi;
+            pend_dtau = tau_out - tau_in;
+            pend_thick = fabs(pend_dtau) > limit;
+            const double tau_thin = p.fortran_consts ? tau_in : tau_out;                 // photorates.f90:121 / rates.cu:37
+            const double *tab = p.tables + (pend_thick ? 0 : p.table_len);
+            pend_A = lookup_issue(tab, pend_thick ? tau_in : tau_thin, p, logtab);
+            pend_B = lookup_issue(tab, pend_thick ? tau_out : tau_thin, p, logtab);
+            pend_dst = dst;
+            pend = rated;
+        }
+    };
+
+    unsigned e = threadIdx.x;
+    uint4 A0 = cellA[e], B0 = cellB[e];
+    uint4 A1 = cellA[e + RT_THREADS], B1 = cellB[e + RT_THREADS];
+    uint4 A2, B2;
+    unsigned idx0, idx1 = 0, idx2 = 0;
+    double nhi0 = *nhi_address(A0.x, idx0), nhi1 = 0.0, nhi2 = 0.0;
+
+    // nsteps is a multiple of 3 (the tables are padded to it) and is followed by two more
+    // all-invalid steps, so every look-ahead stays inside the tables.
+    for (int k = 0; k < nsteps; k += 3, e += 3 * RT_THREADS) {
+        step(e + 2 * RT_THREADS, A0, B0, nhi0, idx0, A1, nhi1, idx1, A2, B2);
+        step(e + 3 * RT_THREADS, A1, B1, nhi1, idx1, A2, nhi2, idx2, A0, B0);
+        step(e + 4 * RT_THREADS, A2, B2, nhi2, idx2, A0, nhi0, idx0, A1, B1);
     }
-    if (pend) { const double v = rate_value(job); if (!(p.ablate & 1)) unsafeAtomicAdd(pend_dst, v); else if (v == 1.2345e-300) pend_dst[0] = v; }
+    if (pend) {
+        const double ta = lookup_value(pend_A), tb = lookup_value(pend_B);
+        const double v = pend_thick ? pend_pref * ta - pend_pref * tb : pend_pref * pend_dtau * ta;
+        if (!(p.ablate & 1)) unsafeAtomicAdd(pend_dst, v); else if (v == 1.2345e-300) pend_dst[0] = v;
+    }
 
     // work accounting: one atomic per wave
     for (int o = 32; o > 0; o >>= 1) {
@@ -459,9 +501,11 @@ void build_octant_geometry(HostGeom &h, int Ea, int Eb, int Ec, double R, double
         h.max_cells = std::max(h.max_cells, count);
         slot_prev.swap(slot_cur);
     }
+    // the kernel walks the steps three at a time and looks two steps ahead: pad to a multiple of
+    // three steps and append four all-invalid steps so that every load stays inside the tables
+    while ((h.cellA.size() / RT_THREADS) % 3) for (int q = 0; q < RT_THREADS; ++q) { h.cellA.push_back(pad_a); h.cellB.push_back(pad_b); }
     h.nsteps = (int)(h.cellA.size() / RT_THREADS);
-    // two all-invalid steps so that the kernel's look-ahead loads stay inside the tables
-    for (int q = 0; q < 2 * RT_THREADS; ++q) { h.cellA.push_back(pad_a); h.cellB.push_back(pad_b); }
+    for (int q = 0; q < 4 * RT_THREADS; ++q) { h.cellA.push_back(pad_a); h.cellB.push_back(pad_b); }
 }
 
 template <typename T>

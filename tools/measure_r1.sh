@@ -1,0 +1,14 @@
+# Round-1 measurement set (run on the GPU box through gpurun).  Outputs under gpurun_out/r1/.
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r1; mkdir -p $O
+cd $R
+timeout -k 10 400 python bench.py --steps 20 --warmup 5 > $O/bench_uniform_R32.json 2> $O/bench_uniform_R32.err
+for RR in 16 64; do timeout -k 10 300 python bench.py --steps 10 --warmup 3 --R $RR --cpu-sources 0 > $O/bench_uniform_R$RR.json 2>/dev/null; done
+timeout -k 10 400 python bench.py --steps 10 --warmup 3 --workload cosmo --cpu-sources 0 > $O/bench_cosmo_R32.json 2> $O/bench_cosmo_R32.err
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 10 --warmup 3 --cpu-sources 0 > $O/stats.log 2>&1
+cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
+cd $R
+bash tools/pmc.sh r1 0 > $O/pmc.log 2>&1
+cp gpurun_out/pmc_r1_summary.txt $O/pmc_summary.txt
+timeout -k 10 300 python tools/pcie_inclusive.py > $O/pcie_inclusive.json 2> $O/pcie_inclusive.err
+ls -la $O
