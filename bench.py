@@ -72,7 +72,7 @@ def make_workload(kind, N, nsrc_total):
         k = np.fft.fftfreq(N)
         k2 = k[:, None, None] ** 2 + k[None, :, None] ** 2 + k[None, None, :N // 2 + 1] ** 2
         k2[0, 0, 0] = 1.0
-        g = np.fft.irfftn(np.fft.rfftn(white) / k2 ** 0.5 * (k2 > 0), s=(N, N, N))      # P(k) ~ k^-2
+        g = np.fft.irfftn(np.fft.rfftn(white) / k2 ** 0.5 * (k2 > 0), s=(N, N, N), axes=(0, 1, 2))   # P(k) ~ k^-2
         g /= g.std()
         sigma, nbar = 1.2, 1.87e-7 * (1 + 9.938) ** 3
         ndens = nbar * np.exp(sigma * g - sigma ** 2 / 2)
@@ -84,6 +84,30 @@ def make_workload(kind, N, nsrc_total):
     else:
         raise ValueError(kind)
     return ndens, xh, temp, dr, pos, flux
+
+
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the raytrace kernel from the committed PMC summary of this round
+    (profiles/r01_pmc_summary.txt: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc passes of
+    this same command).  Counters are in KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section)
+    prescribes for gfx950 -- the doubling was checked on this repository's chemistry kernel, whose
+    2*FETCH_SIZE equals its 5 N^3 float64 loads exactly.  Returns None when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.txt")
+    if not os.path.exists(path):
+        return None
+    fetch = write = None
+    for line in open(path):
+        if "raytrace_octant_kernel" not in line:
+            continue
+        parts = line.split()
+        for i, tok in enumerate(parts):
+            if tok == "FETCH_SIZE":
+                fetch = float(parts[-1].split("=")[1])
+            if tok == "WRITE_SIZE":
+                write = float(parts[-1].split("=")[1])
+    if fetch is None or write is None:
+        return None
+    return (2.0 * fetch + write) * 1024.0
 
 
 def cpu_baseline(kind, N, ndens, xh, temp, dr, pos, flux, thin, thick, dlog, R, nsrc_job, budget_sources):
@@ -205,8 +229,13 @@ def main():
         elapsed = float(tmax[0].item())
         tot_gamma = int(round(t[1].item()))
 
+    if comm is not None:
+        import torch.distributed as dist
+        dist.barrier()
     if rank != 0:
         p.device_close()
+        if comm is not None:
+            dist.destroy_process_group()
         return
 
     units_per_step = tot_gamma + N ** 3
@@ -247,7 +276,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-            "traffic": None,
+            "traffic": (pmc_traffic_bytes() if (args.workload == "uniform" and args.R == 32.0 and N == 256 and args.nsrc == 1000) else None),
+            "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_pmc_summary.txt (separate PMC passes)",
             "algorithmic_bytes_per_launch": RT_BYTES_PER_UPDATE * gamma_cells,
             "avg_launch_ms": rt_ms / max(rt_n, 1),
             "launches_timed": rt_n,
@@ -281,6 +311,8 @@ def main():
                                    "sample": f"failed: {type(e).__name__}: {e}"}
     p.device_close()
     print(json.dumps(out))
+    if comm is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

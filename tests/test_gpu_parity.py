@@ -344,3 +344,37 @@ def test_error_behaviour(asora):
     with pytest.raises(RuntimeError, match="does not match"):
         lib.density_to_device(np.zeros(8 ** 3), 8)
     p.device_close()
+
+
+# ---- multi-GPU plumbing that can be checked on one GPU ----------------------------------------------
+def test_rccl_allreduce_on_library_grid_world1(asora):
+    """torch.distributed (backend nccl == RCCL) all-reduce applied in place to the library's
+    device-resident phi_ion through a zero-copy __cuda_array_interface__ view.  One rank only (the box
+    has one GPU): checks the aliasing, the stream hand-over and that RCCL accepts the pointer."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from pyc2ray_amd import dist as pd
+    p, lib, capi = asora
+    N = 32
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 8)
+    if not dist.is_initialized():
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        pd.init_process_group_from_env("nccl")
+    comm = pd.TorchComm()
+    rng = np.random.default_rng(5)
+    phi = rng.uniform(size=(N, N, N))
+    lib.grid_to_device(capi.GRID_PHI_ION, phi)
+    view = torch.as_tensor(pd._DevicePointer(lib.device_ptr(capi.GRID_PHI_ION), N ** 3), device="cuda")
+    assert view.data_ptr() == lib.device_ptr(capi.GRID_PHI_ION)          # zero copy
+    np.testing.assert_array_equal(view.cpu().numpy().reshape(N, N, N), phi)
+    dist.all_reduce(view, op=dist.ReduceOp.SUM)                              # RCCL on the library's memory
+    view.mul_(2.0)                                                           # write through the view
+    torch.cuda.synchronize()
+    back = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+    np.testing.assert_array_equal(back, 2.0 * phi)
+    comm.allreduce_device_grid(lib, capi.GRID_PHI_ION, N)                    # world 1: no-op path
+    p.device_close()
