@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--workload", choices=["uniform", "cosmo"], default="uniform")
     ap.add_argument("--cpu-sources", type=int, default=64, help="sources in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--z-transposed", type=int, default=1)
+    ap.add_argument("--block-threads", type=int, default=0, help="raytrace workgroup size (0 = auto)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -183,6 +184,7 @@ def main():
     lib.grid_to_device(_capi.GRID_TEMP, temp)
     lib.grid_to_device(_capi.GRID_XH, xh)
     lib.set_option(_capi.OPT_Z_TRANSPOSED, args.z_transposed)
+    lib.set_option(_capi.OPT_BLOCK_THREADS, args.block_threads)
 
     def step():
         lib.grid_copy(_capi.GRID_XH_AV, _capi.GRID_XH)

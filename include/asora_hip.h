@@ -131,7 +131,9 @@ enum {
     ASORA_OPT_TIMING = 2,
     /* 0: z-faces read/accumulate through the [k][j][i] transposed copies (default 1). */
     ASORA_OPT_Z_TRANSPOSED = 3,
-    ASORA_OPT_COUNT = 4
+    /* Workgroup size of the raytrace kernel: 0 (default) = chosen from R; 64, 128, 256 or 512 force it. */
+    ASORA_OPT_BLOCK_THREADS = 4,
+    ASORA_OPT_COUNT = 5
 };
 int asora_set_option(int option, int value);
 int asora_get_option(int option);

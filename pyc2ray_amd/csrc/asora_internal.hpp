@@ -51,7 +51,7 @@ struct State {
     OctGeomDev geom_host[8];                // device pointers of the eight octant tables
     const double2 *logtab_dev = nullptr;
     bool geom_valid = false;
-    int geom_N = 0, geom_S = 0, geom_max_cells = 0;
+    int geom_N = 0, geom_S = 0, geom_max_cells = 0, geom_threads = 0;
     double geom_R = 0.0, geom_dr = 0.0;
 
     // shell scratch for traces whose shell buffers exceed LDS
@@ -69,7 +69,7 @@ struct State {
 
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1};
+    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0};
     double k_ms[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
     long k_n[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
 };

@@ -43,7 +43,6 @@
 
 namespace asora {
 
-constexpr int RT_THREADS = 256;
 constexpr double FOURPI = 12.566370614359172463991853874177;   // raytracing.cu:12
 constexpr int LOG_TABLE_BITS = 7;
 constexpr int LOG_TABLE_SIZE = 1 << LOG_TABLE_BITS;
@@ -165,7 +164,7 @@ __device__ __forceinline__ int wrap_once(int x, int N)
 // Slot max_cells of each shell buffer holds 0.0: upstream corners of weight 0 point there.
 constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_SLOT_MASK = (1u << 30) - 1;
 
-template <bool GLOBAL_SCRATCH, bool DUMP>
+template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP>
 __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtParams p)
 {
     extern __shared__ double lds_raw[];
@@ -422,7 +421,8 @@ inline bool inside_radius_reference(int a, int b, int c, double dr, double R2)
     return d2 / den <= R2;
 }
 
-void build_octant_geometry(HostGeom &h, int Ea, int Eb, int Ec, double R, double dr, int q_max, uint32_t zero_slot_marker)
+void build_octant_geometry(HostGeom &h, int Ea, int Eb, int Ec, double R, double dr, int q_max, uint32_t zero_slot_marker,
+                           int RT_THREADS)
 {
     const double R2 = R * R;
     const double R2hi = R2 * (1.0 + 1e-9) + 1e-9;
@@ -503,8 +503,8 @@ void build_octant_geometry(HostGeom &h, int Ea, int Eb, int Ec, double R, double
     }
     // the kernel walks the steps three at a time and looks two steps ahead: pad to a multiple of
     // three steps and append four all-invalid steps so that every load stays inside the tables
-    while ((h.cellA.size() / RT_THREADS) % 3) for (int q = 0; q < RT_THREADS; ++q) { h.cellA.push_back(pad_a); h.cellB.push_back(pad_b); }
-    h.nsteps = (int)(h.cellA.size() / RT_THREADS);
+    while ((h.cellA.size() / (size_t)RT_THREADS) % 3) for (int q = 0; q < RT_THREADS; ++q) { h.cellA.push_back(pad_a); h.cellB.push_back(pad_b); }
+    h.nsteps = (int)(h.cellA.size() / (size_t)RT_THREADS);
     for (int q = 0; q < 4 * RT_THREADS; ++q) { h.cellA.push_back(pad_a); h.cellB.push_back(pad_b); }
 }
 
@@ -532,13 +532,13 @@ void release_geometry(State &st)
 
 // Build (or reuse) the geometry tables for this (N, R, dr).  dr only enters through the
 // classification of cells sitting exactly on the sphere (see inside_radius_reference).
-static int ensure_geometry(State &st, RtParams &p)
+static int ensure_geometry(State &st, RtParams &p, int threads)
 {
     const int N = p.N;
     const int q_max = (int)std::ceil(1.73205080757 * std::min(p.R, 1.73205080757 * N / 2.0));   // raytracing.cu:14,101
     const int ext_pos = N / 2 - 1 + (N % 2);                                                      // raytracing.cu:122
     const int ext_neg = N / 2;                                                                    // raytracing.cu:123
-    if (st.geom_valid && st.geom_N == N && st.geom_R == p.R && st.geom_dr == p.dr) {
+    if (st.geom_valid && st.geom_N == N && st.geom_R == p.R && st.geom_dr == p.dr && st.geom_threads == threads) {
         for (int o = 0; o < 8; ++o) p.geom[o] = st.geom_host[o];
         p.logtab = st.logtab_dev; p.S = st.geom_S; p.max_cells = st.geom_max_cells;
         return 0;
@@ -566,7 +566,7 @@ static int ensure_geometry(State &st, RtParams &p)
     const uint32_t MARK = 0xffffffffu;
     for (int oct = 0; oct < 8; ++oct) {
         if (owner[oct] != oct) continue;
-        build_octant_geometry(hg[oct], ext(oct, 0), ext(oct, 1), ext(oct, 2), p.R, p.dr, q_max, MARK);
+        build_octant_geometry(hg[oct], ext(oct, 0), ext(oct, 1), ext(oct, 2), p.R, p.dr, q_max, MARK, threads);
         Smax = std::max(Smax, hg[oct].S);
         max_cells = std::max(max_cells, hg[oct].max_cells);
     }
@@ -601,6 +601,7 @@ static int ensure_geometry(State &st, RtParams &p)
     for (int o = 0; o < 8; ++o) st.geom_host[o] = od[o];
     st.logtab_dev = ltd;
     st.geom_N = N; st.geom_R = p.R; st.geom_dr = p.dr; st.geom_S = Smax; st.geom_max_cells = (int)max_cells;
+    st.geom_threads = threads;
     st.geom_valid = true;
     for (int o = 0; o < 8; ++o) p.geom[o] = od[o];
     p.logtab = ltd; p.S = Smax; p.max_cells = (int)max_cells;
@@ -698,9 +699,42 @@ int launch_transpose(State &st, const double *src, double *dst, int N)
 // ---------------------------------------------------------------------------------------------
 static const size_t LDS_LIMIT_BYTES = 160 * 1024;
 
+// Workgroup size: shells of a small trace do not fill 256 lanes (R=16: <= 310 cells), shells of a large one
+// need so much LDS that only two workgroups fit a CU (R=64: 77 KB) -- then 512 threads restore the wave count.
+static int pick_threads(const State &st, double R, int N, bool dump)
+{
+    if (dump) return 256;
+    const int forced = st.opt[ASORA_OPT_BLOCK_THREADS];
+    if (forced == 64 || forced == 128 || forced == 256 || forced == 512) return forced;
+    const double r = std::min(R, 0.87 * N);                 // the window cuts the trace at ~sqrt(3)/2 N
+    const double est_cells = 1.2 * r * r;                   // largest shell of an octant
+    // thresholds from a sweep on MI355X (1000 sources, 256^3): R<=20 -> 64, 24..28 -> 128, 32..44 -> 256, >=48 -> 512
+    if (est_cells <= 580.0) return 64;
+    if (est_cells <= 1080.0) return 128;
+    if (est_cells <= 2700.0) return 256;
+    return 512;
+}
+
+template <int T>
+static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t lds_bytes, bool use_lds, bool dump)
+{
+#define ASORA_LAUNCH(GS, DP)                                                                                   \
+    do {                                                                                                       \
+        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, GS, DP>,                     \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));        \
+        hipLaunchKernelGGL((raytrace_octant_kernel<T, GS, DP>), dim3(grid), dim3(T), lds_bytes, st.stream, q); \
+    } while (0)
+    if (T == 256 && dump) { if (use_lds) ASORA_LAUNCH(false, true); else ASORA_LAUNCH(true, true); }
+    else                  { if (use_lds) ASORA_LAUNCH(false, false); else ASORA_LAUNCH(true, false); }
+#undef ASORA_LAUNCH
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_raytrace(State &st, RtParams &p, bool dump)
 {
-    if (int rc = ensure_geometry(st, p)) return rc;
+    const int threads = pick_threads(st, p.R, p.N, dump);
+    if (int rc = ensure_geometry(st, p, threads)) return rc;
     p.lut_k1 = 0.30102999566398119521 / p.dlogtau;      // log10(2)/dlogtau
     p.lut_k0 = 1.0 - p.minlogtau / p.dlogtau;
 
@@ -736,17 +770,14 @@ int launch_raytrace(State &st, RtParams &p, bool dump)
         const unsigned grid = 64u * (unsigned)((batch + 7) / 8);
         {
             KernelTimer kt(ASORA_KERNEL_RAYTRACE);
-#define ASORA_LAUNCH(GS, DP)                                                                                   \
-    do {                                                                                                       \
-        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<GS, DP>,                        \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));        \
-        hipLaunchKernelGGL((raytrace_octant_kernel<GS, DP>), dim3(grid), dim3(RT_THREADS), lds_bytes,          \
-                           st.stream, q);                                                                      \
-    } while (0)
-            if (use_lds) { if (dump) ASORA_LAUNCH(false, true); else ASORA_LAUNCH(false, false); }
-            else         { if (dump) ASORA_LAUNCH(true, true);  else ASORA_LAUNCH(true, false); }
-#undef ASORA_LAUNCH
-            ASORA_HIP_TRY(hipGetLastError());
+            int rc = 0;
+            switch (threads) {
+                case 64:  rc = launch_variant<64>(st, q, grid, lds_bytes, use_lds, dump); break;
+                case 128: rc = launch_variant<128>(st, q, grid, lds_bytes, use_lds, dump); break;
+                case 512: rc = launch_variant<512>(st, q, grid, lds_bytes, use_lds, dump); break;
+                default:  rc = launch_variant<256>(st, q, grid, lds_bytes, use_lds, dump); break;
+            }
+            if (rc) return rc;
         }
         done += batch;
     }
