@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--cpu-sources", type=int, default=64, help="sources in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--z-transposed", type=int, default=1)
     ap.add_argument("--block-threads", type=int, default=0, help="raytrace workgroup size (0 = auto)")
+    ap.add_argument("--sectors", type=int, default=0, help="0 auto, 1 octant workgroups, 2 octant x sector workgroups")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -185,6 +186,7 @@ def main():
     lib.grid_to_device(_capi.GRID_XH, xh)
     lib.set_option(_capi.OPT_Z_TRANSPOSED, args.z_transposed)
     lib.set_option(_capi.OPT_BLOCK_THREADS, args.block_threads)
+    lib.set_option(_capi.OPT_SECTORS, args.sectors)
 
     def step():
         lib.grid_copy(_capi.GRID_XH_AV, _capi.GRID_XH)

@@ -133,7 +133,10 @@ enum {
     ASORA_OPT_Z_TRANSPOSED = 3,
     /* Workgroup size of the raytrace kernel: 0 (default) = chosen from R; 64, 128, 256 or 512 force it. */
     ASORA_OPT_BLOCK_THREADS = 4,
-    ASORA_OPT_COUNT = 5
+    /* Decomposition of a source: 0 (default) = chosen from R; 1 = one workgroup per octant;
+     * 2 = one per octant and dominant-axis sector (24 per source, diagonal planes re-derived). */
+    ASORA_OPT_SECTORS = 5,
+    ASORA_OPT_COUNT = 6
 };
 int asora_set_option(int option, int value);
 int asora_get_option(int option);

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libasora_hip.so")
 
 # grid selectors / options / kernels, as in include/asora_hip.h
 GRID_NDENS, GRID_XH_AV, GRID_PHI_ION, GRID_TEMP, GRID_XH, GRID_XH_INTERMED = range(6)
-OPT_FORTRAN_CONSTANTS, OPT_GREY_NOTABLES, OPT_TIMING, OPT_Z_TRANSPOSED, OPT_BLOCK_THREADS = range(5)
+OPT_FORTRAN_CONSTANTS, OPT_GREY_NOTABLES, OPT_TIMING, OPT_Z_TRANSPOSED, OPT_BLOCK_THREADS, OPT_SECTORS = range(6)
 KERNEL_RAYTRACE, KERNEL_CHEMISTRY, KERNEL_PREP, KERNEL_FINISH = range(4)
 
 _dp = C.POINTER(C.c_double)

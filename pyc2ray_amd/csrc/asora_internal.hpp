@@ -48,7 +48,8 @@ struct State {
 
     // raytracing geometry tables (built once per (N, R, dr), see raytrace.hip)
     std::vector<void *> geom_owned;
-    OctGeomDev geom_host[8];                // device pointers of the eight octant tables
+    OctGeomDev geom_host[24];               // device pointers of the unit tables
+    int geom_units = 0;
     const double2 *logtab_dev = nullptr;
     bool geom_valid = false;
     int geom_N = 0, geom_S = 0, geom_max_cells = 0, geom_threads = 0;
@@ -69,7 +70,7 @@ struct State {
 
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0};
+    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0};
     double k_ms[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
     long k_n[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
 };
@@ -109,7 +110,8 @@ struct RtParams {
     int fortran_consts, grey, z_transposed;
     int src_begin, src_count;
     int ablate;            // diagnostics only (env ASORA_ABLATE): 1 = no rate atomics, 2 = no rates
-    OctGeomDev geom[8];         // by value: pointers read from the kernarg segment are known-global to the compiler
+    OctGeomDev geom[24];        // by value: pointers read from the kernarg segment are known-global to the compiler
+    int units;                  // 8: one workgroup per octant; 24: per octant and sector (unit = sector*8 + octant)
     const double2 *logtab;      // 128 x {1/c, log2 c}
     const double *nhi;          // nHI [i][j][k]; the [k][j][i] copy sits nhi_t_off elements further
     long long nhi_t_off;

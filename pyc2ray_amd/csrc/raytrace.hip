@@ -162,7 +162,7 @@ __device__ __forceinline__ int wrap_once(int x, int N)
 // Dynamic LDS: [shell buffer 0: max_cells+1 doubles][shell buffer 1: same]   (unless GLOBAL_SCRATCH)
 //              [log table: 128 x {1/c, log2 c}][1/s: S+1 doubles][wrapped i(a), j(b), k(c): 3*(S+1) ints]
 // Slot max_cells of each shell buffer holds 0.0: upstream corners of weight 0 point there.
-constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_SLOT_MASK = (1u << 30) - 1;
+constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_RATE = 1u << 29, CELL_SLOT_MASK = (1u << 29) - 1;
 
 template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP>
 __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtParams p)
@@ -172,14 +172,16 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
     const int blk = blockIdx.x;
     // blocks b and b+8 share an XCD (round-robin dispatch): keep the 8 octants of one source
     // on one XCD so that they share its L2 lines of nHI.  Speed only, never correctness.
-    const int src_local = (blk & 7) + 8 * (blk >> 6);
-    const int oct = (blk >> 3) & 7;
+    // p.units = 8 (one workgroup per octant) or 24 (per octant and sector); unit = sector*8 + octant
+    const int src_local = (blk & 7) + 8 * (blk / (8 * p.units));
+    const int unit = (blk >> 3) % p.units;
+    const int oct = unit & 7;
     if (src_local >= p.src_count) return;
     const int ns = p.src_begin + src_local;
 
-    const uint4 *__restrict__ cellA = p.geom[oct].cellA;
-    const uint4 *__restrict__ cellB = p.geom[oct].cellB;
-    const int nsteps = p.geom[oct].nsteps;
+    const uint4 *__restrict__ cellA = p.geom[unit].cellA;
+    const uint4 *__restrict__ cellB = p.geom[unit].cellB;
+    const int nsteps = p.geom[unit].nsteps;
     const int N = p.N;
     const int i0 = p.src_pos[3 * ns + 0];
     const int j0 = p.src_pos[3 * ns + 1];
@@ -229,7 +231,7 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
         const double cd_out = 0.0 + nHI * path;
         prev[0] = cd_out;
         ++n_eval;
-        if (oct == 0) {
+        if (unit == (p.units == 24 ? 16 : 0)) {       // the source cell is rated once: octant 0 (z-sector)
             if (DUMP) p.dump[idx] = cd_out;
             const double phi = photo_rate_per_atom(flux, 0.0, cd_out, dr * dr * dr * nHI, p, logtab);
             unsafeAtomicAdd(&p.phi[idx], phi);
@@ -318,7 +320,7 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
         // a cell on an octant-boundary plane is rated by the octant with the + sign there
         const unsigned zmask = (a == 0 ? 1u : 0u) | (b == 0 ? 2u : 0u) | (c == 0 ? 4u : 0u);
         const double maxcd = p.fortran_consts ? (double)2e30f : 2e30;                    // raytracing.cu:15
-        const bool owner = valid && (zmask & negmask) == 0;
+        const bool owner = valid && (cur_A.y & CELL_RATE) && (zmask & negmask) == 0;
         if (DUMP) { if (owner) p.dump[(wi[a] * N + wj[b]) * N + wk[c]] = cd_out; }
         rated = owner && cd_in <= maxcd && !(p.ablate & 2);
         n_gamma += (owner && cd_in <= maxcd) ? 1u : 0u;
@@ -408,6 +410,7 @@ struct HostGeom {
     int S = 0;
     int nsteps = 0;
     uint32_t max_cells = 1;
+    bool inconsistent = false;   // a corner of non-zero weight was not found in the unit
 };
 
 inline bool inside_radius_reference(int a, int b, int c, double dr, double R2)
@@ -421,8 +424,17 @@ inline bool inside_radius_reference(int a, int b, int c, double dr, double R2)
     return d2 / den <= R2;
 }
 
+// `unit` selects which dependency-closed part of the octant the table covers:
+//   -1 : the whole octant (one workgroup per octant);
+//    2 : the z-sector = all dk = s cells (closed: their corners are dk = s-1 cells);
+//    1 : the y-sector = the dj = s cells plus the plane {dj = dk} of the z-sector they read
+//        (that plane only reads itself);
+//    0 : the x-sector = the di = s cells plus the planes {di = dk} (z-sector) and {di = dj} (y-sector)
+//        they read (each of which only reads itself and the main diagonal, which is in {di = dk}).
+// A cell is RATED by its home unit only (its own face's sector); the copies a sector keeps of another
+// sector's plane are evaluated for their column density but not rated.
 void build_octant_geometry(HostGeom &h, int Ea, int Eb, int Ec, double R, double dr, int q_max, uint32_t zero_slot_marker,
-                           int RT_THREADS)
+                           int RT_THREADS, int unit)
 {
     const double R2 = R * R;
     const double R2hi = R2 * (1.0 + 1e-9) + 1e-9;
@@ -456,6 +468,14 @@ void build_octant_geometry(HostGeom &h, int Ea, int Eb, int Ec, double R, double
         uint32_t count = 0;
         auto emit = [&](int a, int b, int c, int face, int U, int V) {
             if (!in_sphere(a, b, c)) return;
+            bool rate = true;
+            if (unit >= 0 && face != unit) {
+                // a foreign cell: kept only if this sector reads it
+                const bool keep = (unit == 1) ? (face == 2 && b == c)
+                                              : (unit == 0) ? ((face == 2 && a == c) || (face == 1 && a == b)) : false;
+                if (!keep) return;
+                rate = false;
+            }
             const double u = (double)U, v = (double)V;
             const bool em = U >= 1, e0 = U <= s - 1, fm = V >= 1, f0 = V <= s - 1;
             auto corner = [&](int uu, int vv) -> uint32_t {
@@ -470,12 +490,18 @@ void build_octant_geometry(HostGeom &h, int Ea, int Eb, int Ec, double R, double
             nb.y = (e0 && fm) ? corner(U, V - 1) : zero_slot_marker;
             nb.z = (em && f0) ? corner(U - 1, V) : zero_slot_marker;
             nb.w = (e0 && f0) ? corner(U, V) : zero_slot_marker;
+            {   // every corner that carries weight must be part of this unit
+                const double fu = U == s ? 1.0 : u / sd, fv = V == s ? 1.0 : v / sd;
+                const double wts[4] = {fu * fv, fv * (1.0 - fu), fu * (1.0 - fv), (1.0 - fu) * (1.0 - fv)};
+                const uint32_t sl[4] = {nb.x, nb.y, nb.z, nb.w};
+                for (int q = 0; q < 4; ++q) if (wts[q] != 0.0 && sl[q] == zero_slot_marker) h.inconsistent = true;
+            }
             const double path = std::sqrt((u * u + v * v) / (sd * sd) + 1.0);  // raytracing.cu:444
             uint64_t pbits;
             std::memcpy(&pbits, &path, sizeof pbits);
             uint4 ca;
             ca.x = (uint32_t)a | ((uint32_t)b << 10) | ((uint32_t)c << 20) | ((uint32_t)face << 30);
-            ca.y = count | CELL_VALID;
+            ca.y = count | CELL_VALID | (rate ? CELL_RATE : 0u);
             ca.z = (uint32_t)(pbits & 0xffffffffu);
             ca.w = (uint32_t)(pbits >> 32);
             h.cellA.push_back(ca);
@@ -532,48 +558,58 @@ void release_geometry(State &st)
 
 // Build (or reuse) the geometry tables for this (N, R, dr).  dr only enters through the
 // classification of cells sitting exactly on the sphere (see inside_radius_reference).
-static int ensure_geometry(State &st, RtParams &p, int threads)
+static int ensure_geometry(State &st, RtParams &p, int threads, int units)
 {
     const int N = p.N;
     const int q_max = (int)std::ceil(1.73205080757 * std::min(p.R, 1.73205080757 * N / 2.0));   // raytracing.cu:14,101
     const int ext_pos = N / 2 - 1 + (N % 2);                                                      // raytracing.cu:122
     const int ext_neg = N / 2;                                                                    // raytracing.cu:123
-    if (st.geom_valid && st.geom_N == N && st.geom_R == p.R && st.geom_dr == p.dr && st.geom_threads == threads) {
-        for (int o = 0; o < 8; ++o) p.geom[o] = st.geom_host[o];
+    if (st.geom_valid && st.geom_N == N && st.geom_R == p.R && st.geom_dr == p.dr && st.geom_threads == threads &&
+        st.geom_units == units) {
+        for (int o = 0; o < units; ++o) p.geom[o] = st.geom_host[o];
+        p.units = units;
         p.logtab = st.logtab_dev; p.S = st.geom_S; p.max_cells = st.geom_max_cells;
         return 0;
     }
     release_geometry(st);
 
-    // octants with the same periodic window share one table; when the sphere does not reach the
-    // window on any axis all eight are identical
+    // unit = sector*8 + octant (sector = face code 0:x 1:y 2:z; one unit per octant when units == 8).
+    // Units with the same sector and the same periodic window share one table; when the sphere does
+    // not reach the window on any axis all octants are identical.
     const double R2hi_all = p.R * p.R * (1.0 + 1e-9) + 1e-9;
     const bool unclipped = std::isfinite(R2hi_all) && std::floor(std::sqrt(R2hi_all)) <= (double)std::min(ext_pos, ext_neg);
     auto ext = [&](int oct, int ax) { return ((oct >> ax) & 1) ? ext_neg : ext_pos; };
-    int owner[8];
-    for (int oct = 0; oct < 8; ++oct) {
-        owner[oct] = oct;
-        for (int o2 = 0; o2 < oct; ++o2)
+    int owner[24];
+    for (int u = 0; u < units; ++u) {
+        owner[u] = u;
+        const int oct = u & 7;
+        for (int u2 = 0; u2 < u; ++u2) {
+            const int o2 = u2 & 7;
+            if ((u2 >> 3) != (u >> 3)) continue;
             if (unclipped || (ext(oct, 0) == ext(o2, 0) && ext(oct, 1) == ext(o2, 1) && ext(oct, 2) == ext(o2, 2))) {
-                owner[oct] = owner[o2];
+                owner[u] = owner[u2];
                 break;
             }
+        }
     }
-    HostGeom hg[8];
-    OctGeomDev od[8];
+    std::vector<HostGeom> hg(units);
+    OctGeomDev od[24];
     int Smax = 0;
     uint32_t max_cells = 1;
     const uint32_t MARK = 0xffffffffu;
-    for (int oct = 0; oct < 8; ++oct) {
-        if (owner[oct] != oct) continue;
-        build_octant_geometry(hg[oct], ext(oct, 0), ext(oct, 1), ext(oct, 2), p.R, p.dr, q_max, MARK, threads);
-        Smax = std::max(Smax, hg[oct].S);
-        max_cells = std::max(max_cells, hg[oct].max_cells);
+    for (int u = 0; u < units; ++u) {
+        if (owner[u] != u) continue;
+        const int oct = u & 7, sector = units == 24 ? (u >> 3) : -1;
+        build_octant_geometry(hg[u], ext(oct, 0), ext(oct, 1), ext(oct, 2), p.R, p.dr, q_max, MARK, threads, sector);
+        if (hg[u].inconsistent)
+            return fail(11, "raytrace geometry: a cell of a sector reads a corner outside the sector (internal error)");
+        Smax = std::max(Smax, hg[u].S);
+        max_cells = std::max(max_cells, hg[u].max_cells);
     }
     // zero-slot marker -> max_cells (the slot that holds 0.0), then upload
-    for (int oct = 0; oct < 8; ++oct) {
-        if (owner[oct] != oct) continue;
-        HostGeom &h = hg[oct];
+    for (int u = 0; u < units; ++u) {
+        if (owner[u] != u) continue;
+        HostGeom &h = hg[u];
         for (auto &nb : h.cellB) {
             if (nb.x == MARK) nb.x = max_cells;
             if (nb.y == MARK) nb.y = max_cells;
@@ -582,11 +618,12 @@ static int ensure_geometry(State &st, RtParams &p, int threads)
         }
         OctGeomDev d;
         d.nsteps = h.nsteps;
+        d.pad_ = 0;
         if (int rc = upload(h.cellA, d.cellA, st.geom_owned)) return rc;
         if (int rc = upload(h.cellB, d.cellB, st.geom_owned)) return rc;
-        od[oct] = d;
+        od[u] = d;
     }
-    for (int oct = 0; oct < 8; ++oct) od[oct] = od[owner[oct]];
+    for (int u = 0; u < units; ++u) od[u] = od[owner[u]];
 
     // log2 table: interval centres c = 1 + (i + 1/2)/128, entries {1/c, log2 c}
     std::vector<double2> lt(LOG_TABLE_SIZE);
@@ -598,12 +635,14 @@ static int ensure_geometry(State &st, RtParams &p, int threads)
     const double2 *ltd = nullptr;
     if (int rc = upload(lt, ltd, st.geom_owned)) return rc;
 
-    for (int o = 0; o < 8; ++o) st.geom_host[o] = od[o];
+    for (int o = 0; o < units; ++o) st.geom_host[o] = od[o];
+    st.geom_units = units;
     st.logtab_dev = ltd;
     st.geom_N = N; st.geom_R = p.R; st.geom_dr = p.dr; st.geom_S = Smax; st.geom_max_cells = (int)max_cells;
     st.geom_threads = threads;
     st.geom_valid = true;
-    for (int o = 0; o < 8; ++o) p.geom[o] = od[o];
+    for (int o = 0; o < units; ++o) p.geom[o] = od[o];
+    p.units = units;
     p.logtab = ltd; p.S = Smax; p.max_cells = (int)max_cells;
     return 0;
 }
@@ -699,20 +738,25 @@ int launch_transpose(State &st, const double *src, double *dst, int N)
 // ---------------------------------------------------------------------------------------------
 static const size_t LDS_LIMIT_BYTES = 160 * 1024;
 
-// Workgroup size: shells of a small trace do not fill 256 lanes (R=16: <= 310 cells), shells of a large one
-// need so much LDS that only two workgroups fit a CU (R=64: 77 KB) -- then 512 threads restore the wave count.
-static int pick_threads(const State &st, double R, int N, bool dump)
+// Decomposition and workgroup size.  Shells of a small trace do not fill 256 lanes (R=16: <= 310 cells per
+// octant shell); shells of a large one need so much LDS that only two octant workgroups fit a CU (R=64: 77 KB),
+// where splitting each octant into its three sectors restores the wave count.  Thresholds from sweeps on
+// MI355X (1000 sources, 256^3; tools/sweep_threads.sh):
+//   R <= 20: octants x 64 threads | 24..28: octants x 128 | 32..44: octants x 256 | >= 48: sectors x 256
+static void pick_launch_shape(const State &st, double R, int N, bool dump, int &units, int &threads)
 {
-    if (dump) return 256;
-    const int forced = st.opt[ASORA_OPT_BLOCK_THREADS];
-    if (forced == 64 || forced == 128 || forced == 256 || forced == 512) return forced;
     const double r = std::min(R, 0.87 * N);                 // the window cuts the trace at ~sqrt(3)/2 N
     const double est_cells = 1.2 * r * r;                   // largest shell of an octant
-    // thresholds from a sweep on MI355X (1000 sources, 256^3): R<=20 -> 64, 24..28 -> 128, 32..44 -> 256, >=48 -> 512
-    if (est_cells <= 580.0) return 64;
-    if (est_cells <= 1080.0) return 128;
-    if (est_cells <= 2700.0) return 256;
-    return 512;
+    if (est_cells <= 580.0) { units = 8; threads = 64; }
+    else if (est_cells <= 1080.0) { units = 8; threads = 128; }
+    else if (est_cells <= 2700.0) { units = 8; threads = 256; }
+    else { units = 24; threads = 256; }
+    const int want_sectors = st.opt[ASORA_OPT_SECTORS];
+    if (want_sectors == 1) units = 8;
+    if (want_sectors == 2) units = 24;
+    const int forced = st.opt[ASORA_OPT_BLOCK_THREADS];
+    if (forced == 64 || forced == 128 || forced == 256 || forced == 512) threads = forced;
+    if (dump) threads = 256;                                // the column-density dump variant is built for 256 only
 }
 
 template <int T>
@@ -733,8 +777,9 @@ static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t ld
 
 int launch_raytrace(State &st, RtParams &p, bool dump)
 {
-    const int threads = pick_threads(st, p.R, p.N, dump);
-    if (int rc = ensure_geometry(st, p, threads)) return rc;
+    int units, threads;   // one workgroup per (source, octant) or per (source, octant, sector)
+    pick_launch_shape(st, p.R, p.N, dump, units, threads);
+    if (int rc = ensure_geometry(st, p, threads, units)) return rc;
     p.lut_k1 = 0.30102999566398119521 / p.dlogtau;      // log10(2)/dlogtau
     p.lut_k0 = 1.0 - p.minlogtau / p.dlogtau;
 
@@ -750,11 +795,11 @@ int launch_raytrace(State &st, RtParams &p, bool dump)
         if (!use_lds) {
             // bound the global shell scratch to ~2 GiB per launch (the reference's source batching,
             // raytracing.cu:126, reappears only for traces whose shells outgrow LDS)
-            const size_t per_src = 8 * shell_bytes;
+            const size_t per_src = (size_t)units * shell_bytes;
             const size_t budget = (size_t)2 << 30;
             int max_batch = (int)std::max<size_t>(8, (budget / per_src) / 8 * 8);
             batch = std::min(batch, max_batch);
-            const size_t need = (size_t)64 * ((batch + 7) / 8) * shell_bytes;
+            const size_t need = (size_t)8 * units * ((batch + 7) / 8) * shell_bytes;
             if (need > st.shell_scratch_bytes) {
                 if (st.shell_scratch) ASORA_HIP_TRY(hipFree(st.shell_scratch));
                 st.shell_scratch = nullptr;
@@ -767,7 +812,7 @@ int launch_raytrace(State &st, RtParams &p, bool dump)
         q.src_begin = p.src_begin + done;
         q.src_count = batch;
         q.shell_scratch = use_lds ? nullptr : st.shell_scratch;
-        const unsigned grid = 64u * (unsigned)((batch + 7) / 8);
+        const unsigned grid = 8u * (unsigned)units * (unsigned)((batch + 7) / 8);
         {
             KernelTimer kt(ASORA_KERNEL_RAYTRACE);
             int rc = 0;

@@ -140,6 +140,34 @@ def test_z_transposed_layout_is_only_a_layout(asora):
     np.testing.assert_allclose(a, b, rtol=1e-13, atol=0)
 
 
+@pytest.mark.parametrize("name", ["u16_1src_R8", "l16_7src_R5.5", "l17_3src_Rbox", "l32_5src_R10", "l16_thick"])
+@pytest.mark.parametrize("threads", [64, 128, 256, 512])
+def test_decomposition_and_workgroup_size_do_not_change_results(asora, name, threads):
+    """One workgroup per octant vs one per (octant, sector), at every workgroup size: same Gamma and the
+    same count of rated pairs; the sector form evaluates a few more column densities (re-derived planes)."""
+    p, lib, capi = asora
+    c = cases.rt_case(name, "soft")
+    N = c["N"]
+    pos0, flux = _setup(p, lib, c, N)
+    numtau = c["thin"].shape[0] - 1
+    ref = O.asora_do_all_sources(c["R"], c["sig"], c["dr"], c["ndens"], c["xh"], pos0, flux, c["thin"], c["thick"],
+                                 c["minlogtau"], c["dlogtau"], NumTau=numtau, flags=O.ASORA_MODE)["phi_ion"]
+    out = {}
+    try:
+        lib.set_option(capi.OPT_BLOCK_THREADS, threads)
+        for mode in (1, 2):
+            lib.set_option(capi.OPT_SECTORS, mode)
+            phi = _asora_call(lib, c, N, numtau)
+            np.testing.assert_allclose(phi, ref, rtol=GAMMA_RTOL, atol=0)
+            out[mode] = (phi, lib.last_raytrace_counts())
+    finally:
+        lib.set_option(capi.OPT_SECTORS, 0)
+        lib.set_option(capi.OPT_BLOCK_THREADS, 0)
+    np.testing.assert_allclose(out[1][0], out[2][0], rtol=1e-12, atol=0)
+    assert out[1][1][0] == out[2][1][0]               # rated pairs
+    assert out[2][1][1] >= out[1][1][1]               # evaluations
+
+
 def test_grey_notables_option(asora):
     p, lib, capi = asora
     c = cases.rt_case("l16_7src_R5.5", "grey")
