@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <vector>
 
 namespace asora {
 
@@ -253,10 +254,18 @@ int asora_photo_table_to_device(const double *thin_table, const double *thick_ta
     if (NumTau < 1 || !thin_table || !thick_table) return fail(3, "photo_table_to_device: empty table");
     State &st = g_state;
     if (st.tables) { (void)hipFree(st.tables); st.tables = nullptr; }
-    const size_t bytes = sizeof(double) * (size_t)NumTau;
-    ASORA_HIP_TRY(hipMalloc(&st.tables, 2 * bytes));
-    ASORA_HIP_TRY(hipMemcpy(st.tables, thick_table, bytes, hipMemcpyHostToDevice));
-    ASORA_HIP_TRY(hipMemcpy(st.tables + NumTau, thin_table, bytes, hipMemcpyHostToDevice));
+    // device layout: pairs {T[i], T[i+1]-T[i]} so that one 16-byte load serves the linear interpolation
+    // of photo_lookuptable (rates.cu:82); the last pair is {T[last], 0}
+    std::vector<double2> pairs(2 * (size_t)NumTau);
+    for (int t = 0; t < 2; ++t) {
+        const double *src = t == 0 ? thick_table : thin_table;
+        for (int i = 0; i < NumTau; ++i) {
+            pairs[(size_t)t * NumTau + i].x = src[i];
+            pairs[(size_t)t * NumTau + i].y = (i + 1 < NumTau) ? src[i + 1] - src[i] : 0.0;
+        }
+    }
+    ASORA_HIP_TRY(hipMalloc(&st.tables, pairs.size() * sizeof(double2)));
+    ASORA_HIP_TRY(hipMemcpy(st.tables, pairs.data(), pairs.size() * sizeof(double2), hipMemcpyHostToDevice));
     st.table_len = NumTau;
     return 0;
 }

@@ -39,7 +39,7 @@ struct State {
     double *phi_t = nullptr;   // rate accumulator for z-faces, transposed [k][j][i]
     double *staging = nullptr; // N^3 staging grid for 'F'-order transfers / debug dumps
 
-    double *tables = nullptr;      // [thick | thin], each table_len long
+    double2 *tables = nullptr;     // [thick | thin] as pairs {T[i], T[i+1]-T[i]}, each table_len long
     int table_len = 0;
 
     int32_t *src_pos = nullptr;
@@ -117,7 +117,7 @@ struct RtParams {
     long long nhi_t_off;
     double *phi;                // Gamma accumulator [i][j][k]; the transposed one phi_t_off elements further
     long long phi_t_off;
-    const double *tables;       // thick table at [0, table_len), thin at [table_len, 2*table_len)
+    const double2 *tables;      // pairs {T[i], T[i+1]-T[i]}: thick table at [0, table_len), thin at [table_len, 2*table_len)
     const int32_t *src_pos;
     const double *src_flux;
     double *dump;               // debug: outgoing column density (N^3) or nullptr

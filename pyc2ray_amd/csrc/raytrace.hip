@@ -75,24 +75,20 @@ __device__ __forceinline__ double log2_pos(double x, const double2 *__restrict__
 // 1 + (log10(tau) - minlogtau)/dlogtau; here that is one fused multiply-add on log2(tau) with
 // k1 = log10(2)/dlogtau, k0 = 1 - minlogtau/dlogtau.  Indices are clamped to the last table
 // element (the reference reads one past the end when NumTau == len(table), tau >= 10^maxlogtau).
-struct Lookup { double t0, t1, residual; };
-__device__ __forceinline__ Lookup lookup_issue(const double *__restrict__ table, double tau, const RtParams &p,
+// The device tables hold pairs {T[i], T[i+1] - T[i]} (last pair {T[last], 0}): one 16-byte load per lookup.
+struct Lookup { double2 t; double residual; };
+__device__ __forceinline__ Lookup lookup_issue(const double2 *__restrict__ table, double tau, const RtParams &p,
                                                const double2 *__restrict__ logtab)
 {
     const double l2 = log2_pos(fmax(1.0e-20, tau), logtab);
     const double real_i = fmin(p.numtau_f, fmax(0.0, fma(l2, p.lut_k1, p.lut_k0)));
-    int i0 = (int)real_i;
-    int i1 = min(p.NumTau, i0 + 1);
+    const int i0 = (int)real_i;
     Lookup L;
     L.residual = real_i - (double)i0;
-    const int last = p.table_len - 1;
-    i0 = min(i0, last);
-    i1 = min(i1, last);
-    L.t0 = table[i0];
-    L.t1 = table[i1];
+    L.t = table[min(i0, p.table_len - 1)];
     return L;
 }
-__device__ __forceinline__ double lookup_value(const Lookup &L) { return fma(L.residual, L.t1 - L.t0, L.t0); }
+__device__ __forceinline__ double lookup_value(const Lookup &L) { return fma(L.residual, L.t.y, L.t.x); }
 
 // photoion_rates_gpu rates.cu:16-41 divided by nHI (raytracing.cu:324), also in two halves.
 // pref = flux/(vol*nHI) replaces the reference's two divisions by one.  A cell is "thick" when
@@ -117,7 +113,7 @@ __device__ __forceinline__ RateJob rate_issue(double flux, double cd_in, double 
     const double tau_thin = p.fortran_consts ? tau_in : tau_out;
     // one code path for both kinds of cell: per-lane table and arguments
     // thick table at [0, table_len), thin table at [table_len, 2*table_len) of one allocation
-    const double *tab = p.tables + (J.thick ? 0 : p.table_len);
+    const double2 *tab = p.tables + (J.thick ? 0 : p.table_len);
     J.A = lookup_issue(tab, J.thick ? tau_in : tau_thin, p, logtab);
     J.B = lookup_issue(tab, J.thick ? tau_out : tau_thin, p, logtab);
     return J;
@@ -189,7 +185,7 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
     const double flux = p.src_flux[ns];
     const int sa = (oct & 1) ? -1 : 1, sb = (oct & 2) ? -1 : 1, sc = (oct & 4) ? -1 : 1;
 
-    const int slots = p.max_cells + 1;
+    const int slots = (p.max_cells + 2) & ~1;      // cells + the zero slot, even (keeps the tables behind 16-B aligned)
     double *prev, *cur, *after;
     if (GLOBAL_SCRATCH) {
         prev = p.shell_scratch + (size_t)blk * 2 * slots;
@@ -264,7 +260,7 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
     double pend_pref = 0.0, pend_dtau = 0.0;
     bool pend_thick = false;
     Lookup pend_A, pend_B;
-    pend_A.t0 = pend_A.t1 = pend_A.residual = 0.0; pend_B = pend_A;
+    pend_A.t.x = pend_A.t.y = pend_A.residual = 0.0; pend_B = pend_A;
     double *pend_dst = p.phi;
 
     auto step = [&](unsigned e_pf, const uint4 &cur_A, const uint4 &cur_B, const double cur_nhi, const unsigned cur_idx,
@@ -354,7 +350,7 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
             pend_dtau = tau_out - tau_in;
             pend_thick = fabs(pend_dtau) > limit;
             const double tau_thin = p.fortran_consts ? tau_in : tau_out;                 // photorates.f90:121 / rates.cu:37
-            const double *tab = p.tables + (pend_thick ? 0 : p.table_len);
+            const double2 *tab = p.tables + (pend_thick ? 0 : p.table_len);
             pend_A = lookup_issue(tab, pend_thick ? tau_in : tau_thin, p, logtab);
             pend_B = lookup_issue(tab, pend_thick ? tau_out : tau_thin, p, logtab);
             pend_dst = dst;
@@ -783,8 +779,10 @@ int launch_raytrace(State &st, RtParams &p, bool dump)
     p.lut_k1 = 0.30102999566398119521 / p.dlogtau;      // log10(2)/dlogtau
     p.lut_k0 = 1.0 - p.minlogtau / p.dlogtau;
 
-    const size_t slots = (size_t)p.max_cells + 1;
-    const size_t fixed_bytes = LOG_TABLE_SIZE * sizeof(double2) + 3 * (size_t)(p.S + 1) * sizeof(int);
+    const size_t slots = ((size_t)p.max_cells + 2) & ~(size_t)1;   // max_cells + zero slot, rounded to even (16-B alignment)
+    // log table, 1/s table, three wrapped-coordinate tables (see the kernel's LDS layout)
+    const size_t fixed_bytes = LOG_TABLE_SIZE * sizeof(double2) + (size_t)(p.S + 1) * sizeof(double) +
+                               3 * (size_t)(p.S + 1) * sizeof(int);
     const size_t shell_bytes = 2 * slots * sizeof(double);
     const bool use_lds = shell_bytes + fixed_bytes <= LDS_LIMIT_BYTES;
     const size_t lds_bytes = (use_lds ? shell_bytes : 0) + fixed_bytes;

@@ -201,8 +201,11 @@ def test_large_radius_and_window_clipping(asora, N, R):
     np.testing.assert_allclose(phi, ref, rtol=GAMMA_RTOL, atol=0)
 
 
-def test_shells_beyond_lds_use_global_scratch(asora):
-    """N=168 full box: shell buffers 6*85^2*8 B = 347 KB > 160 KB LDS -> global-scratch variant."""
+@pytest.mark.parametrize("mode", [1, 2])
+def test_large_shells_global_scratch_and_large_lds(asora, mode):
+    """N=168 full box.  One workgroup per octant (mode 1): shell buffers 2*21.8k*8 B = 349 KB > 160 KB of LDS
+    -> the global-scratch variant.  One per (octant, sector) (mode 2, what the library picks at this size):
+    117 KB of dynamic LDS per workgroup."""
     p, lib, capi = asora
     N = 168
     nd, xh, dr = cases.grid(N, "lognormal", 41, 0.02)
@@ -211,7 +214,11 @@ def test_shells_beyond_lds_use_global_scratch(asora):
     c = dict(N=N, ndens=nd, xh=xh, dr=dr, pos=pos, flux=flux, R=1000.0, thin=thin, thick=thick, dlogtau=dlog,
              minlogtau=cases.MINLOGTAU, sig=cases.SIG)
     pos0, fl = _setup(p, lib, c, N)
-    phi = _asora_call(lib, c, N, thin.shape[0] - 1)
+    lib.set_option(capi.OPT_SECTORS, mode)
+    try:
+        phi = _asora_call(lib, c, N, thin.shape[0] - 1)
+    finally:
+        lib.set_option(capi.OPT_SECTORS, 0)
     ref = O.asora_do_all_sources(1000.0, cases.SIG, dr, nd, xh, pos0, fl, thin, thick, cases.MINLOGTAU, dlog,
                                  NumTau=thin.shape[0] - 1, flags=O.ASORA_MODE)["phi_ion"]
     np.testing.assert_allclose(phi, ref, rtol=GAMMA_RTOL, atol=0)
