@@ -18,20 +18,49 @@ State &state() { return g_state; }
 int fail(int code, const std::string &msg) { g_error = msg; return code; }
 void clear_error() { g_error.clear(); }
 
-KernelTimer::KernelTimer(int w) : which(w), on(g_state.opt[ASORA_OPT_TIMING] != 0 && g_state.ev0 != nullptr)
+// Kernel timing with HIP events on the library's stream.  Events are recorded without any host
+// synchronisation (so that enabling the timers does not perturb what is being timed) and resolved
+// when the totals are queried, or when the pool of pending pairs is full.
+static int flush_timers()
 {
-    if (on) (void)hipEventRecord(g_state.ev0, g_state.stream);
+    State &st = g_state;
+    if (st.pending_timers.empty()) return 0;
+    ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    for (auto &pt : st.pending_timers) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pt.e0, pt.e1) == hipSuccess) {
+            st.k_ms[pt.which] += (double)ms;
+            st.k_n[pt.which] += 1;
+        }
+        st.free_events.push_back(pt.e0);
+        st.free_events.push_back(pt.e1);
+    }
+    st.pending_timers.clear();
+    return 0;
+}
+
+static hipEvent_t take_event()
+{
+    State &st = g_state;
+    if (!st.free_events.empty()) { hipEvent_t e = st.free_events.back(); st.free_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+KernelTimer::KernelTimer(int w) : which(w), on(g_state.opt[ASORA_OPT_TIMING] != 0 && g_state.stream != nullptr)
+{
+    if (!on) return;
+    if (g_state.pending_timers.size() >= 4096) (void)flush_timers();
+    e0 = take_event();
+    e1 = take_event();
+    (void)hipEventRecord(e0, g_state.stream);
 }
 KernelTimer::~KernelTimer()
 {
     if (!on) return;
-    (void)hipEventRecord(g_state.ev1, g_state.stream);
-    (void)hipEventSynchronize(g_state.ev1);
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, g_state.ev0, g_state.ev1) == hipSuccess) {
-        g_state.k_ms[which] += (double)ms;
-        g_state.k_n[which] += 1;
-    }
+    (void)hipEventRecord(e1, g_state.stream);
+    g_state.pending_timers.push_back({which, e0, e1});
 }
 
 // stream, events and the chemistry reduction buffers: needed with or without device_init
@@ -44,8 +73,6 @@ static int ensure_runtime()
     ASORA_HIP_TRY(hipGetDeviceProperties(&prop, st.device));
     st.cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ASORA_HIP_TRY(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
-    ASORA_HIP_TRY(hipEventCreate(&st.ev0));
-    ASORA_HIP_TRY(hipEventCreate(&st.ev1));
     st.red_blocks = chemistry_reduction_blocks(st);
     ASORA_HIP_TRY(hipMalloc(&st.red_partial, sizeof(double) * 3 * st.red_blocks));
     ASORA_HIP_TRY(hipMalloc(&st.red_final, sizeof(double) * 3));
@@ -406,6 +433,7 @@ int asora_kernel_time_ms(int kernel, double *total_ms, long *launches)
 {
     clear_error();
     if (kernel < 0 || kernel >= ASORA_KERNEL_COUNT) return fail(3, "kernel_time_ms: unknown kernel");
+    if (int rc = flush_timers()) return rc;
     if (total_ms) *total_ms = g_state.k_ms[kernel];
     if (launches) *launches = g_state.k_n[kernel];
     return 0;
@@ -413,6 +441,7 @@ int asora_kernel_time_ms(int kernel, double *total_ms, long *launches)
 
 int asora_kernel_time_reset(void)
 {
+    (void)flush_timers();
     for (int k = 0; k < ASORA_KERNEL_COUNT; ++k) { g_state.k_ms[k] = 0.0; g_state.k_n[k] = 0; }
     return 0;
 }

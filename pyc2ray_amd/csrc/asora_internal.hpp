@@ -69,7 +69,9 @@ struct State {
     long long last_gamma_cells = 0, last_eval_cells = 0;
 
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    struct PendingTimer { int which; hipEvent_t e0, e1; };
+    std::vector<PendingTimer> pending_timers;     // recorded, not yet resolved
+    std::vector<hipEvent_t> free_events;
     int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0};
     double k_ms[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
     long k_n[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
@@ -91,6 +93,7 @@ void clear_error();
 struct KernelTimer {
     int which;
     bool on;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     explicit KernelTimer(int w);
     ~KernelTimer();
 };

@@ -16,61 +16,80 @@ namespace asora {
 
 constexpr int CH_THREADS = 256;
 
-__global__ void __launch_bounds__(CH_THREADS) chemistry_kernel(const ChemParams p)
+// One cell: do_chemistry + the convergence test of evolve0D_global.
+__device__ __forceinline__ void chemistry_cell(const ChemParams &p, double n, double T, double x0, double gamma,
+                                               double &xav, double &xint, unsigned int &nconv)
 {
     // single-precision parameters promoted to double, chemistry.f90:9-10
     const double min_frac_change = (double)1.0e-3f;
     const double min_frac_atoms = (double)1.0e-8f;
     const double eps = 1e-14;                                        // chemistry.f90:8
 
+    const double xav_start = xav;                                    // chemistry.f90:91,99
+    const double yh_av = 1.0 - xav;                                  // chemistry.f90:93
+
+    // doric's temperature-only factors, chemistry.f90:257-262 (isothermal: same every iteration)
+    const double brech0 = 1.0 * p.bh00 * pow(T / 1e4, p.albpow);
+    const double acolh0 = p.colh0 * sqrt(T) * exp(-p.temph0 / T);
+    // temperature convergence term of do_chemistry, chemistry.f90:185-186 (0 unless T is 0/NaN)
+    const bool t_ok = fabs((T - T) / T) < min_frac_change;
+
+    int nit = 0;
+    for (;;) {                                                       // do_chemistry, chemistry.f90:146-203
+        nit += 1;
+        const double xav_old = xav;
+        const double de = n * (xav + p.abu_c);                       // chemistry.f90:162
+        // doric, chemistry.f90:279-311
+        const double aih0 = gamma + de * acolh0;
+        const double delth = aih0 + de * brech0;
+        const double eqxh = aih0 / delth;
+        const double deltht = delth * p.dt;
+        const double ee = exp(-deltht);
+        xint = (x0 - eqxh) * ee + eqxh;
+        if (xint < eps) xint = eps;
+        const double avg = (deltht < (double)1.0e-8f) ? 1.0 : (1.0 - ee) / deltht;
+        xav = eqxh + (x0 - eqxh) * avg;
+        if (xav < eps) xav = eps;
+        if ((fabs((xav - xav_old) / (1.0 - xav)) < min_frac_change || (1.0 - xav < min_frac_atoms)) && t_ok)
+            break;                                                   // chemistry.f90:182-189
+        if (nit > 400) break;                                        // chemistry.f90:192
+    }
+    if (fabs(xav - xav_start) > min_frac_change && fabs((xav - xav_start) / yh_av) > min_frac_change &&
+        yh_av > min_frac_atoms)
+        nconv += 1;                                                  // chemistry.f90:100-104
+}
+
+// Two consecutive cells per lane: 16-byte loads and stores (the grids are 256-byte aligned).
+__global__ void __launch_bounds__(CH_THREADS) chemistry_kernel(const ChemParams p)
+{
     double sum1 = 0.0, sum0 = 0.0;
     unsigned int nconv = 0;
 
+    const size_t npair = p.ncell / 2;
     const size_t stride = (size_t)gridDim.x * CH_THREADS;
-    for (size_t idx = (size_t)blockIdx.x * CH_THREADS + threadIdx.x; idx < p.ncell; idx += stride) {
-        const double n = p.ndens[idx];
-        const double T = p.temp[idx];
-        const double x0 = p.xh[idx];
-        const double gamma = p.phi[idx];
-        double xav = p.xh_av[idx];
-        const double xav_start = xav;                                // chemistry.f90:91,99
-        const double yh_av = 1.0 - xav;                              // chemistry.f90:93
-
-        // doric's temperature-only factors, chemistry.f90:257-262 (isothermal: same every iteration)
-        const double brech0 = 1.0 * p.bh00 * pow(T / 1e4, p.albpow);
-        const double acolh0 = p.colh0 * sqrt(T) * exp(-p.temph0 / T);
-        // temperature convergence term of do_chemistry, chemistry.f90:185-186 (0 unless T is 0/NaN)
-        const bool t_ok = fabs((T - T) / T) < min_frac_change;
-
-        double xint = 0.0;
-        int nit = 0;
-        for (;;) {                                                   // do_chemistry, chemistry.f90:146-203
-            nit += 1;
-            const double xav_old = xav;
-            const double de = n * (xav + p.abu_c);                   // chemistry.f90:162
-            // doric, chemistry.f90:279-311
-            const double aih0 = gamma + de * acolh0;
-            const double delth = aih0 + de * brech0;
-            const double eqxh = aih0 / delth;
-            const double deltht = delth * p.dt;
-            const double ee = exp(-deltht);
-            xint = (x0 - eqxh) * ee + eqxh;
-            if (xint < eps) xint = eps;
-            const double avg = (deltht < (double)1.0e-8f) ? 1.0 : (1.0 - ee) / deltht;
-            xav = eqxh + (x0 - eqxh) * avg;
-            if (xav < eps) xav = eps;
-            if ((fabs((xav - xav_old) / (1.0 - xav)) < min_frac_change || (1.0 - xav < min_frac_atoms)) && t_ok)
-                break;                                               // chemistry.f90:182-189
-            if (nit > 400) break;                                    // chemistry.f90:192
-        }
-
-        if (fabs(xav - xav_start) > min_frac_change && fabs((xav - xav_start) / yh_av) > min_frac_change &&
-            yh_av > min_frac_atoms)
-            nconv += 1;                                              // chemistry.f90:100-104
-        p.xh_intermed[idx] = xint;                                   // chemistry.f90:107-108
+    const double2 *nd2 = reinterpret_cast<const double2 *>(p.ndens);
+    const double2 *tp2 = reinterpret_cast<const double2 *>(p.temp);
+    const double2 *x02 = reinterpret_cast<const double2 *>(p.xh);
+    const double2 *ph2 = reinterpret_cast<const double2 *>(p.phi);
+    double2 *xa2 = reinterpret_cast<double2 *>(p.xh_av);
+    double2 *xi2 = reinterpret_cast<double2 *>(p.xh_intermed);
+    for (size_t q = (size_t)blockIdx.x * CH_THREADS + threadIdx.x; q < npair; q += stride) {
+        const double2 n = nd2[q], T = tp2[q], x0 = x02[q], g = ph2[q];
+        double2 xav = xa2[q], xint;
+        chemistry_cell(p, n.x, T.x, x0.x, g.x, xav.x, xint.x, nconv);
+        chemistry_cell(p, n.y, T.y, x0.y, g.y, xav.y, xint.y, nconv);
+        xi2[q] = xint;                                               // chemistry.f90:107-108
+        xa2[q] = xav;
+        sum1 += xint.x; sum0 += 1.0 - xint.x;                        // evolve.py:216-217
+        sum1 += xint.y; sum0 += 1.0 - xint.y;
+    }
+    if ((p.ncell & 1) && blockIdx.x == 0 && threadIdx.x == 0) {      // odd cell count: the last cell
+        const size_t idx = p.ncell - 1;
+        double xav = p.xh_av[idx], xint;
+        chemistry_cell(p, p.ndens[idx], p.temp[idx], p.xh[idx], p.phi[idx], xav, xint, nconv);
+        p.xh_intermed[idx] = xint;
         p.xh_av[idx] = xav;
-        sum1 += xint;                                                // evolve.py:216
-        sum0 += 1.0 - xint;                                          // evolve.py:217
+        sum1 += xint; sum0 += 1.0 - xint;
     }
 
     // block reduction in a fixed order
@@ -114,7 +133,7 @@ int chemistry_reduction_blocks(const State &st) { return st.cu_count * 8; }
 
 int launch_chemistry(State &st, ChemParams &p, hipStream_t stream)
 {
-    const size_t want = (p.ncell + CH_THREADS - 1) / CH_THREADS;
+    const size_t want = std::max<size_t>(1, (p.ncell / 2 + CH_THREADS - 1) / CH_THREADS);
     const int blocks = (int)std::min<size_t>(want, (size_t)p.red_blocks);
     ChemParams q = p;
     q.red_blocks = blocks;
