@@ -164,7 +164,7 @@ def main():
     from pyc2ray_amd.utils.sourceutils import format_sources
 
     comm = None
-    if world > 1:
+    if world > 1 or os.environ.get("PYC2RAY_AMD_FORCE_COLLECTIVE", "0") == "1":
         import torch
         import torch.distributed as dist
         from pyc2ray_amd.dist import TorchComm, init_process_group_from_env

@@ -127,8 +127,8 @@ class TorchComm:
     def allreduce_device_grid(self, libasora, which, N):
         """In-place sum over ranks of the device-resident grid `which` (N^3 float64)."""
         import torch
-        if self.Get_size() == 1:
-            return
+        if self.Get_size() == 1 and os.environ.get("PYC2RAY_AMD_FORCE_COLLECTIVE", "0") != "1":
+            return          # nothing to sum (the env switch lets a 1-GPU box exercise the collective path)
         if self._backend() == "nccl":
             libasora.synchronize()                     # the library works on its own stream
             view = torch.as_tensor(_DevicePointer(libasora.device_ptr(which), N ** 3), device="cuda")

@@ -413,3 +413,84 @@ def test_rccl_allreduce_on_library_grid_world1(asora):
     np.testing.assert_array_equal(back, 2.0 * phi)
     comm.allreduce_device_grid(lib, capi.GRID_PHI_ION, N)                    # world 1: no-op path
     p.device_close()
+
+
+# ---- edge cases -----------------------------------------------------------------------------------------
+def _edge_case(p, lib, capi, N, pos, flux, R, tau_cell=0.1, seed=71, tables="soft", xh_override=None):
+    nd, xh, dr = cases.grid(N, "lognormal", seed, tau_cell)
+    if xh_override is not None:
+        xh = xh_override(xh)
+    thin, thick, dlog = cases.soft_tables() if tables == "soft" else cases.grey_tables()
+    c = dict(N=N, ndens=nd, xh=xh, dr=dr, pos=np.asarray(pos), flux=np.asarray(flux, dtype=float), R=R, thin=thin,
+             thick=thick, dlogtau=dlog, minlogtau=cases.MINLOGTAU, sig=cases.SIG)
+    pos0, fl = _setup(p, lib, c, N)
+    phi = _asora_call(lib, c, N, thin.shape[0] - 1)
+    ref = O.asora_do_all_sources(R, cases.SIG, dr, nd, xh, pos0, fl, thin, thick, cases.MINLOGTAU, dlog,
+                                 NumTau=thin.shape[0] - 1, flags=O.ASORA_MODE)
+    return phi, ref["phi_ion"]
+
+
+@pytest.mark.parametrize("R", [0.0, 0.5, 1.0, 1.5, 2.0 ** 0.5, 3.0 ** 0.5, 2.0])
+def test_tiny_radii(asora, R):
+    """R = 0: only the source cell is rated; R = 1, sqrt2, sqrt3: the 6 / 18 / 26 nearest cells join
+    (cells exactly on the sphere are classified as the reference's floating-point test does)."""
+    p, lib, capi = asora
+    phi, ref = _edge_case(p, lib, capi, 12, [[4], [7], [9]], [2.0], R)
+    assert (phi != 0).sum() == (ref != 0).sum()
+    np.testing.assert_allclose(phi, ref, rtol=GAMMA_RTOL, atol=0)
+
+
+def test_sources_on_the_box_corners_wrap_periodically(asora):
+    p, lib, capi = asora
+    N = 20
+    pos = np.array([[1, N, 1, N], [1, N, N, 1], [1, N, 1, 1]])
+    phi, ref = _edge_case(p, lib, capi, N, pos, [1.0, 2.0, 3.0, 4.0], 7.3)
+    np.testing.assert_allclose(phi, ref, rtol=GAMMA_RTOL, atol=0)
+
+
+def test_coincident_sources_add_up(asora):
+    """Several sources in the same cell: every rate atomic of theirs collides."""
+    p, lib, capi = asora
+    pos = np.array([[6] * 9, [6] * 9, [6] * 9])
+    phi9, ref9 = _edge_case(p, lib, capi, 16, pos, [1.5] * 9, 6.0)
+    phi1, _ = _edge_case(p, lib, capi, 16, pos[:, :1], [1.5], 6.0)
+    np.testing.assert_allclose(phi9, ref9, rtol=GAMMA_RTOL, atol=0)
+    np.testing.assert_allclose(phi9, 9.0 * phi1, rtol=1e-12, atol=0)
+
+
+def test_no_sources_gives_zero_rates(asora):
+    p, lib, capi = asora
+    N = 12
+    nd, xh, dr = cases.grid(N, "uniform", 0, 0.1)
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 8)
+    thin, thick, dlog = cases.grey_tables()
+    p.photo_table_to_device(thin, thick)
+    lib.source_data_to_device(np.zeros(0, dtype=np.int32), np.zeros(0), 0)
+    lib.grid_to_device(capi.GRID_NDENS, nd)
+    lib.grid_to_device(capi.GRID_XH_AV, xh)
+    lib.raytrace_device(5.0, cases.SIG, dr, 0, 0, cases.MINLOGTAU, dlog, thin.shape[0] - 1)
+    phi = lib.grid_to_host(capi.GRID_PHI_ION, np.full((N, N, N), 7.0))
+    assert not phi.any()
+    with pytest.raises(RuntimeError, match="outside the 0 uploaded sources"):
+        lib.raytrace_device(5.0, cases.SIG, dr, 0, 1, cases.MINLOGTAU, dlog, thin.shape[0] - 1)
+
+
+def test_column_density_cap_stops_the_rates(asora):
+    """Beyond N_HI = 2e30 cm^-2 the reference adds no rate (raytracing.cu:15,315); the column density keeps
+    growing.  A huge cell size pushes most of the box over the cap."""
+    p, lib, capi = asora
+    phi, ref = _edge_case(p, lib, capi, 16, [[8], [8], [8]], [1.0], 1000.0, tau_cell=3e12, tables="grey")
+    assert 0 < (ref != 0).sum() < ref.size // 2
+    assert np.array_equal(phi != 0, ref != 0)
+    w = ref != 0
+    np.testing.assert_allclose(phi[w], ref[w], rtol=GAMMA_RTOL, atol=0)
+
+
+def test_nearly_ionised_medium_thin_cells(asora):
+    """x -> 1: optical depths per cell far below 1e-7, every cell takes the optically thin branch."""
+    p, lib, capi = asora
+    phi, ref = _edge_case(p, lib, capi, 16, [[3, 12], [5, 9], [14, 2]], [1.0, 4.0], 9.0, tau_cell=1e-3,
+                          xh_override=lambda x: 1.0 - 1e-7 * (1.0 + x))
+    np.testing.assert_allclose(phi, ref, rtol=GAMMA_RTOL, atol=0)
