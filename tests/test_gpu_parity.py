@@ -494,3 +494,48 @@ def test_nearly_ionised_medium_thin_cells(asora):
     phi, ref = _edge_case(p, lib, capi, 16, [[3, 12], [5, 9], [14, 2]], [1.0, 4.0], 9.0, tau_cell=1e-3,
                           xh_override=lambda x: 1.0 - 1e-7 * (1.0 + x))
     np.testing.assert_allclose(phi, ref, rtol=GAMMA_RTOL, atol=0)
+
+
+# ---- physics known-answer: the reference's Test 1 (Stroemgren sphere) ----------------------------------------
+def test_stroemgren_sphere_expansion(asora, tmp_path):
+    """BASELINE configs[1] / the reference's paper test 1 (test/paper_tests/test1_Ifront): one source of
+    1e54 photons/s in a uniform medium n_H = 1.87e-4 cm^-3, T = 1e4 K, grey opacity, box 5e24 cm, 128^3 cells,
+    ten steps of 50 Myr.  The ionisation-front radius (x = 0.5 along the +i axis, as make_plot.ipynb cell 7 finds
+    it) must follow the analytic r_I(t) = r_S (1 - exp(-t/t_rec))^(1/3), r_S = 964.377 kpc, t_rec = 654.266 Myr
+    (make_plot.ipynb cell 5).  The reference's own figure shows r_N/r_A within [0.985, 1.005] at 256^3."""
+    p, lib, capi = asora
+    N = 128
+    kpc, myr = 3.086e21, 3.15576e13
+    boxsize = 5e24
+    dr = boxsize / N
+    ndens = np.full((N, N, N), 1.87e-7 * (1 + 9.0) ** 3, order="F")
+    xh = np.full((N, N, N), 1.2e-3, order="F")
+    temp = np.full((N, N, N), 1e4, order="F")
+    src_pos = np.array([[64], [64], [64]])
+    src_flux = np.array([1e54 / 1e48])
+    thin, thick, dlog = cases.grey_tables(20000)
+    colh0 = 1.3e-8 * 0.83 * 1.0 / 13.598 ** 2
+    temph0 = 13.598 / 8.617e-05
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 1)
+    p.photo_table_to_device(thin, thick)
+    R_max_LLS = 15.0 * N / 1.62022035
+    r_S = ((3 * 1e54) / (4 * np.pi * 2.59e-13 * 1.87e-4 ** 2)) ** (1. / 3) / kpc
+    t_rec = 1.0 / (2.59e-13 * 1.87e-4 * myr)
+    assert abs(r_S - 964.377) < 1e-3 and abs(t_rec - 654.266) < 1e-3
+    x_axis = (np.arange(N - 63) * dr) / kpc                       # distance from the source cell along +i
+    ratios = []
+    for step in range(1, 11):
+        xh, phi = p.evolve3D(50 * myr, dr, src_flux, src_pos, True, 1000, 128, 1e-2, temp, ndens, xh, thin, thick,
+                             cases.MINLOGTAU, dlog, R_max_LLS, 1e-4, cases.SIG, 2.59e-13, -0.7, colh0, temph0, 7.1e-7,
+                             logfile=str(tmp_path / "log"), quiet=True)
+        prof = xh[63:, 63, 63]
+        front = np.interp(0.5, np.flip(prof), np.flip(x_axis))
+        r_A = r_S * (1.0 - np.exp(-50.0 * step / t_rec)) ** (1. / 3)
+        ratios.append(front / r_A)
+    ratios = np.array(ratios)
+    print("r_N/r_A per 50 Myr step:", np.round(ratios, 4))
+    assert np.all(ratios[1:] > 0.975) and np.all(ratios[1:] < 1.01), ratios
+    assert 0.3 < xh.mean() < 0.5                                  # ~ (4/3 pi r_I^3)/box: 0.41 at 500 Myr
+    p.device_close()
