@@ -51,6 +51,11 @@ int asora_density_to_device(const double *ndens, int N);
  * NumTau = number of elements of each table. */
 int asora_photo_table_to_device(const double *thin_table, const double *thick_table, int NumTau);
 
+/* Heating tables (no counterpart in the reference's GPU library, which lists GPU heating as TODO,
+ * pyc2ray/c2ray_base.py:424-426; the Fortran CPU path has them: src/c2ray/photorates.f90:118,124).
+ * Same length and tau grid as the photo tables, which must have been uploaded first. */
+int asora_heat_table_to_device(const double *heat_thin_table, const double *heat_thick_table, int NumTau);
+
 /* libasora.source_data_to_device(pos, flux, NumSrc)     python_module.cu:133-148 -> memory.cu:99-114 */
 int asora_source_data_to_device(const int32_t *pos, const double *flux, int NumSrc);
 
@@ -88,7 +93,8 @@ enum {
     ASORA_GRID_TEMP = 3,        /* temperature                                          */
     ASORA_GRID_XH = 4,          /* ionised fraction at start of the step                */
     ASORA_GRID_XH_INTERMED = 5, /* end-of-step ionised fraction                         */
-    ASORA_GRID_COUNT = 6
+    ASORA_GRID_PHI_HEAT = 6,    /* photo-heating rate (only filled when heating is on)  */
+    ASORA_GRID_COUNT = 7
 };
 
 /* Upload / download one N^3 grid.  order = 'C': buffer is logical [i][j][k] C-contiguous;
@@ -136,7 +142,10 @@ enum {
     /* Decomposition of a source: 0 (default) = chosen from R; 1 = one workgroup per octant;
      * 2 = one per octant and dominant-axis sector (24 per source, diagonal planes re-derived). */
     ASORA_OPT_SECTORS = 5,
-    ASORA_OPT_COUNT = 6
+    /* 1: the raytrace also accumulates the photo-heating rate into ASORA_GRID_PHI_HEAT
+     *    (src/c2ray/photorates.f90:118,124; src/c2ray/raytracing.f90:532,537); needs heat tables. */
+    ASORA_OPT_HEATING = 6,
+    ASORA_OPT_COUNT = 7
 };
 int asora_set_option(int option, int value);
 int asora_get_option(int option);

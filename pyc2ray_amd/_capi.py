@@ -10,8 +10,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libasora_hip.so")
 
 # grid selectors / options / kernels, as in include/asora_hip.h
-GRID_NDENS, GRID_XH_AV, GRID_PHI_ION, GRID_TEMP, GRID_XH, GRID_XH_INTERMED = range(6)
-OPT_FORTRAN_CONSTANTS, OPT_GREY_NOTABLES, OPT_TIMING, OPT_Z_TRANSPOSED, OPT_BLOCK_THREADS, OPT_SECTORS = range(6)
+GRID_NDENS, GRID_XH_AV, GRID_PHI_ION, GRID_TEMP, GRID_XH, GRID_XH_INTERMED, GRID_PHI_HEAT = range(7)
+(OPT_FORTRAN_CONSTANTS, OPT_GREY_NOTABLES, OPT_TIMING, OPT_Z_TRANSPOSED, OPT_BLOCK_THREADS, OPT_SECTORS,
+ OPT_HEATING) = range(7)
 KERNEL_RAYTRACE, KERNEL_CHEMISTRY, KERNEL_PREP, KERNEL_FINISH = range(4)
 
 _dp = C.POINTER(C.c_double)
@@ -24,6 +25,7 @@ SIGNATURES = {
     "asora_device_close": (C.c_int, []),
     "asora_density_to_device": (C.c_int, [_dp, C.c_int]),
     "asora_photo_table_to_device": (C.c_int, [_dp, _dp, C.c_int]),
+    "asora_heat_table_to_device": (C.c_int, [_dp, _dp, C.c_int]),
     "asora_source_data_to_device": (C.c_int, [_ip, _dp, C.c_int]),
     "asora_do_all_sources": (C.c_int, [C.c_double, _dp, C.c_double, C.c_double, _dp, _dp, _dp, C.c_int, C.c_int,
                                        C.c_double, C.c_double, C.c_int]),

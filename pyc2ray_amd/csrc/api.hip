@@ -87,7 +87,8 @@ static int release_all()
     State &st = g_state;
     auto drop = [](auto *&ptr) { if (ptr) { (void)hipFree(ptr); ptr = nullptr; } };
     for (int g = 0; g < ASORA_GRID_COUNT; ++g) { drop(st.grid[g]); st.grid_valid[g] = false; }
-    drop(st.nhi); drop(st.nhi_t); drop(st.phi_t); drop(st.staging);
+    drop(st.nhi); drop(st.nhi_t); drop(st.phi_t); drop(st.heat_t); drop(st.staging);
+    st.have_heat_tables = false;
     drop(st.tables); st.table_len = 0;
     drop(st.src_pos); drop(st.src_flux); st.num_src = 0;
     drop(st.shell_scratch); st.shell_scratch_bytes = 0;
@@ -126,9 +127,16 @@ static int do_raytrace(double R, double sig, double dr, int src_begin, int src_c
     if (NumTau < 1 && !st.opt[ASORA_OPT_GREY_NOTABLES]) return fail(4, "raytrace: NumTau must be >= 1");
 
     const bool zt = st.opt[ASORA_OPT_Z_TRANSPOSED] != 0;
+    const bool heat = st.opt[ASORA_OPT_HEATING] != 0 && dump == nullptr;
+    if (heat && (!st.have_heat_tables || st.opt[ASORA_OPT_GREY_NOTABLES]))
+        return fail(4, "raytrace: heating requested but no heating tables on device (heat_table_to_device)");
     const size_t bytes = st.ncell * sizeof(double);
     ASORA_HIP_TRY(hipMemsetAsync(st.grid[ASORA_GRID_PHI_ION], 0, bytes, st.stream));      // raytracing.cu:113
     if (zt) ASORA_HIP_TRY(hipMemsetAsync(st.phi_t, 0, bytes, st.stream));
+    if (heat) {
+        ASORA_HIP_TRY(hipMemsetAsync(st.grid[ASORA_GRID_PHI_HEAT], 0, bytes, st.stream));
+        if (zt) ASORA_HIP_TRY(hipMemsetAsync(st.heat_t, 0, bytes, st.stream));
+    }
     ASORA_HIP_TRY(hipMemsetAsync(st.counters, 0, sizeof(unsigned long long) * 2, st.stream));
     if (int rc = launch_prepare_nhi(st, zt)) return rc;
 
@@ -148,14 +156,20 @@ static int do_raytrace(double R, double sig, double dr, int src_begin, int src_c
     p.phi = st.grid[ASORA_GRID_PHI_ION];
     p.phi_t_off = (long long)(((intptr_t)st.phi_t - (intptr_t)st.grid[ASORA_GRID_PHI_ION]) / (intptr_t)sizeof(double));
     p.tables = st.tables;
+    p.heat = st.grid[ASORA_GRID_PHI_HEAT];
+    p.heat_t_off = (long long)(((intptr_t)st.heat_t - (intptr_t)st.grid[ASORA_GRID_PHI_HEAT]) / (intptr_t)sizeof(double));
     p.src_pos = st.src_pos; p.src_flux = st.src_flux;
     p.dump = dump;
     p.counters = st.counters;
     { const char *ab = getenv("ASORA_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
-    if (int rc = launch_raytrace(st, p, dump != nullptr)) return rc;
-    if (zt)
+    if (int rc = launch_raytrace(st, p, dump != nullptr, heat)) return rc;
+    if (zt) {
         if (int rc = launch_finish_phi(st)) return rc;
+        if (heat)
+            if (int rc = launch_fold_transposed(st, st.heat_t, st.grid[ASORA_GRID_PHI_HEAT])) return rc;
+    }
     st.grid_valid[ASORA_GRID_PHI_ION] = true;
+    if (heat) st.grid_valid[ASORA_GRID_PHI_HEAT] = true;
     return 0;
 }
 
@@ -184,6 +198,7 @@ int asora_device_init_ex(int N, int num_src_par, int device_id)
     ASORA_HIP_TRY(hipMalloc(&st.nhi, bytes));
     ASORA_HIP_TRY(hipMalloc(&st.nhi_t, bytes));
     ASORA_HIP_TRY(hipMalloc(&st.phi_t, bytes));
+    ASORA_HIP_TRY(hipMalloc(&st.heat_t, bytes));
     ASORA_HIP_TRY(hipMalloc(&st.staging, bytes));
     st.init = true;
     return 0;
@@ -283,7 +298,7 @@ int asora_photo_table_to_device(const double *thin_table, const double *thick_ta
     if (st.tables) { (void)hipFree(st.tables); st.tables = nullptr; }
     // device layout: pairs {T[i], T[i+1]-T[i]} so that one 16-byte load serves the linear interpolation
     // of photo_lookuptable (rates.cu:82); the last pair is {T[last], 0}
-    std::vector<double2> pairs(2 * (size_t)NumTau);
+    std::vector<double2> pairs(4 * (size_t)NumTau, double2{0.0, 0.0});   // [thick | thin | heat thick | heat thin]
     for (int t = 0; t < 2; ++t) {
         const double *src = t == 0 ? thick_table : thin_table;
         for (int i = 0; i < NumTau; ++i) {
@@ -294,6 +309,30 @@ int asora_photo_table_to_device(const double *thin_table, const double *thick_ta
     ASORA_HIP_TRY(hipMalloc(&st.tables, pairs.size() * sizeof(double2)));
     ASORA_HIP_TRY(hipMemcpy(st.tables, pairs.data(), pairs.size() * sizeof(double2), hipMemcpyHostToDevice));
     st.table_len = NumTau;
+    st.have_heat_tables = false;
+    return 0;
+}
+
+int asora_heat_table_to_device(const double *heat_thin_table, const double *heat_thick_table, int NumTau)
+{
+    clear_error();
+    if (int rc = require_init("heat_table_to_device")) return rc;
+    State &st = g_state;
+    if (!st.tables) return fail(4, "heat_table_to_device: upload the photo tables first (photo_table_to_device)");
+    if (NumTau != st.table_len || !heat_thin_table || !heat_thick_table)
+        return fail(3, "heat_table_to_device: the heating tables must have the length of the photo tables (" +
+                           std::to_string(st.table_len) + ")");
+    std::vector<double2> pairs(2 * (size_t)NumTau);
+    for (int t = 0; t < 2; ++t) {
+        const double *src = t == 0 ? heat_thick_table : heat_thin_table;
+        for (int i = 0; i < NumTau; ++i) {
+            pairs[(size_t)t * NumTau + i].x = src[i];
+            pairs[(size_t)t * NumTau + i].y = (i + 1 < NumTau) ? src[i + 1] - src[i] : 0.0;
+        }
+    }
+    ASORA_HIP_TRY(hipMemcpy(st.tables + 2 * (size_t)NumTau, pairs.data(), pairs.size() * sizeof(double2),
+                            hipMemcpyHostToDevice));
+    st.have_heat_tables = true;
     return 0;
 }
 

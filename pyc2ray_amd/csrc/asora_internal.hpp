@@ -30,16 +30,18 @@ struct State {
     int num_src_par = 0;           // accepted, unused (no per-source N^3 scratch in this build)
     int cu_count = 256;
 
-    double *grid[ASORA_GRID_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool grid_valid[ASORA_GRID_COUNT] = {false, false, false, false, false, false};
+    double *grid[ASORA_GRID_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool grid_valid[ASORA_GRID_COUNT] = {false, false, false, false, false, false, false};
 
     // derived per raytrace call
     double *nhi = nullptr;     // ndens*(1-xh_av), [i][j][k]
     double *nhi_t = nullptr;   // same, transposed [k][j][i]
     double *phi_t = nullptr;   // rate accumulator for z-faces, transposed [k][j][i]
+    double *heat_t = nullptr;  // heating-rate accumulator for z-faces, transposed
+    bool have_heat_tables = false;
     double *staging = nullptr; // N^3 staging grid for 'F'-order transfers / debug dumps
 
-    double2 *tables = nullptr;     // [thick | thin] as pairs {T[i], T[i+1]-T[i]}, each table_len long
+    double2 *tables = nullptr;     // [thick | thin | heat thick | heat thin] as pairs {T[i], T[i+1]-T[i]}, each table_len long
     int table_len = 0;
 
     int32_t *src_pos = nullptr;
@@ -72,7 +74,7 @@ struct State {
     struct PendingTimer { int which; hipEvent_t e0, e1; };
     std::vector<PendingTimer> pending_timers;     // recorded, not yet resolved
     std::vector<hipEvent_t> free_events;
-    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0};
+    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0};
     double k_ms[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
     long k_n[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
 };
@@ -120,7 +122,9 @@ struct RtParams {
     long long nhi_t_off;
     double *phi;                // Gamma accumulator [i][j][k]; the transposed one phi_t_off elements further
     long long phi_t_off;
-    const double2 *tables;      // pairs {T[i], T[i+1]-T[i]}: thick table at [0, table_len), thin at [table_len, 2*table_len)
+    const double2 *tables;      // pairs {T[i], T[i+1]-T[i]}: thick at [0, len), thin at [len, 2 len), heat thick at [2 len, 3 len), heat thin at [3 len, 4 len)
+    double *heat;               // heating accumulator (HEAT kernels); transposed one heat_t_off elements further
+    long long heat_t_off;
     const int32_t *src_pos;
     const double *src_flux;
     double *dump;               // debug: outgoing column density (N^3) or nullptr
@@ -131,7 +135,8 @@ struct RtParams {
 void release_geometry(State &st);
 int launch_prepare_nhi(State &st, bool need_transposed);
 int launch_finish_phi(State &st);
-int launch_raytrace(State &st, RtParams &p, bool dump);
+int launch_raytrace(State &st, RtParams &p, bool dump, bool heat);
+int launch_fold_transposed(State &st, const double *src_t, double *dst);   // dst[i][j][k] += src_t[k][j][i]
 int launch_transpose(State &st, const double *src, double *dst, int N);   // dst[k][j][i] = src[i][j][k]
 
 // ---------------------------------------------------------------------------------------------

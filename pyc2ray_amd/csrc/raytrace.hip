@@ -76,7 +76,8 @@ __device__ __forceinline__ double log2_pos(double x, const double2 *__restrict__
 // k1 = log10(2)/dlogtau, k0 = 1 - minlogtau/dlogtau.  Indices are clamped to the last table
 // element (the reference reads one past the end when NumTau == len(table), tau >= 10^maxlogtau).
 // The device tables hold pairs {T[i], T[i+1] - T[i]} (last pair {T[last], 0}): one 16-byte load per lookup.
-struct Lookup { double2 t; double residual; };
+struct Lookup { double2 t; double2 h; double residual; };   // h: the heating-table pair at the same index
+template <bool HEAT = false>
 __device__ __forceinline__ Lookup lookup_issue(const double2 *__restrict__ table, double tau, const RtParams &p,
                                                const double2 *__restrict__ logtab)
 {
@@ -85,10 +86,13 @@ __device__ __forceinline__ Lookup lookup_issue(const double2 *__restrict__ table
     const int i0 = (int)real_i;
     Lookup L;
     L.residual = real_i - (double)i0;
-    L.t = table[min(i0, p.table_len - 1)];
+    const int i = min(i0, p.table_len - 1);
+    L.t = table[i];
+    if (HEAT) L.h = table[i + 2 * p.table_len]; else L.h = L.t;
     return L;
 }
 __device__ __forceinline__ double lookup_value(const Lookup &L) { return fma(L.residual, L.t.y, L.t.x); }
+__device__ __forceinline__ double lookup_heat(const Lookup &L) { return fma(L.residual, L.h.y, L.h.x); }
 
 // photoion_rates_gpu rates.cu:16-41 divided by nHI (raytracing.cu:324), also in two halves.
 // pref = flux/(vol*nHI) replaces the reference's two divisions by one.  A cell is "thick" when
@@ -135,6 +139,21 @@ __device__ __forceinline__ double grey_rate_per_atom(double flux, double cd_in, 
     return pref * (tau_out - tau_in) * exp(-tau_in);
 }
 
+// heating rate of one cell per atom (photorates.f90:118,124), used for the source cell only
+__device__ __forceinline__ double heat_rate_per_atom(double flux, double cd_in, double cd_out, double vol_nhi,
+                                                     const RtParams &p, const double2 *__restrict__ logtab)
+{
+    const double tau_in = cd_in * p.sig, tau_out = cd_out * p.sig;
+    const double limit = p.fortran_consts ? (double)1.0e-7f : 1.0e-7;
+    const double pref = flux / vol_nhi;
+    const bool thick = fabs(tau_out - tau_in) > limit;
+    const double tau_thin = p.fortran_consts ? tau_in : tau_out;
+    const double2 *tab = p.tables + (thick ? 0 : p.table_len);
+    const Lookup A = lookup_issue<true>(tab, thick ? tau_in : tau_thin, p, logtab);
+    const Lookup B = lookup_issue<true>(tab, thick ? tau_out : tau_thin, p, logtab);
+    return thick ? pref * (lookup_heat(A) - lookup_heat(B)) : pref * (tau_out - tau_in) * lookup_heat(A);
+}
+
 __device__ __forceinline__ double photo_rate_per_atom(double flux, double cd_in, double cd_out, double vol_nhi,
                                                       const RtParams &p, const double2 *__restrict__ logtab)
 {
@@ -160,7 +179,7 @@ __device__ __forceinline__ int wrap_once(int x, int N)
 // Slot max_cells of each shell buffer holds 0.0: upstream corners of weight 0 point there.
 constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_RATE = 1u << 29, CELL_SLOT_MASK = (1u << 29) - 1;
 
-template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP>
+template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP, bool HEAT>
 __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtParams p)
 {
     extern __shared__ double lds_raw[];
@@ -231,6 +250,7 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
             if (DUMP) p.dump[idx] = cd_out;
             const double phi = photo_rate_per_atom(flux, 0.0, cd_out, dr * dr * dr * nHI, p, logtab);
             unsafeAtomicAdd(&p.phi[idx], phi);
+            if (HEAT && !p.grey) unsafeAtomicAdd(&p.heat[idx], heat_rate_per_atom(flux, 0.0, cd_out, dr * dr * dr * nHI, p, logtab));
             ++n_gamma;
         }
     }
@@ -262,6 +282,7 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
     Lookup pend_A, pend_B;
     pend_A.t.x = pend_A.t.y = pend_A.residual = 0.0; pend_B = pend_A;
     double *pend_dst = p.phi;
+    int pend_zt = 0;               // the pending cell accumulates into the transposed grids
 
     auto step = [&](unsigned e_pf, const uint4 &cur_A, const uint4 &cur_B, const double cur_nhi, const unsigned cur_idx,
                     const uint4 &nxt_A, double &nxt_nhi, unsigned &nxt_idx, uint4 &pf_A, uint4 &pf_B) {
@@ -336,6 +357,11 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
             const double ta = lookup_value(pend_A), tb = lookup_value(pend_B);
             const double v = pend_thick ? pend_pref * ta - pend_pref * tb : pend_pref * pend_dtau * ta;
             if (!(p.ablate & 1)) unsafeAtomicAdd(pend_dst, v); else if (v == 1.2345e-300) pend_dst[0] = v;
+            if (HEAT) {      // photorates.f90:118,124 with the same table index and residual
+                const double ha = lookup_heat(pend_A), hb = lookup_heat(pend_B);
+                const double h = pend_thick ? pend_pref * (ha - hb) : pend_pref * pend_dtau * ha;
+                unsafeAtomicAdd(p.heat + (pend_dst - p.phi) + (p.heat_t_off - p.phi_t_off) * (long long)pend_zt, h);
+            }
         }
         if (grey) {
             if (rated) unsafeAtomicAdd(dst, grey_rate_per_atom(flux, cd_in, cd_out, vol_nhi, p));
@@ -351,9 +377,10 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
             pend_thick = fabs(pend_dtau) > limit;
             const double tau_thin = p.fortran_consts ? tau_in : tau_out;                 // photorates.f90:121 / rates.cu:37
             const double2 *tab = p.tables + (pend_thick ? 0 : p.table_len);
-            pend_A = lookup_issue(tab, pend_thick ? tau_in : tau_thin, p, logtab);
-            pend_B = lookup_issue(tab, pend_thick ? tau_out : tau_thin, p, logtab);
+            pend_A = lookup_issue<HEAT>(tab, pend_thick ? tau_in : tau_thin, p, logtab);
+            pend_B = lookup_issue<HEAT>(tab, pend_thick ? tau_out : tau_thin, p, logtab);
             pend_dst = dst;
+            pend_zt = (ztr && (cur_A.x >> 30) == 2) ? 1 : 0;
             pend = rated;
         }
     };
@@ -376,6 +403,11 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
         const double ta = lookup_value(pend_A), tb = lookup_value(pend_B);
         const double v = pend_thick ? pend_pref * ta - pend_pref * tb : pend_pref * pend_dtau * ta;
         if (!(p.ablate & 1)) unsafeAtomicAdd(pend_dst, v); else if (v == 1.2345e-300) pend_dst[0] = v;
+        if (HEAT) {
+            const double ha = lookup_heat(pend_A), hb = lookup_heat(pend_B);
+            const double h = pend_thick ? pend_pref * (ha - hb) : pend_pref * pend_dtau * ha;
+            unsafeAtomicAdd(p.heat + (pend_dst - p.phi) + (p.heat_t_off - p.phi_t_off) * (long long)pend_zt, h);
+        }
     }
 
     // work accounting: one atomic per wave
@@ -721,6 +753,14 @@ int launch_finish_phi(State &st)
     return 0;
 }
 
+int launch_fold_transposed(State &st, const double *src_t, double *dst)
+{
+    KernelTimer kt(ASORA_KERNEL_FINISH);
+    hipLaunchKernelGGL(transpose_ik_kernel<true>, tile_grid(st.N), dim3(32, 8), 0, st.stream, src_t, dst, st.N);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_transpose(State &st, const double *src, double *dst, int N)
 {
     hipLaunchKernelGGL(transpose_ik_kernel<false>, tile_grid(N), dim3(32, 8), 0, st.stream, src, dst, N);
@@ -756,22 +796,23 @@ static void pick_launch_shape(const State &st, double R, int N, bool dump, int &
 }
 
 template <int T>
-static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t lds_bytes, bool use_lds, bool dump)
+static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t lds_bytes, bool use_lds, bool dump, bool heat)
 {
-#define ASORA_LAUNCH(GS, DP)                                                                                   \
-    do {                                                                                                       \
-        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, GS, DP>,                     \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));        \
-        hipLaunchKernelGGL((raytrace_octant_kernel<T, GS, DP>), dim3(grid), dim3(T), lds_bytes, st.stream, q); \
+#define ASORA_LAUNCH(GS, DP, HT)                                                                                   \
+    do {                                                                                                           \
+        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, GS, DP, HT>,                     \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));            \
+        hipLaunchKernelGGL((raytrace_octant_kernel<T, GS, DP, HT>), dim3(grid), dim3(T), lds_bytes, st.stream, q); \
     } while (0)
-    if (T == 256 && dump) { if (use_lds) ASORA_LAUNCH(false, true); else ASORA_LAUNCH(true, true); }
-    else                  { if (use_lds) ASORA_LAUNCH(false, false); else ASORA_LAUNCH(true, false); }
+    if (T == 256 && dump) { if (use_lds) ASORA_LAUNCH(false, true, false); else ASORA_LAUNCH(true, true, false); }
+    else if (heat)        { if (use_lds) ASORA_LAUNCH(false, false, true); else ASORA_LAUNCH(true, false, true); }
+    else                  { if (use_lds) ASORA_LAUNCH(false, false, false); else ASORA_LAUNCH(true, false, false); }
 #undef ASORA_LAUNCH
     ASORA_HIP_TRY(hipGetLastError());
     return 0;
 }
 
-int launch_raytrace(State &st, RtParams &p, bool dump)
+int launch_raytrace(State &st, RtParams &p, bool dump, bool heat)
 {
     int units, threads;   // one workgroup per (source, octant) or per (source, octant, sector)
     pick_launch_shape(st, p.R, p.N, dump, units, threads);
@@ -815,10 +856,10 @@ int launch_raytrace(State &st, RtParams &p, bool dump)
             KernelTimer kt(ASORA_KERNEL_RAYTRACE);
             int rc = 0;
             switch (threads) {
-                case 64:  rc = launch_variant<64>(st, q, grid, lds_bytes, use_lds, dump); break;
-                case 128: rc = launch_variant<128>(st, q, grid, lds_bytes, use_lds, dump); break;
-                case 512: rc = launch_variant<512>(st, q, grid, lds_bytes, use_lds, dump); break;
-                default:  rc = launch_variant<256>(st, q, grid, lds_bytes, use_lds, dump); break;
+                case 64:  rc = launch_variant<64>(st, q, grid, lds_bytes, use_lds, dump, heat); break;
+                case 128: rc = launch_variant<128>(st, q, grid, lds_bytes, use_lds, dump, heat); break;
+                case 512: rc = launch_variant<512>(st, q, grid, lds_bytes, use_lds, dump, heat); break;
+                default:  rc = launch_variant<256>(st, q, grid, lds_bytes, use_lds, dump, heat); break;
             }
             if (rc) return rc;
         }

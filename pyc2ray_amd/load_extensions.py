@@ -64,6 +64,13 @@ class _LibAsora:
         _capi.check(self._lib.asora_photo_table_to_device(_capi.dptr(t0), _capi.dptr(t1), int(NumTau)),
                     "photo_table_to_device")
 
+    def heat_table_to_device(self, heat_thin_table, heat_thick_table, NumTau):
+        """Extension: photo-heating tables (the reference's GPU library has none)."""
+        t0 = np.ascontiguousarray(heat_thin_table, dtype=np.float64)
+        t1 = np.ascontiguousarray(heat_thick_table, dtype=np.float64)
+        _capi.check(self._lib.asora_heat_table_to_device(_capi.dptr(t0), _capi.dptr(t1), int(NumTau)),
+                    "heat_table_to_device")
+
     def source_data_to_device(self, pos, flux, NumSrc):
         p = np.ascontiguousarray(pos)
         if p.dtype != np.int32:

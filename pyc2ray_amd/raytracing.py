@@ -25,9 +25,10 @@ def do_raytracing(dr,
     """Raytrace all sources once and return the photo-ionisation rate grid.
 
     Same 17 positional arguments as the reference (pyc2ray/raytracing.py:34-43).  Returns
-    ``(phi_ion, phi_heat)``; on the GPU path the reference's return statement refers to an
-    undefined ``phi_heat`` (raytracing.py:108, NameError) -- here it is ``None`` (the reference lists
-    GPU heating as TODO, c2ray_base.py:424-426).  ``use_gpu=False`` selects the reference's Fortran
+    ``(phi_ion, phi_heat)``.  On the GPU path the reference's return statement refers to an
+    undefined ``phi_heat`` (raytracing.py:108, NameError; GPU heating is a TODO there,
+    c2ray_base.py:424-426); here the photo-heating rate is computed on the GPU when non-zero heating
+    tables are passed (arithmetic of the Fortran path, photorates.f90:118,124) and is ``None`` otherwise.  ``use_gpu=False`` selects the reference's Fortran
     CPU raytracer, which this build does not ship: RuntimeError.
     """
     if use_gpu and not cuda_is_init():
@@ -55,9 +56,21 @@ def do_raytracing(dr,
     libasora.grid_to_device(_capi.GRID_XH_AV, xh_av)
     printlog("Copied source data to device.", logfile, quiet)
 
+    # photo-heating: only when real heating tables are passed (the reference's callers pass zeros when
+    # compute_heating_rates is off, c2ray_base.py:430-431)
+    want_heat = (heat_thin_table is not None and heat_thick_table is not None
+                 and (np.any(heat_thin_table) or np.any(heat_thick_table)))
+    if want_heat:
+        libasora.heat_table_to_device(heat_thin_table, heat_thick_table, NumTau)
+    libasora.set_option(_capi.OPT_HEATING, 1 if want_heat else 0)
+
     trt0 = time.time()
     printlog("Doing Raytracing...", logfile, quiet, ' ')
-    libasora.raytrace_device(R_max_LLS, sig, dr, 0, NumSrc, minlogtau, dlogtau, NumTau)
+    try:
+        libasora.raytrace_device(R_max_LLS, sig, dr, 0, NumSrc, minlogtau, dlogtau, NumTau)
+    finally:
+        libasora.set_option(_capi.OPT_HEATING, 0)
     phi_ion = libasora.grid_to_host(_capi.GRID_PHI_ION, np.empty((N, N, N)))
+    phi_heat = libasora.grid_to_host(_capi.GRID_PHI_HEAT, np.empty((N, N, N))) if want_heat else None
     printlog(f"took {(time.time()-trt0) : .1f} s.", logfile, quiet)
-    return phi_ion, None
+    return phi_ion, phi_heat

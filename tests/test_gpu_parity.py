@@ -539,3 +539,40 @@ def test_stroemgren_sphere_expansion(asora, tmp_path):
     assert np.all(ratios[1:] > 0.975) and np.all(ratios[1:] < 1.01), ratios
     assert 0.3 < xh.mean() < 0.5                                  # ~ (4/3 pi r_I^3)/box: 0.41 at 500 Myr
     p.device_close()
+
+
+# ---- photo-heating (extension; arithmetic of the Fortran path) -------------------------------------------------
+@pytest.mark.parametrize("name", ["l16_7src_R5.5", "l17_3src_Rbox", "l32_5src_R10", "l16_thin"])
+def test_heating_rates_match_fortran_path(asora, name, tmp_path):
+    """do_raytracing with real heating tables returns phi_heat computed on the GPU.  The checker is the oracle's
+    restatement of the Fortran CPU path (photorates.f90:118,124, raytracing.f90:532,537), itself bit-identical to
+    the compiled reference (tests/test_oracle_vs_reference.py)."""
+    p, lib, capi = asora
+    c = cases.rt_case(name, "soft")
+    N = c["N"]
+    hthin, hthick = 2.1e-11 * c["thin"] * np.linspace(1.0, 3.0, c["thin"].shape[0]), 1.7e-11 * c["thick"]
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 8)
+    p.photo_table_to_device(c["thin"][:-1], c["thick"][:-1])         # tables of NumTau = len-1 points
+    lib.set_option(capi.OPT_FORTRAN_CONSTANTS, 1)
+    try:
+        phi, heat = p.do_raytracing(c["dr"], c["flux"], c["pos"], True, 1000, N, 0.0, c["ndens"], c["xh"],
+                                    c["thin"][:-1], c["thick"][:-1], hthin[:-1], hthick[:-1], c["minlogtau"],
+                                    c["dlogtau"], c["R"], c["sig"], logfile=str(tmp_path / "log"), quiet=True)
+    finally:
+        lib.set_option(capi.OPT_FORTRAN_CONSTANTS, 0)
+    ref = O.do_all_sources(c["flux"], c["pos"], max_subbox=1000, subboxsize=N, sig=c["sig"], dr=c["dr"],
+                           ndens=c["ndens"], xh_av=c["xh"], loss_fraction=0.0, thin=c["thin"][:-1],
+                           thick=c["thick"][:-1], minlogtau=c["minlogtau"], dlogtau=c["dlogtau"], R_max_LLS=c["R"],
+                           heat_thin=hthin[:-1], heat_thick=hthick[:-1], NumTau=c["thin"].shape[0] - 1)
+    assert heat is not None and heat.shape == (N, N, N)
+    np.testing.assert_allclose(phi, ref["phi_ion"], rtol=GAMMA_RTOL, atol=0)
+    np.testing.assert_allclose(heat, ref["phi_heat"], rtol=GAMMA_RTOL, atol=0)
+    assert np.array_equal(heat != 0, phi != 0)
+    # zero heating tables (what evolve3D passes, evolve.py:193): no heating grid
+    phi2, heat2 = p.do_raytracing(c["dr"], c["flux"], c["pos"], True, 1000, N, 0.0, c["ndens"], c["xh"], c["thin"][:-1],
+                                  c["thick"][:-1], np.zeros(5), np.zeros(5), c["minlogtau"], c["dlogtau"], c["R"],
+                                  c["sig"], logfile=str(tmp_path / "log"), quiet=True)
+    assert heat2 is None
+    p.device_close()

@@ -37,6 +37,21 @@ def test_random_chemistry_passes(seed):
     assert np.array_equal(xa, xa2) and np.array_equal(xi, xi2) and conv == conv2
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_heating_grid_of_the_fortran_path(seed):
+    N = 12 + seed
+    nd, xh, dr = cases.grid(N, "lognormal", 5000 + seed, 0.07)
+    pos, flux = cases.sources(N, 3, 5100 + seed, flux=2.0)
+    thin, thick, dlog = cases.soft_tables()
+    ht, hk = 3e-11 * thin[::-1].copy(), 2e-11 * thick
+    kw = dict(max_subbox=1000, subboxsize=N, sig=cases.SIG, dr=dr, ndens=nd, xh_av=xh, loss_fraction=0.0, thin=thin,
+              thick=thick, minlogtau=cases.MINLOGTAU, dlogtau=dlog, R_max_LLS=1000.0, heat_thin=ht, heat_thick=hk,
+              NumTau=thin.shape[0] - 1)
+    a, b = O.do_all_sources(flux, pos, **kw), F.do_all_sources(flux, pos, **kw)
+    assert np.array_equal(a["phi_heat"], b["phi_heat"]) and np.any(a["phi_heat"])
+    assert np.array_equal(a["phi_ion"], b["phi_ion"])
+
+
 def test_heating_tables_and_grey_rates():
     thin, thick, dlog = cases.soft_tables()
     ht, hk = 3e-11 * thin, 2e-11 * thick
