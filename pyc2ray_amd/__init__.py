@@ -10,4 +10,7 @@ from .asora_core import *      # noqa: F401,F403
 from .raytracing import *      # noqa: F401,F403
 from .chemistry import *       # noqa: F401,F403
 from .utils import *           # noqa: F401,F403
+from .radiation import *       # noqa: F401,F403
+from .c2ray_base import *      # noqa: F401,F403
+from .c2ray_test import *      # noqa: F401,F403
 from . import evolve, raytracing, chemistry, asora_core, utils, dist   # noqa: F401

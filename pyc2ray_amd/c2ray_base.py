@@ -1,0 +1,343 @@
+"""Thin C2Ray simulation class with the reference's interface (pyc2ray/c2ray_base.py).
+
+Holds the parameters of a run, derives the constants the hot path needs, builds the radiation tables
+and forwards ``evolve3D`` / ``do_raytracing`` to the MI355X kernels.  Same YAML layout, attribute names
+and method names as the reference, so its driver scripts (e.g. test/paper_tests/test1_Ifront/run_test.py)
+work with ``import pyc2ray_amd as pc2r``.
+
+Differences from the reference:
+  * ``do_raytracing`` passes the heating tables (the reference's method passes 16 arguments to a
+    17-argument function, c2ray_base.py:314-321, and raises TypeError).
+  * Cosmology: astropy's ``FlatLambdaCDM`` is used when astropy is installed; otherwise
+    ``FlatLambdaCDMLite`` below evaluates the same flat LCDM expressions (matter + Lambda + photons +
+    3.04 massless neutrinos).  The lite version could not be compared with astropy in the build
+    container (astropy absent), so runs that need cosmological time steps to 1e-6 should have astropy.
+  * ``use_mpi`` may be ``pyc2ray_amd.dist.MPI`` (torch.distributed/RCCL) as well as mpi4py's ``MPI``.
+"""
+import atexit
+import re
+
+import numpy as np
+import yaml
+
+try:
+    from yaml import CSafeLoader as SafeLoader
+except ImportError:  # pragma: no cover
+    from yaml import SafeLoader
+
+from .asora_core import cuda_is_init, device_close, device_init, photo_table_to_device
+from .evolve import evolve3D, evolve3D_MPI
+from .radiation import BlackBodySource, make_tau_table
+from .raytracing import do_raytracing
+from .utils.logutils import printlog
+
+__all__ = ['C2Ray', 'FlatLambdaCDMLite', 'YEAR', 'Mpc']
+
+# Conversion factors with the values the reference hard-codes (c2ray_base.py:74-80)
+pc = 3.086e18
+YEAR = 3.15576E+07
+ev2fr = 0.241838e15                     # eV to frequency (Hz)
+ev2k = 1.0 / 8.617e-05                  # eV to Kelvin
+kpc = 1e3 * pc
+Mpc = 1e6 * pc
+msun2g = 1.98892e33
+
+
+class FlatLambdaCDMLite:
+    """Flat LCDM background with the expressions astropy's FlatLambdaCDM(H0, Om0, Tcmb0, Ob0=...) uses
+    (massless neutrinos, Neff = 3.04): E(z)^2 = Om0 (1+z)^3 + (Ogamma0 + Onu0)(1+z)^4 + Ode0.
+    Only what C2Ray needs: age, lookback_time, scale_factor, and the inverse of age."""
+
+    _G = 6.6743e-11               # CODATA 2018, SI
+    _c = 299792458.0
+    _sigma_sb = 5.670374419e-8
+    _Mpc_m = 3.0856775814913673e22
+
+    def __init__(self, H0, Om0, Tcmb0=0.0, Ob0=None, Neff=3.04):
+        self.H0 = float(H0)
+        self.Om0 = float(Om0)
+        self.Ob0 = Ob0
+        self.Tcmb0 = float(Tcmb0)
+        self._H0_s = self.H0 * 1e3 / self._Mpc_m                       # s^-1
+        rho_crit = 3.0 * self._H0_s ** 2 / (8.0 * np.pi * self._G)      # kg m^-3
+        self.Ogamma0 = 4.0 * self._sigma_sb / self._c ** 3 * self.Tcmb0 ** 4 / rho_crit
+        self.Onu0 = 0.22710731766 * Neff * self.Ogamma0
+        self.Ode0 = 1.0 - self.Om0 - self.Ogamma0 - self.Onu0
+
+    def efunc(self, z):
+        zp1 = 1.0 + np.asarray(z, dtype=float)
+        return np.sqrt(self.Om0 * zp1 ** 3 + (self.Ogamma0 + self.Onu0) * zp1 ** 4 + self.Ode0)
+
+    def scale_factor(self, z):
+        return 1.0 / (1.0 + z)
+
+    def age(self, z):
+        """Age of the universe at redshift z, in seconds."""
+        from scipy.integrate import quad
+        # t = 1/H0 int_0^{a} da' / (a' E(a'))  with a = 1/(1+z)
+        a = 1.0 / (1.0 + z)
+        f = lambda x: 1.0 / (x * float(self.efunc(1.0 / x - 1.0)))
+        val, _ = quad(f, 0.0, a, epsabs=0.0, epsrel=1e-12, limit=200)
+        return val / self._H0_s
+
+    def lookback_time(self, z):
+        return self.age(0.0) - self.age(z)
+
+    def z_at_age(self, t):
+        from scipy.optimize import brentq
+        return brentq(lambda z: self.age(z) - t, -0.5, 1e4, xtol=1e-12, rtol=1e-12)
+
+
+def _make_cosmology(H0, Om0, Tcmb0, Ob0):
+    try:
+        from astropy.cosmology import FlatLambdaCDM
+        return FlatLambdaCDM(H0, Om0, Tcmb0, Ob0=Ob0), True
+    except ImportError:
+        return FlatLambdaCDMLite(H0, Om0, Tcmb0, Ob0=Ob0), False
+
+
+class C2Ray:
+    def __init__(self, paramfile, Nmesh, use_gpu, use_mpi):
+        """Basis class of a C2Ray simulation (pyc2ray/c2ray_base.py:82-145).
+
+        paramfile : YAML parameter file (same keys as the reference's parameters.yml files)
+        Nmesh     : mesh size
+        use_gpu   : must be True in this build (the reference's Fortran CPU raytracer is not shipped)
+        use_mpi   : None/False, mpi4py's MPI module, or pyc2ray_amd.dist.MPI
+        """
+        if use_mpi:
+            self.mpi = use_mpi
+            self.comm = use_mpi.COMM_WORLD
+            self.rank = self.comm.Get_rank()
+            self.nprocs = self.comm.Get_size()
+        else:
+            self.mpi = False
+            self.rank = 0
+            self.nprocs = 1
+
+        self._read_paramfile(paramfile)
+        self.N = Nmesh
+        self.shape = (Nmesh, Nmesh, Nmesh)
+
+        if use_gpu:
+            self.gpu = True
+            src_batch_size = self._ld["Raytracing"]["source_batch_size"]
+            device_init(Nmesh, src_batch_size)
+            atexit.register(self._gpu_close)
+        else:
+            self.gpu = False
+
+        self._param_init()
+        self._output_init()
+        self._grid_init()
+        self._cosmology_init()
+        self._redshift_init()
+        self._material_init()
+        self._sources_init()
+        self._radiation_init()
+        if self.rank == 0:
+            if self.gpu:
+                q_max = np.ceil(1.73205080757 * min(self.R_max_LLS, 1.73205080757 * self.N / 2))
+                self.printlog(f"Using ASORA Raytracing ( q_max = {q_max : n} )")
+            else:
+                self.printlog(f"Using CPU Raytracing (subboxsize = {self.subboxsize : n}, max_subbox = {self.max_subbox : n})")
+            if self.mpi:
+                self.printlog(f"Using {self.nprocs:n} MPI Ranks")
+            else:
+                self.printlog("Running in non-MPI (single-GPU/CPU) mode")
+            self.printlog("Starting simulation... \n\n")
+
+    # ---- time evolution -------------------------------------------------------------------------
+    def set_timestep(self, z1, z2, num_timesteps):
+        """Time step (s) between two redshift slices (c2ray_base.py:147-168)."""
+        t1 = self._lookback_s(z1)
+        t2 = self._lookback_s(z2)
+        return (t1 - t2) / num_timesteps
+
+    def evolve3D(self, dt, src_flux, src_pos):
+        """Evolve the grid over one time step (c2ray_base.py:170-226)."""
+        args = (self.temp, self.ndens, self.xh, self.photo_thin_table, self.photo_thick_table, self.minlogtau,
+                self.dlogtau, self.R_max_LLS, self.convergence_fraction, self.sig, self.bh00, self.albpow,
+                self.colh0, self.temph0, self.abu_c, self.logfile)
+        if self.mpi and src_flux.shape[0] >= self.nprocs:
+            self.xh, self.phi_ion = evolve3D_MPI(dt, self.dr, src_flux, src_pos, self.gpu, self.max_subbox,
+                                                 self.subboxsize, self.loss_fraction, self.mpi, self.comm, self.rank,
+                                                 self.nprocs, *args)
+        else:
+            self.xh, self.phi_ion = evolve3D(dt, self.dr, src_flux, src_pos, self.gpu, self.max_subbox,
+                                             self.subboxsize, self.loss_fraction, *args)
+
+    def cosmo_evolve(self, dt):
+        """Advance time and redshift by dt, diluting density and rescaling the cell size when the run is
+        cosmological; redshift is set at the half time step (c2ray_base.py:229-257)."""
+        t_now = self.time
+        t_half = t_now + 0.5 * dt
+        t_after = t_now + dt
+        z_half = self.time2zred(t_half)
+        if self.cosmological:
+            dilution_factor = ((1 + z_half) / (1 + self.zred)) ** 3
+            self.ndens *= dilution_factor
+            self.dr = self.dr_c * self._scale_factor(z_half)
+        self.zred = z_half
+        self.time = t_after
+
+    def printlog(self, s, quiet=False):
+        if self.logfile is None:
+            raise RuntimeError("Please set the log file in output_ini")
+        printlog(s, self.logfile, quiet)
+
+    def write_output(self, z):
+        pass
+
+    # ---- utilities ------------------------------------------------------------------------------
+    def time2zred(self, t):
+        """Redshift at cosmic age t [s] (c2ray_base.py:281-284)."""
+        if self._astropy:
+            from astropy import units as u
+            from astropy.cosmology import z_at_value
+            return z_at_value(self.cosmology.age, t * u.s).value
+        return self.cosmology.z_at_age(t)
+
+    def zred2time(self, z, unit='s'):
+        """Cosmic age at redshift z (c2ray_base.py:286-297)."""
+        if self._astropy:
+            return self.cosmology.age(z).to(unit).value
+        t = self.cosmology.age(z)
+        return {'s': t, 'yr': t / YEAR, 'Myr': t / (1e6 * YEAR), 'Gyr': t / (1e9 * YEAR)}[unit]
+
+    def _lookback_s(self, z):
+        if self._astropy:
+            return self.cosmology.lookback_time(z).to('s').value
+        return self.cosmology.lookback_time(z)
+
+    def _scale_factor(self, z):
+        return float(self.cosmology.scale_factor(z))
+
+    def do_raytracing(self, src_flux, src_pos):
+        """Photo-ionisation rates of the current state, chemistry untouched (c2ray_base.py:300-323)."""
+        gamma = do_raytracing(self.dr, src_flux, src_pos, self.gpu, self.max_subbox, self.subboxsize,
+                              self.loss_fraction, self.ndens, self.xh, self.photo_thin_table,
+                              self.photo_thick_table, self.heat_thin_table, self.heat_thick_table, self.minlogtau,
+                              self.dlogtau, self.R_max_LLS, self.sig, self.logfile)
+        self.phi_ion = gamma[0]
+        if gamma[1] is not None:
+            self.phi_heat = gamma[1]
+        return gamma
+
+    # ---- initialisation (c2ray_base.py:329-480) ----------------------------------------------------
+    def _param_init(self):
+        """Constants of the run from the parameter file (c2ray_base.py:329-352)."""
+        ld = self._ld
+        for key in ('eth0', 'ethe0', 'ethe1', 'bh00', 'fh0', 'xih0', 'albpow'):
+            setattr(self, key, ld['CGS'][key])
+        for key in ('abu_h', 'abu_he', 'abu_c'):
+            setattr(self, key, ld['Abundances'][key])
+        for key in ('loss_fraction', 'convergence_fraction', 'max_subbox', 'subboxsize'):
+            setattr(self, key, ld['Raytracing'][key])
+        self.sig = ld['Photo']['sigma_HI_at_ion_freq']
+        self.mean_molecular = self.abu_h + 4.0 * self.abu_he
+        # collisional ionisation parameter and ionisation energy in K (c2ray_base.py:346-347)
+        self.colh0 = ld['CGS']['colh0_fact'] * self.fh0 * self.xih0 / self.eth0 ** 2
+        self.temph0 = self.eth0 * ev2k
+
+    def _cosmology_init(self):
+        cs = self._ld['Cosmology']
+        self.cosmology, self._astropy = _make_cosmology(100 * cs['h'], cs['Omega0'], cs['cmbtemp'], cs['Omega_B'])
+        self.cosmological = cs['cosmological']
+        self.zred_0 = cs['zred_0']
+        self.age_0 = self.zred2time(self.zred_0)
+        if self.cosmological:
+            if self.rank == 0:
+                self.printlog(f"Cosmology is on, scaling comoving quantities to the initial redshift, which is z0 = {self.zred_0:.3f}...")
+            self.dr = self._scale_factor(self.zred_0) * self.dr_c
+        else:
+            if self.rank == 0:
+                self.printlog("Cosmology is off.")
+
+    def _radiation_init(self):
+        ph = self._ld['Photo']
+        self.minlogtau = ph['minlogtau']
+        self.maxlogtau = ph['maxlogtau']
+        self.NumTau = ph['NumTau']
+        self.SourceType = ph['SourceType']
+        self.grey = ph['grey']
+        self.compute_heating_rates = ph['compute_heating_rates']
+        if self.rank == 0:
+            if self.grey:
+                self.printlog("Warning: Using grey opacity")
+            else:
+                self.printlog(f"Using power-law opacity with {self.NumTau:n} table points between tau=10^({self.minlogtau:n}) and tau=10^({self.maxlogtau:n})")
+        # NumTau + 1 points: tau = 0 first, then log-spaced (as in C2Ray)
+        self.tau, self.dlogtau = make_tau_table(self.minlogtau, self.maxlogtau, self.NumTau)
+        ion_freq_HI = ev2fr * self.eth0
+        ion_freq_HeII = ev2fr * self.ethe1
+        if self.SourceType == 'blackbody':
+            freq_min = ion_freq_HI
+            freq_max = 10 * ion_freq_HeII
+            self.bb_Teff = self._ld['BlackBodySource']['Teff']
+            self.cs_pl_idx_h = self._ld['BlackBodySource']['cross_section_pl_index']
+            radsource = BlackBodySource(self.bb_Teff, self.grey, ion_freq_HI, self.cs_pl_idx_h)
+            if self.rank == 0:
+                self.printlog(f"Using Black-Body sources with effective temperature T = {radsource.temp :.1e} K")
+                self.printlog(f"Spectrum Frequency Range: {freq_min:.3e} to {freq_max:.3e} Hz")
+                self.printlog("Integrating photoionization rates tables...")
+            self.photo_thin_table, self.photo_thick_table = radsource.make_photo_table(self.tau, freq_min, freq_max, 1e48)
+            if self.compute_heating_rates:
+                self.printlog("Integrating photoheating rates tables...")
+                self.heat_thin_table, self.heat_thick_table = radsource.make_heat_table(self.tau, freq_min, freq_max, 1e48)
+            else:
+                self.printlog("INFO: No heating rates")
+                self.heat_thin_table = np.zeros(self.NumTau + 1)
+                self.heat_thick_table = np.zeros(self.NumTau + 1)
+        else:
+            raise NameError("Unknown source type : ", self.SourceType)
+        if self.gpu:
+            photo_table_to_device(self.photo_thin_table, self.photo_thick_table)
+            if self.rank == 0:
+                self.printlog("Successfully copied radiation tables to GPU memory.")
+
+    def _grid_init(self):
+        self.boxsize_c = self._ld['Grid']['boxsize'] * Mpc
+        self.dr_c = self.boxsize_c / self.N
+        if self.rank == 0:
+            self.printlog(f"Welcome! Mesh size is N = {self.N:n}.")
+            self.printlog(f"Simulation Box size (comoving Mpc): {self.boxsize_c/Mpc:.3e}")
+        self.dr = self.dr_c
+        # R_max (LLS type 3) in cell units
+        self.R_max_LLS = self._ld['Photo']['R_max_cMpc'] * self.N / self._ld['Grid']['boxsize']
+        self.printlog(f"Maximum comoving distance for photons from source (type 3 LLS): {self._ld['Photo']['R_max_cMpc'] : .3e} comoving Mpc")
+        self.printlog(f"This corresponds to                                             {self.R_max_LLS : .3f} grid cells.")
+
+    # overridden by the concrete simulation classes
+    def _output_init(self):
+        pass
+
+    def _redshift_init(self):
+        pass
+
+    def _material_init(self):
+        pass
+
+    def _sources_init(self):
+        pass
+
+    def _read_paramfile(self, paramfile):
+        """YAML reader that also takes 1e4-style numbers as floats (c2ray_base.py:490-507)."""
+        class _Loader(SafeLoader):
+            pass
+        _Loader.add_implicit_resolver(
+            u'tag:yaml.org,2002:float',
+            re.compile(u'''^(?:
+            [-+]?(?:[0-9][0-9_]*)\\.[0-9_]*(?:[eE][-+]?[0-9]+)?
+            |[-+]?(?:[0-9][0-9_]*)(?:[eE][-+]?[0-9]+)
+            |\\.[0-9_]+(?:[eE][-+][0-9]+)?
+            |[-+]?[0-9][0-9_]*(?::[0-5]?[0-9])+\\.[0-9_]*
+            |[-+]?\\.(?:inf|Inf|INF)
+            |\\.(?:nan|NaN|NAN))$''', re.X),
+            list(u'-+0123456789.'))
+        with open(paramfile, 'r') as f:
+            self._ld = yaml.load(f, _Loader)
+
+    def _gpu_close(self):
+        if cuda_is_init():
+            device_close()

@@ -1,0 +1,80 @@
+"""The C2Ray / C2Ray_Test classes (interface of pyc2ray/c2ray_base.py, c2ray_test.py)."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PARAMS = os.path.join(HERE, "data", "parameters_test.yml")
+
+
+def test_cosmology_lite_is_self_consistent():
+    from pyc2ray_amd.c2ray_base import FlatLambdaCDMLite, YEAR
+    c = FlatLambdaCDMLite(70.0, 0.27, 2.726, Ob0=0.044)
+    assert abs(c.Om0 + c.Ode0 + c.Ogamma0 + c.Onu0 - 1.0) < 1e-15
+    assert 4.9e-5 < c.Ogamma0 < 5.2e-5                     # photons today for T = 2.726 K, h = 0.7
+    t0 = c.age(0.0) / (1e9 * YEAR)
+    assert 13.5 < t0 < 14.1                                # Gyr for (h, Om) = (0.7, 0.27)
+    for z in (0.5, 6.0, 9.938, 30.0):
+        assert abs(c.z_at_age(c.age(z)) - z) < 1e-9 * (1 + z)
+    assert c.lookback_time(9.0) == pytest.approx(c.age(0.0) - c.age(9.0))
+    # matter-dominated limit: t ~ 2/(3 H0 sqrt(Om)) (1+z)^-3/2 (radiation shortens it by < 4 % at z = 30)
+    z = 30.0
+    t_md = 2.0 / (3.0 * c._H0_s * np.sqrt(c.Om0)) * (1 + z) ** -1.5
+    assert 0.95 < c.age(z) / t_md < 1.0
+
+
+def test_yaml_reader_takes_scientific_notation_as_float(tmp_path):
+    from pyc2ray_amd.c2ray_base import C2Ray
+    obj = C2Ray.__new__(C2Ray)
+    obj._read_paramfile(PARAMS)
+    assert isinstance(obj._ld["Material"]["temp0"], float) and obj._ld["Material"]["temp0"] == 1e4
+    assert obj._ld["Photo"]["NumTau"] == 2000 and obj._ld["CGS"]["bh00"] == 2.59e-13
+
+
+@pytest.mark.gpu
+def test_c2ray_test_class_drives_the_gpu_path(tmp_path):
+    """The reference's driver pattern (test/paper_tests/test1_Ifront/run_test.py:37-77) at 32^3:
+    the class must give exactly what direct evolve3D calls give."""
+    import pyc2ray_amd as pc2r
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        if pc2r.cuda_is_init():
+            pc2r.device_close()
+        N = 32
+        sim = pc2r.C2Ray_Test(PARAMS, N, True)
+        assert sim.R_max_LLS == pytest.approx(15.0 * N / 1.62022035)
+        assert sim.colh0 == pytest.approx(1.3e-8 * 0.83 / 13.598 ** 2) and sim.temph0 == pytest.approx(13.598 / 8.617e-05)
+        assert sim.dr == pytest.approx(1.62022035 * 3.086e24 / N)
+        assert sim.photo_thick_table.shape == (2001,) and sim.photo_thick_table[0] == pytest.approx(1e48, rel=1e-9)
+        with open("src.txt", "w") as f:
+            f.write("1\n16 16 16 1e54 1.0\n")
+        srcpos, srcflux = sim.read_sources("src.txt", 1)
+        zs = sim.generate_redshift_array(3, 5e7)
+        assert zs[0] == pytest.approx(9.0, abs=1e-6) and zs[0] > zs[1] > zs[2]
+        xh_direct = np.array(sim.xh, copy=True)
+        for k in range(2):
+            dt = sim.set_timestep(zs[k], zs[k + 1], 1)
+            assert dt == pytest.approx(5e7 * 3.15576e7, rel=1e-6)
+            sim.density_init(zs[k])
+            assert np.allclose(sim.ndens, 1.87e-7 * 10.0 ** 3)
+            sim.cosmo_evolve(dt)
+            sim.evolve3D(dt, srcflux, srcpos)
+            xh_direct, phi_direct = pc2r.evolve3D(dt, sim.dr, srcflux, srcpos, True, sim.max_subbox, sim.subboxsize,
+                                                  sim.loss_fraction, sim.temp, sim.ndens, xh_direct,
+                                                  sim.photo_thin_table, sim.photo_thick_table, sim.minlogtau,
+                                                  sim.dlogtau, sim.R_max_LLS, sim.convergence_fraction, sim.sig,
+                                                  sim.bh00, sim.albpow, sim.colh0, sim.temph0, sim.abu_c,
+                                                  logfile=sim.logfile, quiet=True)
+            assert np.array_equal(sim.xh, xh_direct) and np.array_equal(sim.phi_ion, phi_direct)
+        assert sim.xh.max() > 0.9 and sim.xh.mean() > 1.2e-3
+        gamma, heat = sim.do_raytracing(srcflux, srcpos)          # the reference's method raises TypeError here
+        assert gamma.shape == (N, N, N) and heat is None and np.array_equal(sim.phi_ion, gamma)
+        sim.write_output(zs[2])
+        sim.write_output_numbered(7)
+        assert os.path.exists(f"./xfrac_{zs[2]:.3f}.pkl") and os.path.exists("./IonRates_7.pkl")
+        pc2r.device_close()
+    finally:
+        os.chdir(cwd)
