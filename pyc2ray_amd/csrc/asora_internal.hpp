@@ -54,6 +54,7 @@ struct State {
     int geom_units = 0;
     const double2 *logtab_dev = nullptr;
     bool geom_valid = false;
+    bool geom_dr_matters = true;
     int geom_N = 0, geom_S = 0, geom_max_cells = 0, geom_threads = 0;
     double geom_R = 0.0, geom_dr = 0.0;
 

@@ -439,6 +439,7 @@ struct HostGeom {
     int nsteps = 0;
     uint32_t max_cells = 1;
     bool inconsistent = false;   // a corner of non-zero weight was not found in the unit
+    bool on_sphere = false;      // some cell needed the floating-point distance test (its result depends on dr)
 };
 
 inline bool inside_radius_reference(int a, int b, int c, double dr, double R2)
@@ -485,6 +486,7 @@ void build_octant_geometry(HostGeom &h, int Ea, int Eb, int Ec, double R, double
         const double n2 = (double)a * a + (double)b * b + (double)c * c;
         if (n2 > R2hi) return false;
         if (n2 < R2 * (1.0 - 1e-9) - 1e-9) return true;
+        h.on_sphere = true;
         return inside_radius_reference(a, b, c, dr, R2);
     };
     const uint4 pad_a = {0u, 0u, 0u, 0u};
@@ -592,8 +594,9 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
     const int q_max = (int)std::ceil(1.73205080757 * std::min(p.R, 1.73205080757 * N / 2.0));   // raytracing.cu:14,101
     const int ext_pos = N / 2 - 1 + (N % 2);                                                      // raytracing.cu:122
     const int ext_neg = N / 2;                                                                    // raytracing.cu:123
-    if (st.geom_valid && st.geom_N == N && st.geom_R == p.R && st.geom_dr == p.dr && st.geom_threads == threads &&
-        st.geom_units == units) {
+    // dr only matters when some cell sits exactly on the sphere (a cosmological run changes dr every step)
+    if (st.geom_valid && st.geom_N == N && st.geom_R == p.R && (st.geom_dr == p.dr || !st.geom_dr_matters) &&
+        st.geom_threads == threads && st.geom_units == units) {
         for (int o = 0; o < units; ++o) p.geom[o] = st.geom_host[o];
         p.units = units;
         p.logtab = st.logtab_dev; p.S = st.geom_S; p.max_cells = st.geom_max_cells;
@@ -625,6 +628,7 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
     int Smax = 0;
     uint32_t max_cells = 1;
     const uint32_t MARK = 0xffffffffu;
+    bool dr_matters = false;
     for (int u = 0; u < units; ++u) {
         if (owner[u] != u) continue;
         const int oct = u & 7, sector = units == 24 ? (u >> 3) : -1;
@@ -633,6 +637,7 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
             return fail(11, "raytrace geometry: a cell of a sector reads a corner outside the sector (internal error)");
         Smax = std::max(Smax, hg[u].S);
         max_cells = std::max(max_cells, hg[u].max_cells);
+        dr_matters = dr_matters || hg[u].on_sphere;
     }
     // zero-slot marker -> max_cells (the slot that holds 0.0), then upload
     for (int u = 0; u < units; ++u) {
@@ -668,6 +673,7 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
     st.logtab_dev = ltd;
     st.geom_N = N; st.geom_R = p.R; st.geom_dr = p.dr; st.geom_S = Smax; st.geom_max_cells = (int)max_cells;
     st.geom_threads = threads;
+    st.geom_dr_matters = dr_matters;
     st.geom_valid = true;
     for (int o = 0; o < units; ++o) p.geom[o] = od[o];
     p.units = units;
