@@ -87,7 +87,8 @@ static int release_all()
     State &st = g_state;
     auto drop = [](auto *&ptr) { if (ptr) { (void)hipFree(ptr); ptr = nullptr; } };
     for (int g = 0; g < ASORA_GRID_COUNT; ++g) { drop(st.grid[g]); st.grid_valid[g] = false; }
-    drop(st.nhi); drop(st.nhi_t); drop(st.phi_t); drop(st.heat_t); drop(st.staging);
+    drop(st.nhi); drop(st.staging);
+    st.nhi_t = st.phi_t = st.heat_t = nullptr;    // second halves of nhi / phi_ion / phi_heat
     st.have_heat_tables = false;
     drop(st.tables); st.table_len = 0;
     drop(st.src_pos); drop(st.src_flux); st.num_src = 0;
@@ -151,17 +152,17 @@ static int do_raytrace(double R, double sig, double dr, int src_begin, int src_c
     p.grey = st.opt[ASORA_OPT_GREY_NOTABLES];
     p.z_transposed = zt ? 1 : 0;
     p.src_begin = src_begin; p.src_count = src_count;
+    p.ncell = (unsigned)st.ncell;
     p.nhi = st.nhi;
-    p.nhi_t_off = (long long)(((intptr_t)st.nhi_t - (intptr_t)st.nhi) / (intptr_t)sizeof(double));
     p.phi = st.grid[ASORA_GRID_PHI_ION];
-    p.phi_t_off = (long long)(((intptr_t)st.phi_t - (intptr_t)st.grid[ASORA_GRID_PHI_ION]) / (intptr_t)sizeof(double));
     p.tables = st.tables;
     p.heat = st.grid[ASORA_GRID_PHI_HEAT];
-    p.heat_t_off = (long long)(((intptr_t)st.heat_t - (intptr_t)st.grid[ASORA_GRID_PHI_HEAT]) / (intptr_t)sizeof(double));
     p.src_pos = st.src_pos; p.src_flux = st.src_flux;
     p.dump = dump;
     p.counters = st.counters;
+#ifdef ASORA_ENABLE_ABLATION
     { const char *ab = getenv("ASORA_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
+#endif
     if (int rc = launch_raytrace(st, p, dump != nullptr, heat)) return rc;
     if (zt) {
         if (int rc = launch_finish_phi(st)) return rc;
@@ -185,7 +186,7 @@ int asora_device_init_ex(int N, int num_src_par, int device_id)
 {
     clear_error();
     State &st = g_state;
-    if (N < 2 || N > 1600) return fail(1, "device_init: N must be in [2, 1600] (32-bit cell indices)");
+    if (N < 2 || N > 1280) return fail(1, "device_init: N must be in [2, 1280] (32-bit cell indices over 2 N^3)");
     if (st.init) release_all();
     if (st.stream && device_id != st.device) return fail(1, "device_init: the device cannot change within a process");
     st.device = device_id;
@@ -194,11 +195,15 @@ int asora_device_init_ex(int N, int num_src_par, int device_id)
     st.ncell = (size_t)N * N * N;
     st.num_src_par = num_src_par;
     const size_t bytes = st.ncell * sizeof(double);
-    for (int g = 0; g < ASORA_GRID_COUNT; ++g) ASORA_HIP_TRY(hipMalloc(&st.grid[g], bytes));
-    ASORA_HIP_TRY(hipMalloc(&st.nhi, bytes));
-    ASORA_HIP_TRY(hipMalloc(&st.nhi_t, bytes));
-    ASORA_HIP_TRY(hipMalloc(&st.phi_t, bytes));
-    ASORA_HIP_TRY(hipMalloc(&st.heat_t, bytes));
+    // the rate grids and nHI carry their [k][j][i] twin directly behind them (one 32-bit index reaches both)
+    for (int g = 0; g < ASORA_GRID_COUNT; ++g) {
+        const bool twin = (g == ASORA_GRID_PHI_ION || g == ASORA_GRID_PHI_HEAT);
+        ASORA_HIP_TRY(hipMalloc(&st.grid[g], twin ? 2 * bytes : bytes));
+    }
+    ASORA_HIP_TRY(hipMalloc(&st.nhi, 2 * bytes));
+    st.nhi_t = st.nhi + st.ncell;
+    st.phi_t = st.grid[ASORA_GRID_PHI_ION] + st.ncell;
+    st.heat_t = st.grid[ASORA_GRID_PHI_HEAT] + st.ncell;
     ASORA_HIP_TRY(hipMalloc(&st.staging, bytes));
     st.init = true;
     return 0;

@@ -34,10 +34,11 @@ struct State {
     bool grid_valid[ASORA_GRID_COUNT] = {false, false, false, false, false, false, false};
 
     // derived per raytrace call
-    double *nhi = nullptr;     // ndens*(1-xh_av), [i][j][k]
-    double *nhi_t = nullptr;   // same, transposed [k][j][i]
-    double *phi_t = nullptr;   // rate accumulator for z-faces, transposed [k][j][i]
-    double *heat_t = nullptr;  // heating-rate accumulator for z-faces, transposed
+    // each of these is the second half of a 2 N^3 allocation whose first half is the [i][j][k] grid
+    double *nhi = nullptr;     // ndens*(1-xh_av), [i][j][k] (owns the allocation)
+    double *nhi_t = nullptr;   // = nhi + N^3: same, transposed [k][j][i]
+    double *phi_t = nullptr;   // = grid[PHI_ION] + N^3: rate accumulator for z-faces, transposed [k][j][i]
+    double *heat_t = nullptr;  // = grid[PHI_HEAT] + N^3: heating-rate accumulator for z-faces, transposed
     bool have_heat_tables = false;
     double *staging = nullptr; // N^3 staging grid for 'F'-order transfers / debug dumps
 
@@ -119,13 +120,11 @@ struct RtParams {
     OctGeomDev geom[24];        // by value: pointers read from the kernarg segment are known-global to the compiler
     int units;                  // 8: one workgroup per octant; 24: per octant and sector (unit = sector*8 + octant)
     const double2 *logtab;      // 128 x {1/c, log2 c}
-    const double *nhi;          // nHI [i][j][k]; the [k][j][i] copy sits nhi_t_off elements further
-    long long nhi_t_off;
-    double *phi;                // Gamma accumulator [i][j][k]; the transposed one phi_t_off elements further
-    long long phi_t_off;
+    unsigned ncell;             // N^3: the [k][j][i] copy of a grid starts ncell elements after its [i][j][k] form
+    const double *nhi;          // nHI, [i][j][k] then [k][j][i]
+    double *phi;                // Gamma accumulator, [i][j][k] then [k][j][i]
     const double2 *tables;      // pairs {T[i], T[i+1]-T[i]}: thick at [0, len), thin at [len, 2 len), heat thick at [2 len, 3 len), heat thin at [3 len, 4 len)
-    double *heat;               // heating accumulator (HEAT kernels); transposed one heat_t_off elements further
-    long long heat_t_off;
+    double *heat;               // heating accumulator (HEAT kernels), [i][j][k] then [k][j][i]
     const int32_t *src_pos;
     const double *src_flux;
     double *dump;               // debug: outgoing column density (N^3) or nullptr

@@ -174,12 +174,23 @@ __device__ __forceinline__ int wrap_once(int x, int N)
 // entry k*RT_THREADS + lane is what `lane` does in step k and the tables can be prefetched blindly.
 //   cellA[e] = { abc, own slot | VALID | LAST_OF_SHELL, path (double, 2 words) }
 //   cellB[e] = { slots of the four upstream corners in the previous shell's buffer }
-// Dynamic LDS: [shell buffer 0: max_cells+1 doubles][shell buffer 1: same]   (unless GLOBAL_SCRATCH)
-//              [log table: 128 x {1/c, log2 c}][1/s: S+1 doubles][wrapped i(a), j(b), k(c): 3*(S+1) ints]
+// Dynamic LDS: [log table: 128 x {1/c, log2 c}][1/s: TABCAP doubles][wrapped i(a), j(b), k(c): 3*TABCAP ints]
+//              [shell buffer 0: max_cells+1 doubles][shell buffer 1: same]   (the last two unless GLOBAL_SCRATCH)
+// TABCAP = 256 (S <= 255) or 1024.
 // Slot max_cells of each shell buffer holds 0.0: upstream corners of weight 0 point there.
+// Diagnostic builds only (make EXTRA=-DASORA_ENABLE_ABLATION, tools/ablate.sh): ASORA_ABLATE=1 skips the rate
+// atomics, 2 the rates, 4 the shell barriers, to attribute kernel time.  Production builds contain none of it.
+#ifdef ASORA_ENABLE_ABLATION
+#define ASORA_ABLATED(bit) ((p.ablate & (bit)) != 0)
+#define ASORA_RATE_ATOMIC(dst, v) do { if (!(p.ablate & 1)) unsafeAtomicAdd((dst), (v)); else if ((v) == 1.2345e-300) (dst)[0] = (v); } while (0)
+#else
+#define ASORA_ABLATED(bit) false
+#define ASORA_RATE_ATOMIC(dst, v) unsafeAtomicAdd((dst), (v))
+#endif
+
 constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_RATE = 1u << 29, CELL_SLOT_MASK = (1u << 29) - 1;
 
-template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP, bool HEAT>
+template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP, bool HEAT, int TABCAP>
 __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtParams p)
 {
     extern __shared__ double lds_raw[];
@@ -204,22 +215,22 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
     const double flux = p.src_flux[ns];
     const int sa = (oct & 1) ? -1 : 1, sb = (oct & 2) ? -1 : 1, sc = (oct & 4) ? -1 : 1;
 
-    const int slots = (p.max_cells + 2) & ~1;      // cells + the zero slot, even (keeps the tables behind 16-B aligned)
-    double *prev, *cur, *after;
+    // LDS: the small tables sit first, at compile-time offsets (TABCAP entries each), then the shell buffers
+    double2 *logtab = reinterpret_cast<double2 *>(lds_raw);
+    double *inv_s = reinterpret_cast<double *>(logtab + LOG_TABLE_SIZE);
+    int *wi = reinterpret_cast<int *>(inv_s + TABCAP);
+    int *wj = wi + TABCAP;
+    int *wk = wj + TABCAP;
+    double *shells = reinterpret_cast<double *>(wk + TABCAP);
+    const int slots = (p.max_cells + 2) & ~1;      // cells + the zero slot, even (keeps 16-B alignment)
+    double *prev, *cur;
     if (GLOBAL_SCRATCH) {
         prev = p.shell_scratch + (size_t)blk * 2 * slots;
         cur = prev + slots;
-        after = lds_raw;
     } else {
-        prev = lds_raw;
+        prev = shells;
         cur = prev + slots;
-        after = cur + slots;
     }
-    double2 *logtab = reinterpret_cast<double2 *>(after);
-    double *inv_s = reinterpret_cast<double *>(logtab + LOG_TABLE_SIZE);
-    int *wi = reinterpret_cast<int *>(inv_s + (p.S + 1));
-    int *wj = wi + (p.S + 1);
-    int *wk = wj + (p.S + 1);
 
     for (int t = threadIdx.x; t < LOG_TABLE_SIZE; t += RT_THREADS) logtab[t] = p.logtab[t];
     for (int t = threadIdx.x; t <= p.S; t += RT_THREADS) {
@@ -266,8 +277,9 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
     auto nhi_address = [&](unsigned abc, unsigned &idx) -> const double * {
         const unsigned i = wi[abc & 1023], j = wj[(abc >> 10) & 1023], k = wk[(abc >> 20) & 1023];
         const bool zt = ztr && (abc >> 30) == 2;
-        idx = zt ? (k * N + j) * N + i : (i * N + j) * N + k;
-        return p.nhi + ((long long)idx + (zt ? p.nhi_t_off : 0ll));
+        // the [k][j][i] copies follow the [i][j][k] grids in memory: one 32-bit index covers both
+        idx = zt ? (k * N + j) * N + i + p.ncell : (i * N + j) * N + k;
+        return p.nhi + idx;
     };
 
     // One step of one lane, straight-line (whole-wave instruction count is what matters, so
@@ -282,7 +294,6 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
     Lookup pend_A, pend_B;
     pend_A.t.x = pend_A.t.y = pend_A.residual = 0.0; pend_B = pend_A;
     double *pend_dst = p.phi;
-    int pend_zt = 0;               // the pending cell accumulates into the transposed grids
 
     auto step = [&](unsigned e_pf, const uint4 &cur_A, const uint4 &cur_B, const double cur_nhi, const unsigned cur_idx,
                     const uint4 &nxt_A, double &nxt_nhi, unsigned &nxt_idx, uint4 &pf_A, uint4 &pf_B) {
@@ -309,7 +320,9 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
         // fu = 0 (resp. 1) makes the weights of the corners that do not exist in shell s-1 exactly 0.
         const int U = face == 0 ? b : a, V = face == 2 ? b : c;
         const double is = inv_s[s];
-        const double fu = U == s ? 1.0 : (double)U * is, fv = V == s ? 1.0 : (double)V * is;
+        // (u*(1/s) may miss 0 or 1 by an ulp; the corner that would then get a ~1e-16 weight does not exist
+        //  in shell s-1 and reads the zero slot, so only the denominator moves, below rounding)
+        const double fu = (double)U * is, fv = (double)V * is;
         const double gu = 1.0 - fu, gv = 1.0 - fv;
         // w_n = s_n / max(0.6, c_n*sig) (raytracing.cu:33,422-425) and
         // cdensi = sum(c_n w_n)/sum(w_n) (raytracing.cu:428), with numerator and denominator
@@ -339,15 +352,15 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
         const double maxcd = p.fortran_consts ? (double)2e30f : 2e30;                    // raytracing.cu:15
         const bool owner = valid && (cur_A.y & CELL_RATE) && (zmask & negmask) == 0;
         if (DUMP) { if (owner) p.dump[(wi[a] * N + wj[b]) * N + wk[c]] = cd_out; }
-        rated = owner && cd_in <= maxcd && !(p.ablate & 2);
+        rated = owner && cd_in <= maxcd && !ASORA_ABLATED(2);
         n_gamma += (owner && cd_in <= maxcd) ? 1u : 0u;
         const double n2 = (double)(a * a + b * b + c * c);
-        vol_nhi = rated ? n2 * (dr * dr * FOURPI) * path * nHI : 1.0;       // raytracing.cu:302-307
-        dst = p.phi + ((long long)cur_idx + ((ztr && face == 2) ? p.phi_t_off : 0ll));
+        vol_nhi = n2 * (dr * dr * FOURPI) * path * nHI;                     // raytracing.cu:302-307
+        dst = p.phi + cur_idx;
         }
 
         if (__builtin_amdgcn_readfirstlane(cur_A.y) & CELL_LAST) {   // shell finished: publish it
-            if (!(p.ablate & 4)) __syncthreads();
+            if (!ASORA_ABLATED(4)) __syncthreads();
             double *tmp = prev; prev = cur; cur = tmp;
         }
 
@@ -356,11 +369,11 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
         if (pend) {
             const double ta = lookup_value(pend_A), tb = lookup_value(pend_B);
             const double v = pend_thick ? pend_pref * ta - pend_pref * tb : pend_pref * pend_dtau * ta;
-            if (!(p.ablate & 1)) unsafeAtomicAdd(pend_dst, v); else if (v == 1.2345e-300) pend_dst[0] = v;
+            ASORA_RATE_ATOMIC(pend_dst, v);
             if (HEAT) {      // photorates.f90:118,124 with the same table index and residual
                 const double ha = lookup_heat(pend_A), hb = lookup_heat(pend_B);
                 const double h = pend_thick ? pend_pref * (ha - hb) : pend_pref * pend_dtau * ha;
-                unsafeAtomicAdd(p.heat + (pend_dst - p.phi) + (p.heat_t_off - p.phi_t_off) * (long long)pend_zt, h);
+                unsafeAtomicAdd(p.heat + (pend_dst - p.phi), h);
             }
         }
         if (grey) {
@@ -369,7 +382,8 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
         } else if (!wave_has_work) {
             pend = false;
         } else {
-            const double tau_in = (rated ? cd_in : 1.0) * sig, tau_out = (rated ? cd_out : 1.0) * sig;
+            // (lanes without a rate run the lookups on whatever they hold: the index is clamped for any input)
+            const double tau_in = cd_in * sig, tau_out = cd_out * sig;
             // TAU_PHOTO_LIMIT: rates.cu:7 (double 1e-7) or photorates.f90:69 (single 1e-7 promoted)
             const double limit = p.fortran_consts ? (double)1.0e-7f : 1.0e-7;
             pend_pref = flux / vol_nhi;
@@ -380,7 +394,6 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
             pend_A = lookup_issue<HEAT>(tab, pend_thick ? tau_in : tau_thin, p, logtab);
             pend_B = lookup_issue<HEAT>(tab, pend_thick ? tau_out : tau_thin, p, logtab);
             pend_dst = dst;
-            pend_zt = (ztr && (cur_A.x >> 30) == 2) ? 1 : 0;
             pend = rated;
         }
     };
@@ -402,11 +415,11 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
     if (pend) {
         const double ta = lookup_value(pend_A), tb = lookup_value(pend_B);
         const double v = pend_thick ? pend_pref * ta - pend_pref * tb : pend_pref * pend_dtau * ta;
-        if (!(p.ablate & 1)) unsafeAtomicAdd(pend_dst, v); else if (v == 1.2345e-300) pend_dst[0] = v;
+        ASORA_RATE_ATOMIC(pend_dst, v);
         if (HEAT) {
             const double ha = lookup_heat(pend_A), hb = lookup_heat(pend_B);
             const double h = pend_thick ? pend_pref * (ha - hb) : pend_pref * pend_dtau * ha;
-            unsafeAtomicAdd(p.heat + (pend_dst - p.phi) + (p.heat_t_off - p.phi_t_off) * (long long)pend_zt, h);
+            unsafeAtomicAdd(p.heat + (pend_dst - p.phi), h);
         }
     }
 
@@ -801,14 +814,17 @@ static void pick_launch_shape(const State &st, double R, int N, bool dump, int &
     if (dump) threads = 256;                                // the column-density dump variant is built for 256 only
 }
 
-template <int T>
+constexpr size_t lds_table_bytes(int tabcap) { return LOG_TABLE_SIZE * sizeof(double2) + (size_t)tabcap * (sizeof(double) + 3 * sizeof(int)); }
+
+template <int T, int TABCAP>
 static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t lds_bytes, bool use_lds, bool dump, bool heat)
 {
 #define ASORA_LAUNCH(GS, DP, HT)                                                                                   \
     do {                                                                                                           \
-        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, GS, DP, HT>,                     \
+        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, GS, DP, HT, TABCAP>,             \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));            \
-        hipLaunchKernelGGL((raytrace_octant_kernel<T, GS, DP, HT>), dim3(grid), dim3(T), lds_bytes, st.stream, q); \
+        hipLaunchKernelGGL((raytrace_octant_kernel<T, GS, DP, HT, TABCAP>), dim3(grid), dim3(T), lds_bytes,        \
+                           st.stream, q);                                                                          \
     } while (0)
     if (T == 256 && dump) { if (use_lds) ASORA_LAUNCH(false, true, false); else ASORA_LAUNCH(true, true, false); }
     else if (heat)        { if (use_lds) ASORA_LAUNCH(false, false, true); else ASORA_LAUNCH(true, false, true); }
@@ -822,14 +838,21 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat)
 {
     int units, threads;   // one workgroup per (source, octant) or per (source, octant, sector)
     pick_launch_shape(st, p.R, p.N, dump, units, threads);
+    {   // number of shells, known before the tables are built: the 1024-entry LDS tables exist for 256/512 threads
+        const double R2hi = p.R * p.R * (1.0 + 1e-9) + 1e-9;
+        const int Emax = p.N / 2;
+        const int S_est = std::isfinite(R2hi) ? (int)std::min((double)Emax, std::floor(std::sqrt(R2hi))) : Emax;
+        if (S_est + 1 > 256 && threads < 256) threads = 256;
+    }
     if (int rc = ensure_geometry(st, p, threads, units)) return rc;
     p.lut_k1 = 0.30102999566398119521 / p.dlogtau;      // log10(2)/dlogtau
     p.lut_k0 = 1.0 - p.minlogtau / p.dlogtau;
 
     const size_t slots = ((size_t)p.max_cells + 2) & ~(size_t)1;   // max_cells + zero slot, rounded to even (16-B alignment)
-    // log table, 1/s table, three wrapped-coordinate tables (see the kernel's LDS layout)
-    const size_t fixed_bytes = LOG_TABLE_SIZE * sizeof(double2) + (size_t)(p.S + 1) * sizeof(double) +
-                               3 * (size_t)(p.S + 1) * sizeof(int);
+    // small tables (log table, 1/s, three wrapped-coordinate tables) at fixed capacity, then the shell buffers
+    const bool big_tables = p.S + 1 > 256;
+    if (p.S + 1 > 1024) return fail(4, "raytrace: more than 1023 shells (mesh too large for this build)");
+    const size_t fixed_bytes = lds_table_bytes(big_tables ? 1024 : 256);
     const size_t shell_bytes = 2 * slots * sizeof(double);
     const bool use_lds = shell_bytes + fixed_bytes <= LDS_LIMIT_BYTES;
     const size_t lds_bytes = (use_lds ? shell_bytes : 0) + fixed_bytes;
@@ -861,11 +884,14 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat)
         {
             KernelTimer kt(ASORA_KERNEL_RAYTRACE);
             int rc = 0;
-            switch (threads) {
-                case 64:  rc = launch_variant<64>(st, q, grid, lds_bytes, use_lds, dump, heat); break;
-                case 128: rc = launch_variant<128>(st, q, grid, lds_bytes, use_lds, dump, heat); break;
-                case 512: rc = launch_variant<512>(st, q, grid, lds_bytes, use_lds, dump, heat); break;
-                default:  rc = launch_variant<256>(st, q, grid, lds_bytes, use_lds, dump, heat); break;
+            if (big_tables) {
+                if (threads == 512) rc = launch_variant<512, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat);
+                else                rc = launch_variant<256, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat);
+            } else switch (threads) {
+                case 64:  rc = launch_variant<64, 256>(st, q, grid, lds_bytes, use_lds, dump, heat); break;
+                case 128: rc = launch_variant<128, 256>(st, q, grid, lds_bytes, use_lds, dump, heat); break;
+                case 512: rc = launch_variant<512, 256>(st, q, grid, lds_bytes, use_lds, dump, heat); break;
+                default:  rc = launch_variant<256, 256>(st, q, grid, lds_bytes, use_lds, dump, heat); break;
             }
             if (rc) return rc;
         }
