@@ -285,6 +285,9 @@ def main():
             "algorithmic_bytes_per_launch": RT_BYTES_PER_UPDATE * gamma_cells,
             "avg_launch_ms": rt_ms / max(rt_n, 1),
             "launches_timed": rt_n,
+            "binding_resource": ("memory-side atomic request rate: TCC_EA0_ATOMIC 2.73e7 64-B requests per launch "
+                                 "(profiles/r01_pmc_summary.txt) against ~2.0e10 requests/s chip-wide "
+                                 "(MI355X_MICROARCH.md, Global float atomics)"),
         },
         "kernels_ms_per_step": {
             "raytrace": rt_ms / K, "chemistry": ch_ms / K, "prepare_nhi": pr_ms / K, "fold_phi_t": fi_ms / K,

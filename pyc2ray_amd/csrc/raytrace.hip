@@ -86,7 +86,10 @@ __device__ __forceinline__ Lookup lookup_issue(const double2 *__restrict__ table
     const int i0 = (int)real_i;
     Lookup L;
     L.residual = real_i - (double)i0;
-    const int i = min(i0, p.table_len - 1);
+    int i = min(i0, p.table_len - 1);
+#ifdef ASORA_ENABLE_ABLATION
+    if (p.ablate & 8) i = 15000 + (threadIdx.x & 3);   // diagnostic: perfectly coalesced lookups
+#endif
     L.t = table[i];
     if (HEAT) L.h = table[i + 2 * p.table_len]; else L.h = L.t;
     return L;
@@ -188,10 +191,21 @@ __device__ __forceinline__ int wrap_once(int x, int N)
 #define ASORA_RATE_ATOMIC(dst, v) unsafeAtomicAdd((dst), (v))
 #endif
 
+// 1: a cell's rate lookups are consumed one step after they are issued (hides their latency, costs ~19 VGPRs).
+// Measured on MI355X: no difference in kernel time (the kernel is bound by the atomic request rate), so off.
+#ifndef ASORA_DEFER
+#define ASORA_DEFER 0
+#endif
+
+// waves per SIMD the register allocation must leave room for (2nd argument of __launch_bounds__)
+#ifndef ASORA_MIN_WAVES
+#define ASORA_MIN_WAVES 1
+#endif
+
 constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_RATE = 1u << 29, CELL_SLOT_MASK = (1u << 29) - 1;
 
 template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP, bool HEAT, int TABCAP>
-__global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtParams p)
+__global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_kernel(const RtParams p)
 {
     extern __shared__ double lds_raw[];
 
@@ -366,7 +380,7 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
 
         // ---- rates, raytracing.cu:315-328 + rates.cu:16-41: retire the previous step's lookups,
         // then issue this step's (consumed one step later)
-        if (pend) {
+        auto retire = [&]() {
             const double ta = lookup_value(pend_A), tb = lookup_value(pend_B);
             const double v = pend_thick ? pend_pref * ta - pend_pref * tb : pend_pref * pend_dtau * ta;
             ASORA_RATE_ATOMIC(pend_dst, v);
@@ -375,7 +389,8 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
                 const double h = pend_thick ? pend_pref * (ha - hb) : pend_pref * pend_dtau * ha;
                 unsafeAtomicAdd(p.heat + (pend_dst - p.phi), h);
             }
-        }
+        };
+        if (ASORA_DEFER && pend) retire();
         if (grey) {
             if (rated) unsafeAtomicAdd(dst, grey_rate_per_atom(flux, cd_in, cd_out, vol_nhi, p));
             pend = false;
@@ -395,6 +410,7 @@ __global__ void __launch_bounds__(RT_THREADS) raytrace_octant_kernel(const RtPar
             pend_B = lookup_issue<HEAT>(tab, pend_thick ? tau_out : tau_thin, p, logtab);
             pend_dst = dst;
             pend = rated;
+            if (!ASORA_DEFER) { if (pend) retire(); pend = false; }
         }
     };
 
