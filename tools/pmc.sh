@@ -17,7 +17,8 @@ for d in sorted(glob.glob("$R/gpurun_out/pmc_${TAG}_[0-9]*/")):
         rows=list(csv.DictReader(open(f)))
         agg=collections.defaultdict(list)
         for r in rows:
-            agg[(r["Kernel_Name"].split("(")[0][-40:],r["Counter_Name"])].append(float(r["Counter_Value"]))
+            name=r["Kernel_Name"].split("(")[0].replace("void ","").split("<")[0]
+            agg[(name,r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (k,c),v in sorted(agg.items()):
             if "raytrace" in k or "chemistry_kernel" in k:
                 line=f"{k:42s} {c:26s} n={len(v)} mean={sum(v)/len(v):.5g}"
