@@ -16,7 +16,7 @@ struct OctGeomDev {
     const uint4 *cellA;          // { |di| | |dj|<<10 | |dk|<<20 | face<<30, own slot | flags, path (double) }
     const uint4 *cellB;          // shell-buffer slots of the four upstream corners in shell s-1
     int nsteps;
-    int pad_;
+    int info;                    // sign bits of the unit | (merge axis + 1) << 3 | rates-the-source-cell << 5
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -118,7 +118,7 @@ struct RtParams {
     int src_begin, src_count;
     int ablate;            // diagnostics only (env ASORA_ABLATE): 1 = no rate atomics, 2 = no rates
     OctGeomDev geom[24];        // by value: pointers read from the kernarg segment are known-global to the compiler
-    int units;                  // 8: one workgroup per octant; 24: per octant and sector (unit = sector*8 + octant)
+    int units;                  // workgroups per source: 8 octants, 24 octant-sectors, or 12 mirrored sector pairs
     const double2 *logtab;      // 128 x {1/c, log2 c}
     unsigned ncell;             // N^3: the [k][j][i] copy of a grid starts ncell elements after its [i][j][k] form
     const double *nhi;          // nHI, [i][j][k] then [k][j][i]

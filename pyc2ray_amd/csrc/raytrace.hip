@@ -177,7 +177,7 @@ __device__ __forceinline__ int wrap_once(int x, int N)
 // entry k*RT_THREADS + lane is what `lane` does in step k and the tables can be prefetched blindly.
 //   cellA[e] = { abc, own slot | VALID | LAST_OF_SHELL, path (double, 2 words) }
 //   cellB[e] = { slots of the four upstream corners in the previous shell's buffer }
-// Dynamic LDS: [log table: 128 x {1/c, log2 c}][1/s: TABCAP doubles][wrapped i(a), j(b), k(c): 3*TABCAP ints]
+// Dynamic LDS: [log table: 128 x {1/c, log2 c}][1/s: TABCAP doubles][wrapped i(a), j(b), k(c), mirrored: 4*TABCAP ints]
 //              [shell buffer 0: max_cells+1 doubles][shell buffer 1: same]   (the last two unless GLOBAL_SCRATCH)
 // TABCAP = 256 (S <= 255) or 1024.
 // Slot max_cells of each shell buffer holds 0.0: upstream corners of weight 0 point there.
@@ -202,7 +202,8 @@ __device__ __forceinline__ int wrap_once(int x, int N)
 #define ASORA_MIN_WAVES 1
 #endif
 
-constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_RATE = 1u << 29, CELL_SLOT_MASK = (1u << 29) - 1;
+constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_RATE = 1u << 29, CELL_NEG = 1u << 28,
+                   CELL_SLOT_MASK = (1u << 28) - 1;   // NEG: the cell lies on the mirrored side of the unit's merge axis
 
 template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP, bool HEAT, int TABCAP>
 __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_kernel(const RtParams p)
@@ -212,22 +213,23 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
     const int blk = blockIdx.x;
     // blocks b and b+8 share an XCD (round-robin dispatch): keep the 8 octants of one source
     // on one XCD so that they share its L2 lines of nHI.  Speed only, never correctness.
-    // p.units = 8 (one workgroup per octant) or 24 (per octant and sector); unit = sector*8 + octant
+    // p.units workgroups per source (8, 24 or 12: see ensure_geometry)
     const int src_local = (blk & 7) + 8 * (blk / (8 * p.units));
     const int unit = (blk >> 3) % p.units;
-    const int oct = unit & 7;
     if (src_local >= p.src_count) return;
     const int ns = p.src_begin + src_local;
 
     const uint4 *__restrict__ cellA = p.geom[unit].cellA;
     const uint4 *__restrict__ cellB = p.geom[unit].cellB;
     const int nsteps = p.geom[unit].nsteps;
+    const int uinfo = p.geom[unit].info;           // sign bits of the unit | (merge axis + 1) << 3 | rates-source << 5
+    const int merge_axis = ((uinfo >> 3) & 3) - 1;
     const int N = p.N;
     const int i0 = p.src_pos[3 * ns + 0];
     const int j0 = p.src_pos[3 * ns + 1];
     const int k0 = p.src_pos[3 * ns + 2];
     const double flux = p.src_flux[ns];
-    const int sa = (oct & 1) ? -1 : 1, sb = (oct & 2) ? -1 : 1, sc = (oct & 4) ? -1 : 1;
+    const int sa = (uinfo & 1) ? -1 : 1, sb = (uinfo & 2) ? -1 : 1, sc = (uinfo & 4) ? -1 : 1;
 
     // LDS: the small tables sit first, at compile-time offsets (TABCAP entries each), then the shell buffers
     double2 *logtab = reinterpret_cast<double2 *>(lds_raw);
@@ -235,7 +237,8 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
     int *wi = reinterpret_cast<int *>(inv_s + TABCAP);
     int *wj = wi + TABCAP;
     int *wk = wj + TABCAP;
-    double *shells = reinterpret_cast<double *>(wk + TABCAP);
+    int *wm = wk + TABCAP;                         // mirrored side of the merge axis
+    double *shells = reinterpret_cast<double *>(wm + TABCAP);
     const int slots = (p.max_cells + 2) & ~1;      // cells + the zero slot, even (keeps 16-B alignment)
     double *prev, *cur;
     if (GLOBAL_SCRATCH) {
@@ -252,6 +255,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
         wi[t] = wrap_once(i0 + sa * t, N);      // periodic position of offset t along each axis
         wj[t] = wrap_once(j0 + sb * t, N);      // (|offset| <= N/2: one wrap suffices, raytracing.cu:270-272)
         wk[t] = wrap_once(k0 + sc * t, N);
+        wm[t] = merge_axis == 0 ? wrap_once(i0 - t, N) : wrap_once(k0 - t, N);
     }
     if (threadIdx.x == 0) { prev[p.max_cells] = 0.0; cur[p.max_cells] = 0.0; }
     __syncthreads();
@@ -271,7 +275,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
         const double cd_out = 0.0 + nHI * path;
         prev[0] = cd_out;
         ++n_eval;
-        if (unit == (p.units == 24 ? 16 : 0)) {       // the source cell is rated once: octant 0 (z-sector)
+        if (uinfo & 32) {                             // the source cell is rated by exactly one unit
             if (DUMP) p.dump[idx] = cd_out;
             const double phi = photo_rate_per_atom(flux, 0.0, cd_out, dr * dr * dr * nHI, p, logtab);
             unsafeAtomicAdd(&p.phi[idx], phi);
@@ -288,8 +292,11 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
     // of step k are issued in step k and consumed (and the atomic issued) in step k+1, so their
     // latency is covered by the next interpolation and never holds up the shell barrier.
     // (The tables carry two all-invalid steps of padding at the end: prefetches stay in bounds.)
-    auto nhi_address = [&](unsigned abc, unsigned &idx) -> const double * {
-        const unsigned i = wi[abc & 1023], j = wj[(abc >> 10) & 1023], k = wk[(abc >> 20) & 1023];
+    auto nhi_address = [&](unsigned abc, unsigned flags, unsigned &idx) -> const double * {
+        const bool neg = (flags & CELL_NEG) != 0;
+        const unsigned i = (neg && merge_axis == 0) ? wm[abc & 1023] : wi[abc & 1023];
+        const unsigned j = wj[(abc >> 10) & 1023];
+        const unsigned k = (neg && merge_axis == 2) ? wm[(abc >> 20) & 1023] : wk[(abc >> 20) & 1023];
         const bool zt = ztr && (abc >> 30) == 2;
         // the [k][j][i] copies follow the [i][j][k] grids in memory: one 32-bit index covers both
         idx = zt ? (k * N + j) * N + i + p.ncell : (i * N + j) * N + k;
@@ -313,7 +320,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
                     const uint4 &nxt_A, double &nxt_nhi, unsigned &nxt_idx, uint4 &pf_A, uint4 &pf_B) {
         pf_A = cellA[e_pf];                                         // two steps ahead
         pf_B = cellB[e_pf];
-        nxt_nhi = *nhi_address(nxt_A.x, nxt_idx);                   // one step ahead
+        nxt_nhi = *nhi_address(nxt_A.x, nxt_A.y, nxt_idx);          // one step ahead
 
         const bool valid = (cur_A.y & CELL_VALID) != 0;
         // waves whose 64 entries are all padding skip the arithmetic (wave-uniform branch)
@@ -365,7 +372,13 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
         const unsigned zmask = (a == 0 ? 1u : 0u) | (b == 0 ? 2u : 0u) | (c == 0 ? 4u : 0u);
         const double maxcd = p.fortran_consts ? (double)2e30f : 2e30;                    // raytracing.cu:15
         const bool owner = valid && (cur_A.y & CELL_RATE) && (zmask & negmask) == 0;
-        if (DUMP) { if (owner) p.dump[(wi[a] * N + wj[b]) * N + wk[c]] = cd_out; }
+        if (DUMP) {
+            if (owner) {
+                const bool neg = (cur_A.y & CELL_NEG) != 0;
+                const unsigned di = (neg && merge_axis == 0) ? wm[a] : wi[a], dk = (neg && merge_axis == 2) ? wm[c] : wk[c];
+                p.dump[(di * N + wj[b]) * N + dk] = cd_out;
+            }
+        }
         rated = owner && cd_in <= maxcd && !ASORA_ABLATED(2);
         n_gamma += (owner && cd_in <= maxcd) ? 1u : 0u;
         const double n2 = (double)(a * a + b * b + c * c);
@@ -419,7 +432,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
     uint4 A1 = cellA[e + RT_THREADS], B1 = cellB[e + RT_THREADS];
     uint4 A2, B2;
     unsigned idx0, idx1 = 0, idx2 = 0;
-    double nhi0 = *nhi_address(A0.x, idx0), nhi1 = 0.0, nhi2 = 0.0;
+    double nhi0 = *nhi_address(A0.x, A0.y, idx0), nhi1 = 0.0, nhi2 = 0.0;
 
     // nsteps is a multiple of 3 (the tables are padded to it) and is followed by two more
     // all-invalid steps, so every look-ahead stays inside the tables.
@@ -482,34 +495,55 @@ inline bool inside_radius_reference(int a, int b, int c, double dr, double R2)
     return d2 / den <= R2;
 }
 
-// `unit` selects which dependency-closed part of the octant the table covers:
-//   -1 : the whole octant (one workgroup per octant);
-//    2 : the z-sector = all dk = s cells (closed: their corners are dk = s-1 cells);
-//    1 : the y-sector = the dj = s cells plus the plane {dj = dk} of the z-sector they read
-//        (that plane only reads itself);
-//    0 : the x-sector = the di = s cells plus the planes {di = dk} (z-sector) and {di = dj} (y-sector)
-//        they read (each of which only reads itself and the main diagonal, which is in {di = dk}).
+// A unit is a dependency-closed set of cells that one workgroup sweeps:
+//   face = -1 : a whole octant;
+//   face =  2 : the z-sector = all dk = s cells (closed: their corners are dk = s-1 cells);
+//   face =  1 : the y-sector = the dj = s cells plus the plane {|dj| = |dk|} of the z-sector they read
+//               (that plane only reads itself);
+//   face =  0 : the x-sector = the di = s cells plus the planes {|di| = |dk|} (z-sector) and {|di| = |dj|}
+//               (y-sector) they read (each of which only reads itself and the main diagonal, which is in
+//               {|di| = |dk|}).
+//   merge_axis = 0 or 2 : the unit covers BOTH signs of that axis (two mirrored sectors in one workgroup, the
+//               plane between them evaluated once), so that its rows along that axis -- the memory-contiguous
+//               one for the unit's faces -- are full chords of the sphere: fewer 64-B atomic requests per cell.
 // A cell is RATED by its home unit only (its own face's sector); the copies a sector keeps of another
 // sector's plane are evaluated for their column density but not rated.
-void build_octant_geometry(HostGeom &h, int Ea, int Eb, int Ec, double R, double dr, int q_max, uint32_t zero_slot_marker,
-                           int RT_THREADS, int unit)
+struct UnitSpec {
+    int face = -1;
+    int merge_axis = -1;
+    int ext[3] = {0, 0, 0};   // periodic-window extent of each axis on the side this unit looks at
+    int ext_neg = 0;          // extent on the mirrored side of merge_axis
+};
+
+void build_unit_geometry(HostGeom &h, const UnitSpec &us, double R, double dr, int q_max, uint32_t zero_slot_marker,
+                         int RT_THREADS)
 {
     const double R2 = R * R;
     const double R2hi = R2 * (1.0 + 1e-9) + 1e-9;
-    const int Emax = std::max(Ea, std::max(Eb, Ec));
+    int Emax = std::max(us.ext[0], std::max(us.ext[1], us.ext[2]));
+    if (us.merge_axis >= 0) Emax = std::max(Emax, us.ext_neg);
     int S = Emax;
     if (std::isfinite(R2hi)) S = (int)std::min((double)Emax, std::floor(std::sqrt(R2hi)));
     h.S = S;
-    // slot maps of the previous / current shell: face*(P*P) + u*P + v with P = S+1
-    const size_t P = (size_t)S + 1;
-    std::vector<uint32_t> slot_prev(3 * P * P, zero_slot_marker), slot_cur(3 * P * P, zero_slot_marker);
-    slot_prev[0] = 0;             // (0,0,0) sits in slot 0 (z-face entry a=0,b=0 of shell 0)
-    auto slot_of = [&](const std::vector<uint32_t> &m, int a, int b, int c, int t) -> uint32_t {
-        // cell (a,b,c) of shell t = max(a,b,c)
-        if (c == t) return m[0 * P * P + (size_t)b * P + a];
-        if (b == t) return m[1 * P * P + (size_t)a * P + c];
-        return m[2 * P * P + (size_t)b * P + c];
+    static const int DOM[3] = {0, 1, 2};                 // dominant axis of face 0 (x), 1 (y), 2 (z)
+    static const int TE[3] = {1, 0, 0}, TF[3] = {2, 2, 1};   // transverse axes (e,f): x:(y,z) y:(x,z) z:(x,y)
+    // slot maps of the previous / current shell, keyed by face, sign of the dominant offset and the signed
+    // transverse offsets
+    const size_t P2 = 2 * (size_t)S + 1;
+    const size_t map_size = 3 * 2 * P2 * P2;
+    std::vector<uint32_t> slot_prev(map_size, zero_slot_marker), slot_cur(map_size, zero_slot_marker);
+    auto key_of = [&](const int x[3]) -> size_t {
+        // face by magnitudes, ties z, then y (raytracing.cu:394,446,491)
+        const int aa = std::abs(x[0]), bb = std::abs(x[1]), cc = std::abs(x[2]);
+        const int t = std::max(aa, std::max(bb, cc));
+        const int face = (cc == t) ? 2 : (bb == t) ? 1 : 0;
+        const int d = DOM[face], e = TE[face], f = TF[face];
+        const size_t neg = x[d] < 0 ? 1 : 0;
+        return ((size_t)(face * 2) + neg) * P2 * P2 + (size_t)(x[e] + S) * P2 + (size_t)(x[f] + S);
     };
+    {   const int origin[3] = {0, 0, 0};
+        slot_prev[key_of(origin)] = 0;       // the source cell sits in slot 0 of shell 0
+    }
     auto in_sphere = [&](int a, int b, int c) -> bool {
         if (a + b + c > q_max) return false;                                   // raytracing.cu:101,198
         const double n2 = (double)a * a + (double)b * b + (double)c * c;
@@ -523,26 +557,27 @@ void build_octant_geometry(HostGeom &h, int Ea, int Eb, int Ec, double R, double
     for (int s = 1; s <= S; ++s) {
         std::fill(slot_cur.begin(), slot_cur.end(), zero_slot_marker);
         const double sd = (double)s;
-        const size_t first = h.cellA.size();
         uint32_t count = 0;
-        auto emit = [&](int a, int b, int c, int face, int U, int V) {
+        auto emit = [&](const int x[3], int face) {
+            const int a = std::abs(x[0]), b = std::abs(x[1]), c = std::abs(x[2]);
             if (!in_sphere(a, b, c)) return;
             bool rate = true;
-            if (unit >= 0 && face != unit) {
+            if (us.face >= 0 && face != us.face) {
                 // a foreign cell: kept only if this sector reads it
-                const bool keep = (unit == 1) ? (face == 2 && b == c)
-                                              : (unit == 0) ? ((face == 2 && a == c) || (face == 1 && a == b)) : false;
+                const bool keep = (us.face == 1) ? (face == 2 && b == c)
+                                                 : (us.face == 0) ? ((face == 2 && a == c) || (face == 1 && a == b)) : false;
                 if (!keep) return;
                 rate = false;
             }
+            const int d = DOM[face], e = TE[face], f = TF[face];
+            const int U = std::abs(x[e]), V = std::abs(x[f]);
+            const int sgd = x[d] < 0 ? -1 : 1, sge = x[e] < 0 ? -1 : 1, sgf = x[f] < 0 ? -1 : 1;
             const double u = (double)U, v = (double)V;
             const bool em = U >= 1, e0 = U <= s - 1, fm = V >= 1, f0 = V <= s - 1;
             auto corner = [&](int uu, int vv) -> uint32_t {
-                int aa, bb, cc;
-                if (face == 2) { aa = uu; bb = vv; cc = s - 1; }
-                else if (face == 1) { aa = uu; bb = s - 1; cc = vv; }
-                else { aa = s - 1; bb = uu; cc = vv; }
-                return slot_of(slot_prev, aa, bb, cc, s - 1);
+                int n[3];
+                n[d] = sgd * (s - 1); n[e] = sge * uu; n[f] = sgf * vv;
+                return slot_prev[key_of(n)];
             };
             uint4 nb;
             nb.x = (em && fm) ? corner(U - 1, V - 1) : zero_slot_marker;
@@ -558,31 +593,44 @@ void build_octant_geometry(HostGeom &h, int Ea, int Eb, int Ec, double R, double
             const double path = std::sqrt((u * u + v * v) / (sd * sd) + 1.0);  // raytracing.cu:444
             uint64_t pbits;
             std::memcpy(&pbits, &path, sizeof pbits);
+            const bool neg = us.merge_axis >= 0 && x[us.merge_axis] < 0;
             uint4 ca;
             ca.x = (uint32_t)a | ((uint32_t)b << 10) | ((uint32_t)c << 20) | ((uint32_t)face << 30);
-            ca.y = count | CELL_VALID | (rate ? CELL_RATE : 0u);
+            ca.y = count | CELL_VALID | (rate ? CELL_RATE : 0u) | (neg ? CELL_NEG : 0u);
             ca.z = (uint32_t)(pbits & 0xffffffffu);
             ca.w = (uint32_t)(pbits >> 32);
             h.cellA.push_back(ca);
             h.cellB.push_back(nb);
-            size_t key = face == 2 ? (0 * P * P + (size_t)b * P + a)
-                       : face == 1 ? (1 * P * P + (size_t)a * P + c) : (2 * P * P + (size_t)b * P + c);
-            slot_cur[key] = count++;
+            slot_cur[key_of(x)] = count++;
         };
-        if (s <= Ec)
-            for (int b = 0; b <= std::min(s, Eb); ++b)
-                for (int a = 0; a <= std::min(s, Ea); ++a) emit(a, b, s, 2, a, b);
-        if (s <= Eb)
-            for (int a = 0; a <= std::min(s, Ea); ++a)
-                for (int c = 0; c <= std::min(s - 1, Ec); ++c) emit(a, s, c, 1, a, c);
-        if (s <= Ea)
-            for (int b = 0; b <= std::min(s - 1, Eb); ++b)
-                for (int c = 0; c <= std::min(s - 1, Ec); ++c) emit(s, b, c, 0, b, c);
+        // signed range of a transverse axis whose magnitude may reach `maxmag`
+        auto lo_of = [&](int axis, int maxmag) { return us.merge_axis == axis ? -std::min(maxmag, us.ext_neg) : 0; };
+        auto hi_of = [&](int axis, int maxmag) { return std::min(maxmag, us.ext[axis]); };
+        for (int face = 2; face >= 0; --face) {
+            if (us.face == 2 && face != 2) continue;          // the z-sector holds z-face cells only
+            if (us.face == 1 && face == 0) continue;          // the y-sector never needs x-face cells
+            const int d = DOM[face];
+            // the memory-contiguous transverse axis runs fastest: a (axis 0) on the z-face, c (axis 2) otherwise
+            const int fast = face == 2 ? 0 : 2;
+            const int slow = face == 2 ? 1 : (face == 1 ? 0 : 1);
+            const int max_fast = (face == 2) ? s : s - 1;                     // y/x-face: |dk| < s
+            const int max_slow = (face == 0) ? s - 1 : s;                     // x-face: |dj| < s
+            for (int dsgn = 1; dsgn >= -1; dsgn -= 2) {
+                if (dsgn < 0 && us.merge_axis != d) break;
+                const int ext_d = dsgn > 0 ? us.ext[d] : us.ext_neg;
+                if (s > ext_d) continue;
+                for (int sl = lo_of(slow, max_slow); sl <= hi_of(slow, max_slow); ++sl)
+                    for (int fa = lo_of(fast, max_fast); fa <= hi_of(fast, max_fast); ++fa) {
+                        int x[3];
+                        x[d] = dsgn * s; x[slow] = sl; x[fast] = fa;
+                        emit(x, face);
+                    }
+            }
+        }
         if (count == 0) break;                        // nothing further out either
         // pad the shell to whole steps and flag every entry of its last step
         while (h.cellA.size() % RT_THREADS) { h.cellA.push_back(pad_a); h.cellB.push_back(pad_b); }
         for (size_t q = h.cellA.size() - RT_THREADS; q < h.cellA.size(); ++q) h.cellA[q].y |= CELL_LAST;
-        (void)first;
         h.max_cells = std::max(h.max_cells, count);
         slot_prev.swap(slot_cur);
     }
@@ -633,20 +681,44 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
     }
     release_geometry(st);
 
-    // unit = sector*8 + octant (sector = face code 0:x 1:y 2:z; one unit per octant when units == 8).
-    // Units with the same sector and the same periodic window share one table; when the sphere does
-    // not reach the window on any axis all octants are identical.
+    // Units of a source:
+    //    8: unit = octant                              (bit ax of the octant index = negative side of axis ax)
+    //   24: unit = sector*8 + octant                   (sector = face code 0:x 1:y 2:z)
+    //   12: unit = sector*4 + q, two mirrored sectors  (z-sector mirrored in x: q = sign bits of (y,z);
+    //                                                   y- and x-sector mirrored in z: q = sign bits of (x,y))
+    // Units with the same sector and the same periodic window share one table; when the sphere does not reach
+    // the window on any axis all of a sector's units are identical.
     const double R2hi_all = p.R * p.R * (1.0 + 1e-9) + 1e-9;
     const bool unclipped = std::isfinite(R2hi_all) && std::floor(std::sqrt(R2hi_all)) <= (double)std::min(ext_pos, ext_neg);
-    auto ext = [&](int oct, int ax) { return ((oct >> ax) & 1) ? ext_neg : ext_pos; };
+    UnitSpec spec[24];
+    int info[24];
+    for (int u = 0; u < units; ++u) {
+        int neg[3] = {0, 0, 0};
+        UnitSpec &us = spec[u];
+        if (units == 12) {
+            us.face = u >> 2;
+            us.merge_axis = us.face == 2 ? 0 : 2;
+            const int q = u & 3;
+            if (us.face == 2) { neg[1] = q & 1; neg[2] = (q >> 1) & 1; }
+            else              { neg[0] = q & 1; neg[1] = (q >> 1) & 1; }
+        } else {
+            us.face = units == 24 ? (u >> 3) : -1;
+            us.merge_axis = -1;
+            for (int ax = 0; ax < 3; ++ax) neg[ax] = ((u & 7) >> ax) & 1;
+        }
+        for (int ax = 0; ax < 3; ++ax) us.ext[ax] = neg[ax] ? ext_neg : ext_pos;
+        us.ext_neg = ext_neg;
+        // exactly one unit rates the source cell: the all-positive one (of the z-sector when there are sectors)
+        const bool rates_source = !neg[0] && !neg[1] && !neg[2] && (us.face == -1 || us.face == 2);
+        info[u] = neg[0] | (neg[1] << 1) | (neg[2] << 2) | ((us.merge_axis + 1) << 3) | (rates_source ? 32 : 0);
+    }
     int owner[24];
     for (int u = 0; u < units; ++u) {
         owner[u] = u;
-        const int oct = u & 7;
         for (int u2 = 0; u2 < u; ++u2) {
-            const int o2 = u2 & 7;
-            if ((u2 >> 3) != (u >> 3)) continue;
-            if (unclipped || (ext(oct, 0) == ext(o2, 0) && ext(oct, 1) == ext(o2, 1) && ext(oct, 2) == ext(o2, 2))) {
+            if (spec[u2].face != spec[u].face || spec[u2].merge_axis != spec[u].merge_axis) continue;
+            if (unclipped || (spec[u].ext[0] == spec[u2].ext[0] && spec[u].ext[1] == spec[u2].ext[1] &&
+                              spec[u].ext[2] == spec[u2].ext[2])) {
                 owner[u] = owner[u2];
                 break;
             }
@@ -660,10 +732,9 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
     bool dr_matters = false;
     for (int u = 0; u < units; ++u) {
         if (owner[u] != u) continue;
-        const int oct = u & 7, sector = units == 24 ? (u >> 3) : -1;
-        build_octant_geometry(hg[u], ext(oct, 0), ext(oct, 1), ext(oct, 2), p.R, p.dr, q_max, MARK, threads, sector);
+        build_unit_geometry(hg[u], spec[u], p.R, p.dr, q_max, MARK, threads);
         if (hg[u].inconsistent)
-            return fail(11, "raytrace geometry: a cell of a sector reads a corner outside the sector (internal error)");
+            return fail(11, "raytrace geometry: a cell of a unit reads a corner outside the unit (internal error)");
         Smax = std::max(Smax, hg[u].S);
         max_cells = std::max(max_cells, hg[u].max_cells);
         dr_matters = dr_matters || hg[u].on_sphere;
@@ -680,12 +751,12 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
         }
         OctGeomDev d;
         d.nsteps = h.nsteps;
-        d.pad_ = 0;
+        d.info = 0;
         if (int rc = upload(h.cellA, d.cellA, st.geom_owned)) return rc;
         if (int rc = upload(h.cellB, d.cellB, st.geom_owned)) return rc;
         od[u] = d;
     }
-    for (int u = 0; u < units; ++u) od[u] = od[owner[u]];
+    for (int u = 0; u < units; ++u) { od[u] = od[owner[u]]; od[u].info = info[u]; }
 
     // log2 table: interval centres c = 1 + (i + 1/2)/128, entries {1/c, log2 c}
     std::vector<double2> lt(LOG_TABLE_SIZE);
@@ -810,27 +881,30 @@ int launch_transpose(State &st, const double *src, double *dst, int N)
 static const size_t LDS_LIMIT_BYTES = 160 * 1024;
 
 // Decomposition and workgroup size.  Shells of a small trace do not fill 256 lanes (R=16: <= 310 cells per
-// octant shell); shells of a large one need so much LDS that only two octant workgroups fit a CU (R=64: 77 KB),
-// where splitting each octant into its three sectors restores the wave count.  Thresholds from sweeps on
-// MI355X (1000 sources, 256^3; tools/sweep_threads.sh):
-//   R <= 20: octants x 64 threads | 24..28: octants x 128 | 32..44: octants x 256 | >= 48: sectors x 256
+// octant shell); a large one needs so much LDS per octant that few workgroups fit a CU.  From about R = 28 on,
+// one workgroup per pair of mirrored sectors wins: its rows are full chords of the sphere, which lowers the
+// number of 64-B atomic requests per rated cell (the binding resource) by ~15 %.
+// Thresholds from sweeps on MI355X (1000 sources, 256^3; tools/sweep_threads.sh):
+//   R <= 22: octants x 64 threads | ..27: octants x 128 | 28..35: sector pairs x 128 | 36..54: x 256 | >= 55: x 512
 static void pick_launch_shape(const State &st, double R, int N, bool dump, int &units, int &threads)
 {
     const double r = std::min(R, 0.87 * N);                 // the window cuts the trace at ~sqrt(3)/2 N
     const double est_cells = 1.2 * r * r;                   // largest shell of an octant
     if (est_cells <= 580.0) { units = 8; threads = 64; }
-    else if (est_cells <= 1080.0) { units = 8; threads = 128; }
-    else if (est_cells <= 2700.0) { units = 8; threads = 256; }
-    else { units = 24; threads = 256; }
+    else if (est_cells <= 900.0) { units = 8; threads = 128; }
+    else if (est_cells <= 1500.0) { units = 12; threads = 128; }
+    else if (est_cells <= 3500.0) { units = 12; threads = 256; }
+    else { units = 12; threads = 512; }
     const int want_sectors = st.opt[ASORA_OPT_SECTORS];
     if (want_sectors == 1) units = 8;
     if (want_sectors == 2) units = 24;
+    if (want_sectors == 3) units = 12;
     const int forced = st.opt[ASORA_OPT_BLOCK_THREADS];
     if (forced == 64 || forced == 128 || forced == 256 || forced == 512) threads = forced;
     if (dump) threads = 256;                                // the column-density dump variant is built for 256 only
 }
 
-constexpr size_t lds_table_bytes(int tabcap) { return LOG_TABLE_SIZE * sizeof(double2) + (size_t)tabcap * (sizeof(double) + 3 * sizeof(int)); }
+constexpr size_t lds_table_bytes(int tabcap) { return LOG_TABLE_SIZE * sizeof(double2) + (size_t)tabcap * (sizeof(double) + 4 * sizeof(int)); }
 
 template <int T, int TABCAP>
 static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t lds_bytes, bool use_lds, bool dump, bool heat)

@@ -155,7 +155,7 @@ def test_decomposition_and_workgroup_size_do_not_change_results(asora, name, thr
     out = {}
     try:
         lib.set_option(capi.OPT_BLOCK_THREADS, threads)
-        for mode in (1, 2):
+        for mode in (1, 2, 3):
             lib.set_option(capi.OPT_SECTORS, mode)
             phi = _asora_call(lib, c, N, numtau)
             np.testing.assert_allclose(phi, ref, rtol=GAMMA_RTOL, atol=0)
@@ -164,8 +164,9 @@ def test_decomposition_and_workgroup_size_do_not_change_results(asora, name, thr
         lib.set_option(capi.OPT_SECTORS, 0)
         lib.set_option(capi.OPT_BLOCK_THREADS, 0)
     np.testing.assert_allclose(out[1][0], out[2][0], rtol=1e-12, atol=0)
-    assert out[1][1][0] == out[2][1][0]               # rated pairs
-    assert out[2][1][1] >= out[1][1][1]               # evaluations
+    np.testing.assert_allclose(out[1][0], out[3][0], rtol=1e-12, atol=0)
+    assert out[1][1][0] == out[2][1][0] == out[3][1][0]    # rated pairs
+    assert out[2][1][1] >= out[1][1][1]               # evaluations (re-derived planes)
 
 
 def test_grey_notables_option(asora):
@@ -201,7 +202,7 @@ def test_large_radius_and_window_clipping(asora, N, R):
     np.testing.assert_allclose(phi, ref, rtol=GAMMA_RTOL, atol=0)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_large_shells_global_scratch_and_large_lds(asora, mode):
     """N=168 full box.  One workgroup per octant (mode 1): shell buffers 2*21.8k*8 B = 349 KB > 160 KB of LDS
     -> the global-scratch variant.  One per (octant, sector) (mode 2, what the library picks at this size):
