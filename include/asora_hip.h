@@ -77,6 +77,35 @@ int c2ray_global_pass(double dt, const double *ndens, const double *temp, const 
                       double bh00, double albpow, double colh0, double temph0, double abu_c,
                       int m1, int m2, int m3, int *conv_flag);
 
+/* libc2ray.raytracing.do_all_sources(normflux, srcpos, max_subbox, subboxsize, coldensh_out, sig, dr, ndens,
+ *        xh_av, phi_ion, phi_heat, loss_fraction, photo_thin_table, photo_thick_table, heat_thin_table,
+ *        heat_thick_table, minlogtau, dlogtau, R_max_LLS) -> (sum_nbox, photon_loss)
+ * f2py wrapper of src/c2ray/raytracing.f90:52-119 (built with -DUSE_SUBBOX, src/c2ray/Makefile:3): the
+ * reference's CPU raytracer.  Same semantics, evaluated on the GPU: per source a cube of half-width
+ * min(max_subbox, N/2) is traced in sub-boxes of `subboxsize` cells until the photons crossing the box faces
+ * fall to loss_fraction of the source's output (do_source, f90:193-221); rates are deposited only within
+ * R_max_LLS (cells) and below the column-density cap; Fortran-flavoured constants.
+ *   srcpos        (3,NumSrc) column-major, 1-based                       (f90:64)
+ *   grids         Fortran order (m1,m2,m3), m1 == m2 == m3               (f90:65-70)
+ *   coldensh_out  out: outgoing column density of the cells the LAST source reached, 0 elsewhere (f90:181)
+ *   phi_ion       out (zeroed first, f90:95);  phi_heat  in/out (accumulated onto)
+ *   xh_av, ndens  in
+ *   sum_nbox, photon_loss  out: sub-boxes used by all sources / photons lost through their last boxes
+ * Every cell's rate uses the flux of the LAST source, as the reference does (f90:500,503); set
+ * ASORA_OPT_C2RAY_OWN_FLUX = 1 for each source's own flux.  Cells on a box face that deposit nothing
+ * (beyond R_max_LLS or above the cap) contribute 0 to the loss (the reference adds an undefined value there).
+ * Needs no prior asora_device_init: it initialises the library for m1 itself (and again when a later call
+ * comes with another m1); a library initialised by asora_device_init for another mesh size makes it fail.
+ * Overwrites the device grids NDENS, XH_AV, PHI_ION, PHI_HEAT. */
+int c2ray_do_all_sources(const double *normflux, const int32_t *srcpos, int max_subbox, int subboxsize,
+                         double *coldensh_out, double sig, double dr, const double *ndens, const double *xh_av,
+                         double *phi_ion, double *phi_heat, float loss_fraction,
+                         const double *photo_thin_table, const double *photo_thick_table,
+                         const double *heat_thin_table, const double *heat_thick_table,
+                         double minlogtau, double dlogtau, double R_max_LLS,
+                         int NumTau, int NumSrc, int m1, int m2, int m3,
+                         int *sum_nbox, double *photon_loss);
+
 /* Message of the last failing call in this thread's process ("" if none). */
 const char *asora_last_error(void);
 
@@ -146,7 +175,10 @@ enum {
     /* 1: the raytrace also accumulates the photo-heating rate into ASORA_GRID_PHI_HEAT
      *    (src/c2ray/photorates.f90:118,124; src/c2ray/raytracing.f90:532,537); needs heat tables. */
     ASORA_OPT_HEATING = 6,
-    ASORA_OPT_COUNT = 7
+    /* c2ray_do_all_sources only.  0 (default): every source's rates use the flux of the LAST source, as the
+     *    reference does (src/c2ray/raytracing.f90:500,503 pass normflux(NumSrc));  1: each source its own flux. */
+    ASORA_OPT_C2RAY_OWN_FLUX = 7,
+    ASORA_OPT_COUNT = 8
 };
 int asora_set_option(int option, int value);
 int asora_get_option(int option);

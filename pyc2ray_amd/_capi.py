@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libasora_hip.so")
 # grid selectors / options / kernels, as in include/asora_hip.h
 GRID_NDENS, GRID_XH_AV, GRID_PHI_ION, GRID_TEMP, GRID_XH, GRID_XH_INTERMED, GRID_PHI_HEAT = range(7)
 (OPT_FORTRAN_CONSTANTS, OPT_GREY_NOTABLES, OPT_TIMING, OPT_Z_TRANSPOSED, OPT_BLOCK_THREADS, OPT_SECTORS,
- OPT_HEATING) = range(7)
+ OPT_HEATING, OPT_C2RAY_OWN_FLUX) = range(8)
 KERNEL_RAYTRACE, KERNEL_CHEMISTRY, KERNEL_PREP, KERNEL_FINISH = range(4)
 
 _dp = C.POINTER(C.c_double)
@@ -31,6 +31,9 @@ SIGNATURES = {
                                        C.c_double, C.c_double, C.c_int]),
     "c2ray_global_pass": (C.c_int, [C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double,
                                     C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "c2ray_do_all_sources": (C.c_int, [_dp, _ip, C.c_int, C.c_int, _dp, C.c_double, C.c_double, _dp, _dp, _dp, _dp,
+                                       C.c_float, _dp, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), _dp]),
     "asora_last_error": (C.c_char_p, []),
     "asora_grid_to_device": (C.c_int, [C.c_int, _dp, C.c_int, C.c_char]),
     "asora_grid_to_host": (C.c_int, [C.c_int, _dp, C.c_int, C.c_char]),

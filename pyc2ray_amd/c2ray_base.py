@@ -102,7 +102,8 @@ class C2Ray:
 
         paramfile : YAML parameter file (same keys as the reference's parameters.yml files)
         Nmesh     : mesh size
-        use_gpu   : must be True in this build (the reference's Fortran CPU raytracer is not shipped)
+        use_gpu   : True = ASORA path, device-resident; False = the semantics of the reference's CPU raytracer
+                    (sub-boxes, photon loss), evaluated on the GPU through the libc2ray-compatible entry points
         use_mpi   : None/False, mpi4py's MPI module, or pyc2ray_amd.dist.MPI
         """
         if use_mpi:

@@ -176,6 +176,21 @@ static int do_raytrace(double R, double sig, double dr, int src_begin, int src_c
 
 } // namespace asora
 
+namespace {
+struct DeviceBuffers {      // frees what the call allocated, on every exit path
+    std::vector<void *> ptrs;
+    ~DeviceBuffers() { for (void *q : ptrs) (void)hipFree(q); }
+    template <typename T> int alloc(T *&out, size_t count)
+    {
+        void *d = nullptr;
+        ASORA_HIP_TRY(hipMalloc(&d, std::max<size_t>(count, 1) * sizeof(T)));
+        ptrs.push_back(d);
+        out = static_cast<T *>(d);
+        return 0;
+    }
+};
+}
+
 using namespace asora;
 
 extern "C" {
@@ -194,6 +209,7 @@ int asora_device_init_ex(int N, int num_src_par, int device_id)
     st.N = N;
     st.ncell = (size_t)N * N * N;
     st.num_src_par = num_src_par;
+    st.auto_init = false;
     const size_t bytes = st.ncell * sizeof(double);
     // the rate grids and nHI carry their [k][j][i] twin directly behind them (one 32-bit index reaches both)
     for (int g = 0; g < ASORA_GRID_COUNT; ++g) {
@@ -457,6 +473,178 @@ int c2ray_global_pass(double dt, const double *ndens, const double *temp, const 
     if (!rc && conv_flag) *conv_flag = (int)st.red_host[2];
     cleanup();
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// libc2ray.raytracing.do_all_sources: the host driver of subbox.hip (do_all_sources / do_source,
+// src/c2ray/raytracing.f90:52-249)
+// ---------------------------------------------------------------------------------------------
+int c2ray_do_all_sources(const double *normflux, const int32_t *srcpos, int max_subbox, int subboxsize,
+                         double *coldensh_out, double sig, double dr, const double *ndens, const double *xh_av,
+                         double *phi_ion, double *phi_heat, float loss_fraction,
+                         const double *photo_thin_table, const double *photo_thick_table,
+                         const double *heat_thin_table, const double *heat_thick_table,
+                         double minlogtau, double dlogtau, double R_max_LLS,
+                         int NumTau, int NumSrc, int m1, int m2, int m3,
+                         int *sum_nbox, double *photon_loss)
+{
+    clear_error();
+    State &st = g_state;
+    const char *who = "c2ray_do_all_sources";
+    if (m1 != m2 || m1 != m3) return fail(3, std::string(who) + ": the mesh must be cubic (raytracing.f90:174-175 use m1 for every axis)");
+    if (NumSrc < 0 || (NumSrc > 0 && (!normflux || !srcpos))) return fail(3, std::string(who) + ": bad source arguments");
+    if (!ndens || !xh_av || !phi_ion || !coldensh_out) return fail(3, std::string(who) + ": null grid");
+    if (subboxsize < 1) return fail(3, std::string(who) + ": subboxsize must be >= 1");
+    const bool grey = st.opt[ASORA_OPT_GREY_NOTABLES] != 0;
+    if (!grey && (NumTau < 1 || !photo_thin_table || !photo_thick_table))
+        return fail(3, std::string(who) + ": empty photo-ionisation tables");
+    const bool heat = !grey && phi_heat && heat_thin_table && heat_thick_table;
+    if (!st.init || (st.auto_init && st.N != m1)) {
+        // stateless for the caller, like the f2py function it stands for: the library sets itself up for this mesh
+        if (int rc = asora_device_init(m1, 1)) return rc;
+        st.auto_init = true;
+    } else if (int rc = check_N(who, m1)) return rc;
+    const int N = st.N;
+    for (int s = 0; s < NumSrc; ++s)
+        for (int ax = 0; ax < 3; ++ax)
+            if (srcpos[3 * s + ax] < 1 || srcpos[3 * s + ax] > N)
+                return fail(3, std::string(who) + ": source " + std::to_string(s + 1) + " lies outside the mesh (1-based " +
+                                   std::to_string(srcpos[3 * s + ax]) + " on axis " + std::to_string(ax + 1) + ")");
+
+    DeviceBuffers tmp;
+    const size_t bytes = st.ncell * sizeof(double);
+    // inputs: grids in Fortran order, sources 1-based
+    if (int rc = asora_grid_to_device(ASORA_GRID_NDENS, ndens, N, 'F')) return rc;
+    if (int rc = asora_grid_to_device(ASORA_GRID_XH_AV, xh_av, N, 'F')) return rc;
+    if (heat) { if (int rc = asora_grid_to_device(ASORA_GRID_PHI_HEAT, phi_heat, N, 'F')) return rc; }
+    ASORA_HIP_TRY(hipMemsetAsync(st.grid[ASORA_GRID_PHI_ION], 0, 2 * bytes, st.stream));          // f90:95 (+ its [k][j][i] twin)
+    if (heat) ASORA_HIP_TRY(hipMemsetAsync(st.heat_t, 0, bytes, st.stream));
+    ASORA_HIP_TRY(hipMemsetAsync(st.staging, 0, bytes, st.stream));                               // column densities of the last source
+    if (int rc = launch_prepare_nhi(st, true)) return rc;
+    if (int rc = ensure_logtab(st)) return rc;
+
+    int32_t *d_pos = nullptr; double *d_flux = nullptr; double2 *d_tables = nullptr;
+    if (NumSrc > 0) {
+        std::vector<int32_t> pos0(3 * (size_t)NumSrc);
+        for (size_t q = 0; q < pos0.size(); ++q) pos0[q] = srcpos[q] - 1;
+        if (int rc = tmp.alloc(d_pos, pos0.size())) return rc;
+        if (int rc = tmp.alloc(d_flux, (size_t)NumSrc)) return rc;
+        ASORA_HIP_TRY(hipMemcpy(d_pos, pos0.data(), pos0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        ASORA_HIP_TRY(hipMemcpy(d_flux, normflux, (size_t)NumSrc * sizeof(double), hipMemcpyHostToDevice));
+    }
+    const int len = grey ? 1 : NumTau;
+    {   // [thick | thin | heat thick | heat thin] as pairs {T[i], T[i+1]-T[i]} (see asora_photo_table_to_device)
+        std::vector<double2> pairs(4 * (size_t)len, double2{0.0, 0.0});
+        const double *src[4] = {photo_thick_table, photo_thin_table, heat ? heat_thick_table : nullptr,
+                                heat ? heat_thin_table : nullptr};
+        for (int t = 0; t < 4 && !grey; ++t) {
+            if (!src[t]) continue;
+            for (int i = 0; i < len; ++i) {
+                pairs[(size_t)t * len + i].x = src[t][i];
+                pairs[(size_t)t * len + i].y = (i + 1 < len) ? src[t][i + 1] - src[t][i] : 0.0;
+            }
+        }
+        if (int rc = tmp.alloc(d_tables, pairs.size())) return rc;
+        ASORA_HIP_TRY(hipMemcpy(d_tables, pairs.data(), pairs.size() * sizeof(double2), hipMemcpyHostToDevice));
+    }
+
+    // traversal range per axis side, f90:174-175
+    const int ext_r = std::min(max_subbox, N / 2 - 1 + N % 2);
+    const int ext_l = std::min(max_subbox, N / 2);
+    const int S_all = std::max(ext_r, ext_l);
+    const bool range_open = ext_r > 0 && ext_l > 0;      // else the while loop of do_source never runs (f90:193-195)
+
+    SubboxParams p;
+    std::memset(&p, 0, sizeof p);
+    p.N = N; p.W = std::max(S_all, 0) + 1;
+    p.ext_r = ext_r; p.ext_l = ext_l;
+    p.sig = sig; p.dr = dr; p.R = R_max_LLS;
+    p.numtau_f = (double)(float)NumTau;                                    // photorates.f90:141 real(NumTau)
+    p.lut_k1 = 0.30102999566398119521 / dlogtau;
+    p.lut_k0 = 1.0 - minlogtau / dlogtau;
+    p.table_len = len;
+    p.grey = grey ? 1 : 0; p.heat = heat ? 1 : 0;
+    p.flux_src = st.opt[ASORA_OPT_C2RAY_OWN_FLUX] ? -1 : NumSrc - 1;
+    p.dump_src = NumSrc - 1;
+    p.ncell = (unsigned)st.ncell;
+    p.nhi = st.nhi; p.phi = st.grid[ASORA_GRID_PHI_ION]; p.heat_grid = st.grid[ASORA_GRID_PHI_HEAT];
+    p.dump = st.staging;
+    p.tables = d_tables; p.logtab = st.logtab_dev;
+    p.src_pos = d_pos; p.src_flux = d_flux;
+    p.unit_stride = (size_t)6 * p.W * p.W;
+
+    long long total_nbox = 0;
+    double total_loss = 0.0;
+    // sources in batches bounded by the shell-buffer scratch (8 octants x 2 buffers x 3 W^2 doubles per source)
+    const size_t per_src = 8 * p.unit_stride * sizeof(double);
+    const size_t budget = (size_t)4 << 30;
+    const int max_batch = (int)std::max<size_t>(8, std::min<size_t>((budget / per_src) / 8 * 8, 1 << 20));
+    int *d_active = nullptr, *d_nbox = nullptr, *d_nactive = nullptr;
+    double *d_loss = nullptr, *d_loss_final = nullptr;
+    const int cap = std::min(std::max(NumSrc, 1), max_batch);
+    if (int rc = tmp.alloc(d_active, (size_t)cap)) return rc;
+    if (int rc = tmp.alloc(d_nbox, (size_t)cap)) return rc;
+    if (int rc = tmp.alloc(d_nactive, 1)) return rc;
+    if (int rc = tmp.alloc(d_loss, (size_t)cap)) return rc;
+    if (int rc = tmp.alloc(d_loss_final, (size_t)cap)) return rc;
+    std::vector<int> h_nbox((size_t)cap);
+    std::vector<double> h_loss((size_t)cap);
+
+    for (int done = 0; done < NumSrc;) {
+        const int batch = std::min(NumSrc - done, max_batch);
+        const size_t need = (size_t)8 * ((batch + 7) / 8) * per_src;
+        if (need > st.shell_scratch_bytes) {
+            if (st.shell_scratch) ASORA_HIP_TRY(hipFree(st.shell_scratch));
+            st.shell_scratch = nullptr; st.shell_scratch_bytes = 0;
+            ASORA_HIP_TRY(hipMalloc(&st.shell_scratch, need));
+            st.shell_scratch_bytes = need;
+        }
+        p.scratch = st.shell_scratch;
+        p.src_begin = done; p.src_count = batch;
+        p.active = d_active; p.loss = d_loss;
+        int n_active = 0;
+        if (int rc = launch_subbox_decide(st, 0, batch, d_flux, done, (double)loss_fraction, range_open ? 1 : 0, d_active,
+                                          d_loss, d_loss_final, d_nbox, d_nactive)) return rc;
+        ASORA_HIP_TRY(hipMemcpyAsync(&n_active, d_nactive, sizeof(int), hipMemcpyDeviceToHost, st.stream));
+        ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+        long long box = 0;                                    // half-width of the current sub-box, f90:199-200
+        while (n_active > 0) {
+            const long long prev_box = box;
+            box += subboxsize;
+            p.s_begin = (int)std::min<long long>(prev_box, S_all);
+            p.s_end = (int)std::min<long long>(box, S_all);
+            p.edge_r = (int)std::min<long long>(box, ext_r);
+            p.edge_l = (int)std::min<long long>(box, ext_l);
+            if (int rc = launch_subbox_sweep(st, p)) return rc;
+            const int more_range = (box < ext_r && box < ext_l) ? 1 : 0;          // f90:194-195
+            if (int rc = launch_subbox_decide(st, 1, batch, d_flux, done, (double)loss_fraction, more_range, d_active,
+                                              d_loss, d_loss_final, d_nbox, d_nactive)) return rc;
+            ASORA_HIP_TRY(hipMemcpyAsync(&n_active, d_nactive, sizeof(int), hipMemcpyDeviceToHost, st.stream));
+            ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+        }
+        ASORA_HIP_TRY(hipMemcpy(h_nbox.data(), d_nbox, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost));
+        ASORA_HIP_TRY(hipMemcpy(h_loss.data(), d_loss_final, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost));
+        for (int s = 0; s < batch; ++s) { total_nbox += h_nbox[s]; total_loss += h_loss[s]; }   // f90:246-247, in source order
+        done += batch;
+    }
+
+    // fold the [k][j][i] accumulators, return the grids in Fortran order
+    if (int rc = launch_finish_phi(st)) return rc;
+    st.grid_valid[ASORA_GRID_PHI_ION] = true;
+    if (heat) {
+        if (int rc = launch_fold_transposed(st, st.heat_t, st.grid[ASORA_GRID_PHI_HEAT])) return rc;
+        st.grid_valid[ASORA_GRID_PHI_HEAT] = true;
+    }
+    // the last source's column densities sit in the staging grid, which the 'F' download path below reuses:
+    // take them out first, through nHI's transposed half (free once the sweep is over)
+    if (int rc = launch_transpose(st, st.staging, st.nhi_t, N)) return rc;
+    ASORA_HIP_TRY(hipMemcpyAsync(coldensh_out, st.nhi_t, bytes, hipMemcpyDeviceToHost, st.stream));
+    if (int rc = asora_grid_to_host(ASORA_GRID_PHI_ION, phi_ion, N, 'F')) return rc;
+    if (heat) { if (int rc = asora_grid_to_host(ASORA_GRID_PHI_HEAT, phi_heat, N, 'F')) return rc; }
+    ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    if (sum_nbox) *sum_nbox = (int)total_nbox;
+    if (photon_loss) *photon_loss = total_loss;
+    return 0;
 }
 
 int asora_set_option(int option, int value)

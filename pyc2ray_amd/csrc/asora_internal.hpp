@@ -24,6 +24,7 @@ struct OctGeomDev {
 // ---------------------------------------------------------------------------------------------
 struct State {
     bool init = false;
+    bool auto_init = false;        // initialised by c2ray_do_all_sources on its own (may re-initialise for another N)
     int device = 0;
     int N = 0;
     size_t ncell = 0;
@@ -53,7 +54,7 @@ struct State {
     std::vector<void *> geom_owned;
     OctGeomDev geom_host[24];               // device pointers of the unit tables
     int geom_units = 0;
-    const double2 *logtab_dev = nullptr;
+    double2 *logtab_dev = nullptr;          // log2 table (ensure_logtab), lives until the runtime is torn down
     bool geom_valid = false;
     bool geom_dr_matters = true;
     int geom_N = 0, geom_S = 0, geom_max_cells = 0, geom_threads = 0;
@@ -76,7 +77,7 @@ struct State {
     struct PendingTimer { int which; hipEvent_t e0, e1; };
     std::vector<PendingTimer> pending_timers;     // recorded, not yet resolved
     std::vector<hipEvent_t> free_events;
-    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0};
+    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 0};
     double k_ms[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
     long k_n[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
 };
@@ -133,11 +134,43 @@ struct RtParams {
 };
 
 void release_geometry(State &st);
+int ensure_logtab(State &st);
 int launch_prepare_nhi(State &st, bool need_transposed);
 int launch_finish_phi(State &st);
 int launch_raytrace(State &st, RtParams &p, bool dump, bool heat);
 int launch_fold_transposed(State &st, const double *src_t, double *dst);   // dst[i][j][k] += src_t[k][j][i]
 int launch_transpose(State &st, const double *src, double *dst, int N);   // dst[k][j][i] = src[i][j][k]
+
+// ---------------------------------------------------------------------------------------------
+// Raytracing with the reference's CPU semantics: cubic sub-boxes, photon loss (subbox.hip)
+// ---------------------------------------------------------------------------------------------
+struct SubboxParams {
+    int N, W;                   // mesh size; row pitch of the shell-buffer slot layout (largest shell + 1)
+    int ext_r, ext_l;           // traversal range on the + / - side of every axis (raytracing.f90:174-175)
+    int s_begin, s_end;         // this launch sweeps the Chebyshev shells (s_begin, s_end]
+    int edge_r, edge_l;         // faces of the current sub-box: last_r - src, src - last_l (f90:199-200)
+    double sig, dr, R;          // R = R_max_LLS in cells
+    double numtau_f, lut_k1, lut_k0;
+    int table_len, ablate;
+    int grey, heat;
+    int src_begin, src_count;   // batch of sources
+    int flux_src;               // >= 0: every source shines with the flux of this one (f90:500,503); -1: its own
+    int dump_src;               // source whose column densities are returned (the last one), or -1
+    unsigned ncell;
+    const double *nhi;          // [i][j][k] then [k][j][i]
+    double *phi, *heat_grid;    // same layout
+    double *dump;               // [i][j][k]
+    const double2 *tables, *logtab;
+    const int32_t *src_pos;
+    const double *src_flux;
+    double *scratch;            // per workgroup: two shell buffers of 3 W^2 doubles
+    size_t unit_stride;         // = 6 W^2
+    const int *active;          // per source of the batch
+    double *loss;               // per source of the batch: photons through the current box faces
+};
+int launch_subbox_sweep(State &st, const SubboxParams &p);
+int launch_subbox_decide(State &st, int mode, int count, const double *src_flux, int src_begin, double loss_fraction,
+                         int more_range, int *active, double *loss, double *loss_final, int *nbox, int *n_active);
 
 // ---------------------------------------------------------------------------------------------
 // Chemistry (chemistry.hip)

@@ -1,0 +1,67 @@
+// Device functions shared by the raytracing kernels (raytrace.hip: ASORA path, subbox.hip: Fortran-path
+// semantics): the table-based log2 and the photo_lookuptable of src/asora/rates.cu:70-83.
+#pragma once
+#include "asora_internal.hpp"
+
+namespace asora {
+
+constexpr double FOURPI = 12.566370614359172463991853874177;   // raytracing.cu:12
+constexpr int LOG_TABLE_BITS = 7;
+constexpr int LOG_TABLE_SIZE = 1 << LOG_TABLE_BITS;
+
+// ---------------------------------------------------------------------------------------------
+// Rates (src/asora/rates.cu)
+// ---------------------------------------------------------------------------------------------
+
+// log2 of a positive normal double: exponent + table (2^7 intervals of the mantissa: 1/c and
+// log2 c at the interval centres, staged in LDS) + degree-6 series in r = m/c - 1, |r| < 2^-8
+// (truncation 3e-18).  Absolute error ~1 ulp of the result, like libm's log10; it replaces
+// log10 in the table lookup because two of them per cell dominated the instruction count.
+__device__ __forceinline__ double log2_pos(double x, const double2 *__restrict__ logtab)
+{
+    const long long bits = __double_as_longlong(x);
+    const int e = (int)(bits >> 52) - 1023;
+    const int idx = (int)(bits >> (52 - LOG_TABLE_BITS)) & (LOG_TABLE_SIZE - 1);
+    const double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);
+    const double2 t = logtab[idx];                 // {1/c, log2 c}
+    const double r = fma(m, t.x, -1.0);
+    // log2(1+r) = r/ln2 * (1 - r/2 + r^2/3 - r^3/4 + r^4/5 - r^5/6)
+    const double C1 = 1.4426950408889634074, C2 = -0.72134752044448170368, C3 = 0.48089834696298780245,
+                 C4 = -0.36067376022224085184, C5 = 0.28853900817779268147, C6 = -0.24044917348149390123;
+    const double p = r * fma(r, fma(r, fma(r, fma(r, fma(r, C6, C5), C4), C3), C2), C1);
+    return (double)e + (t.y + p);
+}
+
+// photo_lookuptable, rates.cu:70-83 (== photorates.f90:130-147), in two halves so that the two
+// dependent table loads can be in flight while other work is done.  The reference forms
+// 1 + (log10(tau) - minlogtau)/dlogtau; here that is one fused multiply-add on log2(tau) with
+// k1 = log10(2)/dlogtau, k0 = 1 - minlogtau/dlogtau.  Indices are clamped to the last table
+// element (the reference reads one past the end when NumTau == len(table), tau >= 10^maxlogtau).
+// The device tables hold pairs {T[i], T[i+1] - T[i]} (last pair {T[last], 0}): one 16-byte load per lookup.
+struct Lookup { double2 t; double2 h; double residual; };   // h: the heating-table pair at the same index
+template <bool HEAT = false, typename Params = RtParams>
+__device__ __forceinline__ Lookup lookup_issue(const double2 *__restrict__ table, double tau, const Params &p,
+                                               const double2 *__restrict__ logtab)
+{
+    const double l2 = log2_pos(fmax(1.0e-20, tau), logtab);
+    const double real_i = fmin(p.numtau_f, fmax(0.0, fma(l2, p.lut_k1, p.lut_k0)));
+    const int i0 = (int)real_i;
+    Lookup L;
+    L.residual = real_i - (double)i0;
+    int i = min(i0, p.table_len - 1);
+#ifdef ASORA_ENABLE_ABLATION
+    if (p.ablate & 8) i = 15000 + (threadIdx.x & 3);   // diagnostic: perfectly coalesced lookups
+#endif
+    L.t = table[i];
+    if (HEAT) L.h = table[i + 2 * p.table_len]; else L.h = L.t;
+    return L;
+}
+__device__ __forceinline__ double lookup_value(const Lookup &L) { return fma(L.residual, L.t.y, L.t.x); }
+__device__ __forceinline__ double lookup_heat(const Lookup &L) { return fma(L.residual, L.h.y, L.h.x); }
+
+__device__ __forceinline__ int wrap_once(int x, int N)
+{
+    return x < 0 ? x + N : (x >= N ? x - N : x);
+}
+
+} // namespace asora

@@ -35,6 +35,7 @@
 //     (rows contiguous again); the transposed accumulator is folded back once per call.
 //   * nHI = ndens*(1-xh_av) is formed once per call (raytracing.cu:275-276 forms it per visit).
 #include "asora_internal.hpp"
+#include "rates_device.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -42,60 +43,6 @@
 #include <vector>
 
 namespace asora {
-
-constexpr double FOURPI = 12.566370614359172463991853874177;   // raytracing.cu:12
-constexpr int LOG_TABLE_BITS = 7;
-constexpr int LOG_TABLE_SIZE = 1 << LOG_TABLE_BITS;
-
-// ---------------------------------------------------------------------------------------------
-// Rates (src/asora/rates.cu)
-// ---------------------------------------------------------------------------------------------
-
-// log2 of a positive normal double: exponent + table (2^7 intervals of the mantissa: 1/c and
-// log2 c at the interval centres, staged in LDS) + degree-6 series in r = m/c - 1, |r| < 2^-8
-// (truncation 3e-18).  Absolute error ~1 ulp of the result, like libm's log10; it replaces
-// log10 in the table lookup because two of them per cell dominated the instruction count.
-__device__ __forceinline__ double log2_pos(double x, const double2 *__restrict__ logtab)
-{
-    const long long bits = __double_as_longlong(x);
-    const int e = (int)(bits >> 52) - 1023;
-    const int idx = (int)(bits >> (52 - LOG_TABLE_BITS)) & (LOG_TABLE_SIZE - 1);
-    const double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);
-    const double2 t = logtab[idx];                 // {1/c, log2 c}
-    const double r = fma(m, t.x, -1.0);
-    // log2(1+r) = r/ln2 * (1 - r/2 + r^2/3 - r^3/4 + r^4/5 - r^5/6)
-    const double C1 = 1.4426950408889634074, C2 = -0.72134752044448170368, C3 = 0.48089834696298780245,
-                 C4 = -0.36067376022224085184, C5 = 0.28853900817779268147, C6 = -0.24044917348149390123;
-    const double p = r * fma(r, fma(r, fma(r, fma(r, fma(r, C6, C5), C4), C3), C2), C1);
-    return (double)e + (t.y + p);
-}
-
-// photo_lookuptable, rates.cu:70-83 (== photorates.f90:130-147), in two halves so that the two
-// dependent table loads can be in flight while other work is done.  The reference forms
-// 1 + (log10(tau) - minlogtau)/dlogtau; here that is one fused multiply-add on log2(tau) with
-// k1 = log10(2)/dlogtau, k0 = 1 - minlogtau/dlogtau.  Indices are clamped to the last table
-// element (the reference reads one past the end when NumTau == len(table), tau >= 10^maxlogtau).
-// The device tables hold pairs {T[i], T[i+1] - T[i]} (last pair {T[last], 0}): one 16-byte load per lookup.
-struct Lookup { double2 t; double2 h; double residual; };   // h: the heating-table pair at the same index
-template <bool HEAT = false>
-__device__ __forceinline__ Lookup lookup_issue(const double2 *__restrict__ table, double tau, const RtParams &p,
-                                               const double2 *__restrict__ logtab)
-{
-    const double l2 = log2_pos(fmax(1.0e-20, tau), logtab);
-    const double real_i = fmin(p.numtau_f, fmax(0.0, fma(l2, p.lut_k1, p.lut_k0)));
-    const int i0 = (int)real_i;
-    Lookup L;
-    L.residual = real_i - (double)i0;
-    int i = min(i0, p.table_len - 1);
-#ifdef ASORA_ENABLE_ABLATION
-    if (p.ablate & 8) i = 15000 + (threadIdx.x & 3);   // diagnostic: perfectly coalesced lookups
-#endif
-    L.t = table[i];
-    if (HEAT) L.h = table[i + 2 * p.table_len]; else L.h = L.t;
-    return L;
-}
-__device__ __forceinline__ double lookup_value(const Lookup &L) { return fma(L.residual, L.t.y, L.t.x); }
-__device__ __forceinline__ double lookup_heat(const Lookup &L) { return fma(L.residual, L.h.y, L.h.x); }
 
 // photoion_rates_gpu rates.cu:16-41 divided by nHI (raytracing.cu:324), also in two halves.
 // pref = flux/(vol*nHI) replaces the reference's two divisions by one.  A cell is "thick" when
@@ -162,11 +109,6 @@ __device__ __forceinline__ double photo_rate_per_atom(double flux, double cd_in,
 {
     if (p.grey) return grey_rate_per_atom(flux, cd_in, cd_out, vol_nhi, p);
     return rate_value(rate_issue(flux, cd_in, cd_out, vol_nhi, p, logtab));
-}
-
-__device__ __forceinline__ int wrap_once(int x, int N)
-{
-    return x < 0 ? x + N : (x >= N ? x - N : x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -655,11 +597,27 @@ int upload(const std::vector<T> &v, const T *&dev_out, std::vector<void *> &owne
 
 } // namespace
 
+// log2 table of log2_pos: interval centres c = 1 + (i + 1/2)/128, entries {1/c, log2 c}
+int ensure_logtab(State &st)
+{
+    if (st.logtab_dev) return 0;
+    std::vector<double2> lt(LOG_TABLE_SIZE);
+    for (int i = 0; i < LOG_TABLE_SIZE; ++i) {
+        const long double c = 1.0L + ((long double)i + 0.5L) / (long double)LOG_TABLE_SIZE;
+        lt[i].x = (double)(1.0L / c);
+        lt[i].y = (double)std::log2(c);
+    }
+    double2 *d = nullptr;
+    ASORA_HIP_TRY(hipMalloc(&d, lt.size() * sizeof(double2)));
+    ASORA_HIP_TRY(hipMemcpy(d, lt.data(), lt.size() * sizeof(double2), hipMemcpyHostToDevice));
+    st.logtab_dev = d;
+    return 0;
+}
+
 void release_geometry(State &st)
 {
     for (void *q : st.geom_owned) (void)hipFree(q);
     st.geom_owned.clear();
-    st.logtab_dev = nullptr;
     st.geom_valid = false;
 }
 
@@ -758,19 +716,11 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
     }
     for (int u = 0; u < units; ++u) { od[u] = od[owner[u]]; od[u].info = info[u]; }
 
-    // log2 table: interval centres c = 1 + (i + 1/2)/128, entries {1/c, log2 c}
-    std::vector<double2> lt(LOG_TABLE_SIZE);
-    for (int i = 0; i < LOG_TABLE_SIZE; ++i) {
-        const long double c = 1.0L + ((long double)i + 0.5L) / (long double)LOG_TABLE_SIZE;
-        lt[i].x = (double)(1.0L / c);
-        lt[i].y = (double)std::log2(c);
-    }
-    const double2 *ltd = nullptr;
-    if (int rc = upload(lt, ltd, st.geom_owned)) return rc;
+    if (int rc = ensure_logtab(st)) return rc;
+    const double2 *ltd = st.logtab_dev;
 
     for (int o = 0; o < units; ++o) st.geom_host[o] = od[o];
     st.geom_units = units;
-    st.logtab_dev = ltd;
     st.geom_N = N; st.geom_R = p.R; st.geom_dr = p.dr; st.geom_S = Smax; st.geom_max_cells = (int)max_cells;
     st.geom_threads = threads;
     st.geom_dr_matters = dr_matters;

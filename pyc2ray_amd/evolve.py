@@ -20,9 +20,90 @@ from .utils.sourceutils import format_sources
 __all__ = ['evolve3D', 'evolve3D_MPI']
 
 
-def _host_cpu_step_unavailable():
-    # use_gpu=False selects the reference's Fortran CPU raytracer (evolve.py:190-194)
-    load_c2ray().raytracing.do_all_sources()
+def _evolve_cpu_semantics(dt, dr, src_flux, src_pos, max_subbox, subboxsize, loss_fraction, temp, ndens, xh,
+                          photo_thin_table, photo_thick_table, minlogtau, dlogtau, R_max_LLS, convergence_fraction,
+                          sig, bh00, albpow, colh0, temph0, abu_c, logfile, quiet,
+                          use_mpi=None, comm=None, rank=0, nprocs=1):
+    """The use_gpu=False branch of the reference (pyc2ray/evolve.py:168-245, :401-498): host arrays, one call of
+    libc2ray.raytracing.do_all_sources (cubic sub-boxes, photon-loss statistics) and one of
+    libc2ray.chemistry.global_pass per iteration.  Both keep the semantics of the reference's Fortran
+    functions but are evaluated on the GPU, so this branch pays two PCIe round trips of the grids per
+    iteration; use_gpu=True is the device-resident path."""
+    libc2ray = load_c2ray()
+    distributed = bool(use_mpi) and comm is not None and nprocs > 1
+    NumSrc = src_flux.shape[0]
+    N = temp.shape[0]
+    NumCells = N * N * N
+    NumTau = photo_thin_table.shape[0]
+    conv_criterion = min(int(convergence_fraction * NumCells), (NumSrc - 1) / 3)        # evolve.py:127
+    prev_sum_xh1_int = 2 * NumCells
+    prev_sum_xh0_int = 2 * NumCells
+    converged = False
+    niter = 0
+    xh_av = np.copy(xh, order='F')                                                      # evolve.py:136-137
+    xh_intermed = np.copy(xh, order='F')
+    ndens_f, temp_f, xh_f = (np.asfortranarray(a, dtype=np.float64) for a in (ndens, temp, xh))
+    if distributed:                                                                     # evolve.py:360-371
+        perrank = NumSrc // nprocs
+        i_start = int(rank * perrank)
+        i_end = int((rank + 1) * perrank) if rank != nprocs - 1 else NumSrc
+        my_flux, my_pos = src_flux[i_start:i_end], np.asarray(src_pos)[:, i_start:i_end]
+        printlog(f"...rank={rank:n} has {i_end - i_start:n} sources.", logfile, quiet)
+    else:
+        my_flux, my_pos = src_flux, src_pos
+    if rank == 0:
+        printlog("Calling evolve3D...", logfile, quiet)
+        printlog(f"dr [Mpc]: {dr/3.086e24:.3e}", logfile, quiet)
+        printlog(f"dt [years]: {dt/3.15576E+07:.3e}", logfile, quiet)
+        printlog(f"Running on {NumSrc:n} source(s), total normalized ionizing flux: {src_flux.sum():.2e}", logfile, quiet)
+        printlog(f"Mean density (cgs): {ndens.mean():.3e}, Mean ionized fraction: {xh.mean():.3e}", logfile, quiet)
+        printlog(f"Convergence Criterion (Number of points): {conv_criterion : n}", logfile, quiet, end='\n\n')
+    phi_ion = np.zeros((N, N, N), order='F')
+    while not converged:
+        niter += 1
+        trt0 = time.time()
+        printlog("Doing Raytracing...", logfile, quiet, ' ')
+        phi_ion = np.zeros((N, N, N), order='F')                                        # evolve.py:178-182
+        phi_heat = np.zeros((N, N, N), order='F')
+        coldensh_out = np.zeros((N, N, N), order='F')
+        nsubbox, photonloss = libc2ray.raytracing.do_all_sources(
+            my_flux, my_pos, max_subbox, subboxsize, coldensh_out, sig, dr, ndens_f, xh_av, phi_ion, phi_heat,
+            loss_fraction, photo_thin_table, photo_thick_table, np.zeros(NumTau), np.zeros(NumTau),
+            minlogtau, dlogtau, R_max_LLS)
+        printlog(f"took {(time.time()-trt0) : .1f} s.", logfile, quiet)
+        printlog(f"Average number of subboxes: {nsubbox/max(len(my_flux), 1):n}, Total photon loss: {photonloss:.3e}",
+                 logfile, quiet)
+        if distributed:                                                                 # evolve.py:433-437
+            if hasattr(comm, "allreduce_device_grid"):
+                comm.Allreduce(use_mpi.IN_PLACE, [phi_ion, use_mpi.DOUBLE], op=use_mpi.SUM)
+            else:
+                if rank == 0:
+                    comm.Reduce(use_mpi.IN_PLACE, [phi_ion, use_mpi.DOUBLE], op=use_mpi.SUM, root=0)
+                else:
+                    comm.Reduce([phi_ion, use_mpi.DOUBLE], None, op=use_mpi.SUM, root=0)
+                comm.Bcast([phi_ion, use_mpi.DOUBLE], root=0)
+        tch0 = time.time()
+        if rank == 0:
+            printlog("Doing Chemistry...", logfile, quiet, ' ')
+        conv_flag = libc2ray.chemistry.global_pass(dt, ndens_f, temp_f, xh_f, xh_av, xh_intermed, phi_ion,
+                                                   bh00, albpow, colh0, temph0, abu_c)  # evolve.py:210
+        if rank == 0:
+            printlog(f"took {(time.time()-tch0) : .1f} s.", logfile, quiet)
+        sum_xh1_int = np.sum(xh_intermed)                                               # evolve.py:216-217
+        sum_xh0_int = np.sum(1.0 - xh_intermed)
+        rel_change_xh1 = np.abs((sum_xh1_int - prev_sum_xh1_int) / sum_xh1_int) if sum_xh1_int > 0.0 else 1.0
+        rel_change_xh0 = np.abs((sum_xh0_int - prev_sum_xh0_int) / sum_xh0_int) if sum_xh0_int > 0.0 else 1.0
+        if rank == 0:
+            printlog(f"Number of non-converged points: {conv_flag} of {NumCells} ({conv_flag / NumCells * 100 : .3f} % ), "
+                     f"Relative change in ionfrac: {rel_change_xh1 : .2e}", logfile, quiet)
+        converged = (conv_flag < conv_criterion) or ((rel_change_xh1 < convergence_fraction) and
+                                                     (rel_change_xh0 < convergence_fraction))
+        prev_sum_xh1_int = sum_xh1_int
+        prev_sum_xh0_int = sum_xh0_int
+    if rank == 0:
+        printlog("Multiple source convergence reached.", logfile, quiet)
+    _evolve.last_niter = niter
+    return xh_intermed, phi_ion
 
 
 def _allreduce_phi(libasora, N, use_mpi, comm, rank):
@@ -46,9 +127,6 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
             use_mpi=None, comm=None, rank=0, nprocs=1):
     if use_gpu and not cuda_is_init():
         raise RuntimeError("GPU not initialized. Please initialize it by calling device_init(N)")
-    if not use_gpu:
-        _host_cpu_step_unavailable()
-
     distributed = bool(use_mpi) and comm is not None and nprocs > 1
     libasora = load_asora()
 
@@ -167,11 +245,18 @@ def evolve3D(dt, dr,
     src_flux (numsrc) in units of 1e48 s^-1, src_pos (3,numsrc) 1-based, temp/ndens/xh (N,N,N),
     tables as copied to the GPU beforehand with photo_table_to_device(), R_max_LLS in cells.
     max_subbox, subboxsize and loss_fraction only concern the reference's CPU raytracer and have no
-    effect with use_gpu=True; use_gpu=False raises (no CPU compute path in this build).
+    effect with use_gpu=True.  use_gpu=False selects that raytracer's semantics (cubic sub-boxes grown until
+    the photon loss is below loss_fraction, evolve.py:190-194) -- still evaluated on the GPU, through the
+    libc2ray-compatible entry points, with host arrays as in the reference.
 
     Returns (xh_new, phi_ion): end-of-step ionised fraction (laid out like `xh`) and the summed
-    photo-ionisation rate (C-ordered), as the reference's GPU branch does (evolve.py:200,244-245).
+    photo-ionisation rate (C-ordered with use_gpu=True, Fortran-ordered with use_gpu=False, as in the
+    reference, evolve.py:178,200,244-245).
     """
+    if not use_gpu:
+        return _evolve_cpu_semantics(dt, dr, src_flux, src_pos, max_subbox, subboxsize, loss_fraction, temp, ndens,
+                                     xh, photo_thin_table, photo_thick_table, minlogtau, dlogtau, R_max_LLS,
+                                     convergence_fraction, sig, bh00, albpow, colh0, temph0, abu_c, logfile, quiet)
     return _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_table, minlogtau, dlogtau,
                    R_max_LLS, convergence_fraction, sig, bh00, albpow, colh0, temph0, abu_c, logfile, quiet)
 
@@ -195,6 +280,11 @@ def evolve3D_MPI(dt, dr,
     (one process per GPU under torch.distributed: RCCL all-reduce over xGMI directly on the
     device-resident grid).  All ranks return the same (xh_new, phi_ion).
     """
+    if not use_gpu:
+        return _evolve_cpu_semantics(dt, dr, src_flux, src_pos, max_subbox, subboxsize, loss_fraction, temp, ndens,
+                                     xh, photo_thin_table, photo_thick_table, minlogtau, dlogtau, R_max_LLS,
+                                     convergence_fraction, sig, bh00, albpow, colh0, temph0, abu_c, logfile, quiet,
+                                     use_mpi=use_mpi, comm=comm, rank=rank, nprocs=nprocs)
     return _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_table, minlogtau, dlogtau,
                    R_max_LLS, convergence_fraction, sig, bh00, albpow, colh0, temph0, abu_c, logfile, quiet,
                    use_mpi=use_mpi, comm=comm, rank=rank, nprocs=nprocs)

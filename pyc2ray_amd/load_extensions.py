@@ -8,7 +8,9 @@ modules (pyc2ray/evolve.py:147-210, raytracing_benchmark/run_test.py:66-85) runs
 
 Differences, all deliberate:
   * a missing library raises RuntimeError for BOTH loaders (the reference makes ASORA optional and
-    prints an "Info" line, load_extensions.py:41-44).  This build has no CPU path to fall back to.
+    prints an "Info" line, load_extensions.py:41-44).  This build has no CPU path to fall back to:
+    ``libc2ray.raytracing.do_all_sources`` and ``libc2ray.chemistry.global_pass`` keep the semantics of
+    the reference's CPU functions but run on the GPU.
   * errors inside the library come back as RuntimeError carrying the library's message instead of
     an uncaught C++ exception.
   * array arguments are validated (dtype float64 / int32, contiguity, size) instead of being
@@ -219,11 +221,46 @@ class _Raytracing:
     def __init__(self, lib):
         self._lib = lib
 
-    def do_all_sources(self, *args, **kwargs):
-        raise RuntimeError(
-            "libc2ray.raytracing.do_all_sources (the reference's single-threaded Fortran CPU raytracer, "
-            "src/c2ray/raytracing.f90:52) is not part of this build: pyc2ray_amd ships no CPU compute path. "
-            "Call with use_gpu=True (ASORA path on the MI355X).")
+    def do_all_sources(self, normflux, srcpos, max_subbox, subboxsize, coldensh_out, sig, dr, ndens, xh_av,
+                       phi_ion, phi_heat, loss_fraction, photo_thin_table, photo_thick_table,
+                       heat_thin_table, heat_thick_table, minlogtau, dlogtau, r_max_lls):
+        """sum_nbox, photon_loss = do_all_sources(...)   (f2py signature of raytracing.f90:52-56)
+
+        The reference's CPU raytracer -- cubic sub-boxes grown until the photon loss through the box faces is
+        small, rates within r_max_lls, heating rates, column densities of the last source -- evaluated on the
+        GPU (csrc/subbox.hip).  As with f2py's intent(inout), coldensh_out, phi_ion and phi_heat must be
+        Fortran-contiguous float64 (N,N,N) arrays and are updated in place; ndens and xh_av are copied to
+        Fortran order when needed; srcpos is (3,NumSrc), 1-based."""
+        flux = np.ascontiguousarray(normflux, dtype=np.float64)
+        pos = np.asfortranarray(srcpos, dtype=np.int32)
+        if pos.ndim != 2 or pos.shape[0] != 3 or pos.shape[1] != flux.size:
+            raise ValueError("srcpos must have shape (3, NumSrc) matching normflux")
+        shape = np.shape(coldensh_out)
+        if len(shape) != 3 or shape[0] != shape[1] or shape[0] != shape[2]:
+            raise ValueError("grids must have shape (N,N,N)")
+        for name, a in (("coldensh_out", coldensh_out), ("phi_ion", phi_ion), ("phi_heat", phi_heat)):
+            if not isinstance(a, np.ndarray) or a.dtype != np.float64 or a.shape != shape or not a.flags.f_contiguous:
+                raise ValueError(f"{name} must be a Fortran-contiguous float64 array of shape {shape} "
+                                 "(updated in place)")
+        nd = np.asfortranarray(ndens, dtype=np.float64)
+        xa = np.asfortranarray(xh_av, dtype=np.float64)
+        if nd.shape != shape or xa.shape != shape:
+            raise ValueError("ndens and xh_av must have the shape of the output grids")
+        tabs = [np.ascontiguousarray(t, dtype=np.float64) for t in
+                (photo_thin_table, photo_thick_table, heat_thin_table, heat_thick_table)]
+        numtau = tabs[0].size
+        if any(t.size != numtau for t in tabs):
+            raise ValueError("the four radiation tables must have the same length")
+        nbox = C.c_int(0)
+        loss = C.c_double(0.0)
+        N = int(shape[0])
+        _capi.check(self._lib.c2ray_do_all_sources(
+            _capi.dptr(flux), _capi.iptr(pos), int(max_subbox), int(subboxsize), _capi.dptr(coldensh_out),
+            float(sig), float(dr), _capi.dptr(nd), _capi.dptr(xa), _capi.dptr(phi_ion), _capi.dptr(phi_heat),
+            float(loss_fraction), _capi.dptr(tabs[0]), _capi.dptr(tabs[1]), _capi.dptr(tabs[2]), _capi.dptr(tabs[3]),
+            float(minlogtau), float(dlogtau), float(r_max_lls), int(numtau), int(flux.size), N, N, N,
+            C.byref(nbox), C.byref(loss)), "do_all_sources")
+        return nbox.value, loss.value
 
 
 class _LibC2Ray:

@@ -28,8 +28,12 @@ def do_raytracing(dr,
     ``(phi_ion, phi_heat)``.  On the GPU path the reference's return statement refers to an
     undefined ``phi_heat`` (raytracing.py:108, NameError; GPU heating is a TODO there,
     c2ray_base.py:424-426); here the photo-heating rate is computed on the GPU when non-zero heating
-    tables are passed (arithmetic of the Fortran path, photorates.f90:118,124) and is ``None`` otherwise.  ``use_gpu=False`` selects the reference's Fortran
-    CPU raytracer, which this build does not ship: RuntimeError.
+    tables are passed (arithmetic of the Fortran path, photorates.f90:118,124) and is ``None`` otherwise.
+
+    ``use_gpu=False`` selects the semantics of the reference's Fortran CPU raytracer (cubic sub-boxes grown
+    until the photon loss is below loss_fraction, raytracing.py:89-95) -- evaluated on the GPU through
+    ``libc2ray.raytracing.do_all_sources``: returns ``(phi_ion, phi_heat)`` in Fortran order, or
+    ``(phi_ion, nsubbox, photonloss)`` with ``stats=True`` (raytracing.py:105-108).
     """
     if use_gpu and not cuda_is_init():
         raise RuntimeError("GPU not initialized. Please initialize it by calling device_init(N)")
@@ -43,11 +47,20 @@ def do_raytracing(dr,
     printlog(f"Mean density (cgs): {ndens.mean():.3e}, Mean ionized fraction: {xh_av.mean():.3e}", logfile, quiet)
 
     if not use_gpu:
-        # raises: no CPU compute path in this build
-        load_c2ray().raytracing.do_all_sources(src_flux, src_pos, max_subbox, subboxsize, None, sig, dr, ndens,
-                                               xh_av, None, None, loss_fraction, photo_thin_table,
-                                               photo_thick_table, heat_thin_table, heat_thick_table,
-                                               minlogtau, dlogtau, R_max_LLS)
+        trt0 = time.time()
+        printlog("Doing Raytracing...", logfile, quiet, ' ')
+        phi_ion = np.zeros((N, N, N), order='F')                      # raytracing.py:80-83
+        phi_heat = np.zeros((N, N, N), order='F')
+        coldensh_out = np.zeros((N, N, N), order='F')
+        nsubbox, photonloss = load_c2ray().raytracing.do_all_sources(
+            src_flux, src_pos, max_subbox, subboxsize, coldensh_out, sig, dr, np.asfortranarray(ndens), xh_av,
+            phi_ion, phi_heat, loss_fraction, photo_thin_table, photo_thick_table, heat_thin_table,
+            heat_thick_table, minlogtau, dlogtau, R_max_LLS)
+        printlog(f"took {(time.time()-trt0) : .1f} s.", logfile, quiet)
+        printlog(f"Average number of subboxes: {nsubbox/NumSrc:n}, Total photon loss: {photonloss:.3e}", logfile, quiet)
+        if stats:
+            return phi_ion, nsubbox, photonloss
+        return phi_ion, phi_heat
 
     libasora = load_asora()
     srcpos_flat, normflux_flat = format_sources(src_pos, src_flux)

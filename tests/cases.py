@@ -100,3 +100,36 @@ def chem_case(N, seed, dt=3.15576e13):
     phi[rng.uniform(size=(N, N, N)) < 0.02] = 1e-2     # -> fully ionised cells
     return dict(dt=dt, ndens=nd, temp=temp, xh=xh, xh_av=xh_av, xh_intermed=xh.copy(), phi_ion=phi,
                 bh00=BH00, albpow=ALBPOW, colh0=COLH0, temph0=TEMPH0, abu_c=ABU_C)
+
+
+#: sub-box cases of the reference's CPU raytracer (libc2ray.raytracing.do_all_sources): name ->
+#: (raytracing case, tables, max_subbox, subboxsize, loss_fraction, unequal fluxes?[, tau of a mean cell])
+#: All with R_max_LLS = 1000 cells: with a smaller radius, cells on the box faces deposit nothing and the
+#: reference adds an UNDEFINED phi_out to the loss there (raytracing.f90:408,519,543).
+SUBBOX_CASES = {
+    "sb32_b5":   ("l32_5src_R10", "soft", 1000, 5, 0.05, True),
+    "sb32_b3":   ("l32_5src_R10", "grey", 12, 3, 1e-2, False),
+    "sb17_b2":   ("l17_3src_Rbox", "soft", 6, 2, 0.3, True),
+    "sb16_thick": ("l16_thick", "soft", 1000, 2, 1e-2, False),
+    "sb16_b7":   ("l16_7src_R5.5", "soft", 1000, 7, 1e-3, True),
+    "sb16_b8":   ("u16_7src_Rbox", "grey", 1000, 8, 1e-3, False),
+    "sb32_mid":  ("l32_5src_R10", "soft", 1000, 3, 1e-2, True, 1.0),     # sources stop after different box counts
+    "sb32_mid2": ("l32_5src_R10", "grey", 1000, 4, 0.1, True, 0.5),
+    "sb17_mid":  ("l17_3src_Rbox", "soft", 1000, 1, 0.05, False, 1.5),
+}
+
+
+def subbox_case(name):
+    """Inputs of a sub-box case: the raytracing case + heating tables + (optionally) unequal fluxes."""
+    base, tables, max_subbox, subboxsize, loss_fraction, unequal = SUBBOX_CASES[name][:6]
+    c = rt_case(base, tables)
+    c["R"] = 1000.0
+    if len(SUBBOX_CASES[name]) > 6:
+        c["dr"] = SUBBOX_CASES[name][6] / (SIG * 1e-3)
+    n = c["thin"].shape[0]
+    c["heat_thin"] = 1e-11 * c["thin"] * np.linspace(1.0, 2.0, n)
+    c["heat_thick"] = 0.7e-11 * c["thick"] * np.linspace(2.0, 1.0, n)
+    if unequal:
+        c["flux"] = c["flux"] * (0.5 + np.arange(c["flux"].shape[0]))
+    c.update(max_subbox=max_subbox, subboxsize=subboxsize, loss_fraction=loss_fraction)
+    return c

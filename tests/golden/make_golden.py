@@ -107,6 +107,23 @@ def gen_raytrace():
     np.savez_compressed(os.path.join(HERE, "raytrace.npz"), **out)
 
 
+def gen_subbox():
+    """The reference's CPU raytracer with sub-box growth, heating tables and unequal fluxes."""
+    out = {}
+    for name in cases.SUBBOX_CASES:
+        c = cases.subbox_case(name)
+        r = F.do_all_sources(c["flux"], c["pos"], max_subbox=c["max_subbox"], subboxsize=c["subboxsize"],
+                             sig=c["sig"], dr=c["dr"], ndens=c["ndens"], xh_av=c["xh"],
+                             loss_fraction=c["loss_fraction"], thin=c["thin"], thick=c["thick"],
+                             minlogtau=c["minlogtau"], dlogtau=c["dlogtau"], R_max_LLS=c["R"],
+                             heat_thin=c["heat_thin"], heat_thick=c["heat_thick"], NumTau=c["thin"].shape[0] - 1)
+        out[name + "__phi"] = np.ascontiguousarray(r["phi_ion"])
+        out[name + "__heat"] = np.ascontiguousarray(r["phi_heat"])
+        out[name + "__cd"] = np.ascontiguousarray(r["coldens"])
+        out[name + "__stats"] = np.array([r["nsubbox"], r["photon_loss"]])
+    np.savez_compressed(os.path.join(HERE, "subbox.npz"), **out)
+
+
 def gen_global_pass():
     out = {}
     for N, seed in ((16, 21), (12, 22)):
@@ -126,5 +143,6 @@ if __name__ == "__main__":
     gen_rates()
     gen_chem_points()
     gen_raytrace()
+    gen_subbox()
     gen_global_pass()
     print("golden vectors written to", HERE)

@@ -58,13 +58,18 @@ def test_guards_before_device_init(built):
                         np.ones(5), np.ones(5), -20.0, 0.1, 4.0, 1e-18, quiet=True, logfile=None)
 
 
-def test_cpu_path_is_refused_loudly(built):
+def test_cpu_semantics_path_has_no_cpu_fallback(built):
+    """use_gpu=False selects the SEMANTICS of the reference's CPU raytracer (sub-boxes, photon loss); the work is
+    still done by the HIP library.  Without a GPU the call fails loudly instead of computing on the host."""
     import pyc2ray_amd as p
     N = 8
-    g = np.ones((N, N, N))
-    with pytest.raises(RuntimeError, match="no CPU compute path"):
+    g = np.ones((N, N, N)) * 0.5
+    with pytest.raises(RuntimeError, match="do_all_sources failed"):
         p.evolve3D(1.0, 1.0, np.ones(1), np.ones((3, 1)), False, 10, 4, 0.01, g, g, g, np.ones(5), np.ones(5),
                    -20.0, 0.1, 4.0, 1e-4, 1e-18, 1.0, 1.0, 1.0, 1.0, 1.0, quiet=True, logfile=None)
+    with pytest.raises(RuntimeError, match="do_all_sources failed"):
+        p.do_raytracing(1.0, np.ones(1), np.ones((3, 1)), False, 10, 4, 0.01, g, g, np.ones(5), np.ones(5),
+                        np.ones(5), np.ones(5), -20.0, 0.1, 4.0, 1e-18, quiet=True, logfile=None)
 
 
 def test_errors_come_back_as_runtime_errors_with_message(built):

@@ -76,6 +76,23 @@ def test_fortran_path_subbox_early_stop():
     assert r["photon_loss"] == g["subbox__stats"][1]
 
 
+@pytest.mark.parametrize("name", list(cases.SUBBOX_CASES))
+def test_fortran_path_subbox_growth_heating_unequal_fluxes(name):
+    """Sub-box growth with early stop, heating tables and unequal fluxes (the reference rates every source with
+    the last source's flux, raytracing.f90:500,503): bit-identical to the reference's own output."""
+    c = cases.subbox_case(name)
+    g = np.load(os.path.join(G, "subbox.npz"))
+    r = O.do_all_sources(c["flux"], c["pos"], max_subbox=c["max_subbox"], subboxsize=c["subboxsize"], sig=c["sig"],
+                         dr=c["dr"], ndens=c["ndens"], xh_av=c["xh"], loss_fraction=c["loss_fraction"], thin=c["thin"],
+                         thick=c["thick"], minlogtau=c["minlogtau"], dlogtau=c["dlogtau"], R_max_LLS=c["R"],
+                         heat_thin=c["heat_thin"], heat_thick=c["heat_thick"], NumTau=c["thin"].shape[0] - 1)
+    assert np.array_equal(r["phi_ion"], g[name + "__phi"])
+    assert np.array_equal(r["phi_heat"], g[name + "__heat"])
+    assert np.array_equal(r["coldens"], g[name + "__cd"])
+    assert r["nsubbox"] == int(g[name + "__stats"][0])
+    assert r["photon_loss"] == g[name + "__stats"][1]
+
+
 @pytest.mark.parametrize("N,seed", [(16, 21), (12, 22)])
 def test_global_pass(N, seed):
     g = _load("global_pass.npz")
