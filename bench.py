@@ -86,28 +86,42 @@ def make_workload(kind, N, nsrc_total):
     return ndens, xh, temp, dr, pos, flux
 
 
+def workload_label(kind, N, nsrc, R):
+    """Names the BASELINE.json config a run corresponds to (configs[2] is what `metric` is quoted on)."""
+    if kind == "uniform":
+        tag = "BASELINE configs[2]: " if (N, nsrc) == (256, 1000) and R in (16.0, 32.0, 64.0) else ""
+        return (f"{tag}{N}^3 uniform ndens=1e-3 xh=2e-4, {nsrc} random sources/GPU, r_RT={R:g}, "
+                "raytrace + one chemistry pass per step")
+    tag = ("BASELINE configs[3]: " if (N, nsrc, R) == (256, 1000, 32.0) else
+           "BASELINE configs[4] on one GPU: " if (N, nsrc, R) == (512, 100000, 32.0) else "")
+    return (f"{tag}{N}^3 log-normal density, {nsrc} sources/GPU on the densest cells, r_RT={R:g}, "
+            "raytrace + one chemistry pass per step")
+
+
 def pmc_traffic_bytes():
     """HBM bytes per launch of the raytrace kernel from the committed PMC summary of this round
     (profiles/r01_pmc_summary.txt: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc passes of
     this same command).  Counters are in KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section)
     prescribes for gfx950 -- the doubling was checked on this repository's chemistry kernel, whose
     2*FETCH_SIZE equals its 5 N^3 float64 loads exactly.  Returns None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.txt")
-    if not os.path.exists(path):
+    c = pmc_counters()
+    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         return None
-    fetch = write = None
+    return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+
+
+def pmc_counters():
+    """Mean per launch of every counter the committed PMC summary holds for the raytrace kernel."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.txt")
+    out = {}
+    if not os.path.exists(path):
+        return out
     for line in open(path):
         if "raytrace_octant_kernel" not in line:
             continue
         parts = line.split()
-        for i, tok in enumerate(parts):
-            if tok == "FETCH_SIZE":
-                fetch = float(parts[-1].split("=")[1])
-            if tok == "WRITE_SIZE":
-                write = float(parts[-1].split("=")[1])
-    if fetch is None or write is None:
-        return None
-    return (2.0 * fetch + write) * 1024.0
+        out[parts[1]] = float(parts[-1].split("=")[1])
+    return out
 
 
 def cpu_baseline(kind, N, ndens, xh, temp, dr, pos, flux, thin, thick, dlog, R, nsrc_job, budget_sources):
@@ -262,9 +276,7 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": ("BASELINE configs[2]: 256^3 uniform ndens=1e-3 xh=2e-4, 1000 random sources/GPU, r_RT=32, "
-                         "raytrace + one chemistry pass per step" if args.workload == "uniform" else
-                         "BASELINE configs[3]: 256^3 log-normal density, 1000 sources/GPU on densest cells, r_RT=32"),
+            "workload": workload_label(args.workload, N, args.nsrc, args.R),
             "grid": N, "sources_per_gpu": args.nsrc, "R_cells": args.R, "numtau": NUMTAU,
             "parallelism": f"sources x{world}" if world > 1 else "single GPU",
             "unit_definition": "rate-receiving (source,cell) pairs (|d|<=R) + N^3 chemistry cells per step",
@@ -285,9 +297,10 @@ def main():
             "algorithmic_bytes_per_launch": RT_BYTES_PER_UPDATE * gamma_cells,
             "avg_launch_ms": rt_ms / max(rt_n, 1),
             "launches_timed": rt_n,
-            "binding_resource": ("memory-side atomic request rate: TCC_EA0_ATOMIC 2.73e7 64-B requests per launch "
-                                 "(profiles/r01_pmc_summary.txt) against ~2.0e10 requests/s chip-wide "
-                                 "(MI355X_MICROARCH.md, Global float atomics)"),
+            "binding_resource": ("memory-side atomic request rate: TCC_EA0_ATOMIC %.3g 64-B requests per launch of "
+                                 "the default workload (profiles/r01_pmc_summary.txt) against ~2.0e10 requests/s "
+                                 "chip-wide (MI355X_MICROARCH.md, Global float atomics)"
+                                 % pmc_counters().get("TCC_EA0_ATOMIC_sum", float("nan"))),
         },
         "kernels_ms_per_step": {
             "raytrace": rt_ms / K, "chemistry": ch_ms / K, "prepare_nhi": pr_ms / K, "fold_phi_t": fi_ms / K,

@@ -1,0 +1,81 @@
+"""The reference's raytracing benchmark, CPU leg (raytracing_benchmark/run_test.py:88: do_all_sources(normflux,
+srcpos, max_subbox=1000, subboxsize=r_RT, ..., loss_fraction, tables, R_max_LLS=r_RT)), through this build's
+libc2ray-compatible entry point on the GPU, and -- when oracle/_ref is present -- through the reference Fortran
+itself on one host core, on the same inputs.  Prints one JSON line per radius.
+usage: python tools/bench_c2ray_path.py [--N 256] [--nsrc 1000] [--R 16 32] [--cpu-sources 1000] [--workload uniform]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from pyc2ray_amd.load_extensions import load_asora, load_c2ray
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--N", type=int, default=256)
+ap.add_argument("--nsrc", type=int, default=1000)
+ap.add_argument("--R", type=float, nargs="+", default=[16.0, 32.0])
+ap.add_argument("--cpu-sources", type=int, default=1000)
+ap.add_argument("--workload", default="uniform")
+ap.add_argument("--loss-fraction", type=float, default=1e-2)
+ap.add_argument("--reps", type=int, default=3)
+a = ap.parse_args()
+
+N, ns = a.N, a.nsrc
+c2ray = load_c2ray()
+asora = load_asora()
+thin, thick, dlog = bench.make_tables()
+ndens, xh, temp, dr, pos, flux = bench.make_workload(a.workload, N, ns)
+nd_f, xh_f = np.asfortranarray(ndens), np.asfortranarray(xh)
+zeros = np.zeros(thin.shape[0])
+
+for R in a.R:
+    sub = int(R)
+    phi = np.zeros((N, N, N), order="F")
+    heat = np.zeros((N, N, N), order="F")
+    cd = np.zeros((N, N, N), order="F")
+    call = lambda: c2ray.raytracing.do_all_sources(flux, pos, 1000, sub, cd, bench.SIG, dr, nd_f, xh_f, phi, heat,
+                                                   a.loss_fraction, thin, thick, zeros, zeros, bench.MINLOGTAU, dlog, R)
+    call()
+    asora.set_option(2, 1)           # ASORA_OPT_TIMING
+    asora.kernel_time_reset()
+    t0 = time.perf_counter()
+    for _ in range(a.reps):
+        nbox, loss = call()
+    t_gpu = (time.perf_counter() - t0) / a.reps
+    k_ms, k_n = asora.kernel_time_ms(0)
+    asora.set_option(2, 0)
+    out = {"call": "libc2ray.raytracing.do_all_sources on the GPU (host grids in/out, Fortran order)", "N": N,
+           "sources": ns, "R": R, "subboxsize": sub, "loss_fraction": a.loss_fraction, "s_per_call": t_gpu,
+           "sweep_kernels_ms_per_call": k_ms / a.reps, "sweep_launches_per_call": k_n / a.reps,
+           "nsubbox": nbox, "photon_loss": loss}
+    try:
+        from oracle import ref_fortran as F
+        have_ref = F.available()
+    except Exception:
+        have_ref = False
+    m = min(a.cpu_sources, ns)
+    if have_ref and m > 0:
+        # the reference rates every source with the LAST source's flux (raytracing.f90:500,503): keep the last
+        # source last when timing a subset
+        sel = np.r_[0:m - 1, ns - 1] if m < ns else np.arange(ns)
+        t0 = time.perf_counter()
+        r = F.do_all_sources(flux[sel], pos[:, sel], max_subbox=1000, subboxsize=sub, sig=bench.SIG, dr=dr, ndens=ndens,
+                             xh_av=xh, loss_fraction=a.loss_fraction, thin=thin, thick=thick, minlogtau=bench.MINLOGTAU,
+                             dlogtau=dlog, R_max_LLS=R)
+        t_cpu = time.perf_counter() - t0
+        out.update({"cpu_reference_s": t_cpu, "cpu_sources": int(m), "cpu_cores": 1,
+                    "cpu_s_per_source": t_cpu / m, "speedup_same_sources": (t_cpu / m) * ns / t_gpu,
+                    "cpu_nsubbox": r["nsubbox"], "cpu_photon_loss": r["photon_loss"]})
+        if m == ns:
+            ref = r["phi_ion"]
+            w = ref != 0
+            out["phi_max_rel_diff_vs_reference"] = float(np.max(np.abs(phi[w] - ref[w]) / ref[w]))
+            out["phi_cells_compared"] = int(w.sum())
+            out["same_support"] = bool(np.array_equal(w, phi != 0))
+    print(json.dumps(out), flush=True)
