@@ -161,6 +161,9 @@ def main():
     ap.add_argument("--cpu-sources", type=int, default=64, help="sources in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--z-transposed", type=int, default=1)
     ap.add_argument("--block-threads", type=int, default=0, help="raytrace workgroup size (0 = auto)")
+    ap.add_argument("--overlap", type=int, default=-1,
+                    help="N>1: 1 = pipeline the all-reduce of the rate grid with the raytrace (sources traced in order of "
+                         "their first coordinate), 0 = trace, then all-reduce; default: env PYC2RAY_AMD_OVERLAP or 0")
     ap.add_argument("--sectors", type=int, default=0, help="0 auto, 1 octant workgroups, 2 octant x sector workgroups")
     args = ap.parse_args()
 
@@ -178,7 +181,13 @@ def main():
     from pyc2ray_amd.utils.sourceutils import format_sources
 
     comm = None
+    saved_stdout = None
     if world > 1 or os.environ.get("PYC2RAY_AMD_FORCE_COLLECTIVE", "0") == "1":
+        # RCCL prints a version banner on stdout when its first communicator comes up; the contract is ONE JSON
+        # line on stdout, so everything before that line is sent to stderr (at the file-descriptor level)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch
         import torch.distributed as dist
         from pyc2ray_amd.dist import TorchComm, init_process_group_from_env
@@ -193,7 +202,16 @@ def main():
 
     ndens, xh, temp, dr, pos, flux = make_workload(args.workload, N, args.nsrc * world)
     lo, hi = rank * args.nsrc, (rank + 1) * args.nsrc          # contiguous block per rank (evolve.py:362-367)
-    p0, f0 = format_sources(pos[:, lo:hi], flux[lo:hi])
+    my_pos, my_flux = pos[:, lo:hi], flux[lo:hi]
+    overlap = comm is not None and (args.overlap == 1 or (args.overlap < 0 and comm.overlap))
+    src_i0 = None
+    if overlap:
+        comm.overlap = True
+        my_pos, my_flux = comm.sort_sources_for_overlap(my_pos, my_flux)
+        src_i0 = my_pos[0].astype(np.int64) - 1
+    elif comm is not None:
+        comm.overlap = False
+    p0, f0 = format_sources(my_pos, my_flux)
     lib.source_data_to_device(p0, f0, args.nsrc)
     lib.grid_to_device(_capi.GRID_NDENS, ndens)
     lib.grid_to_device(_capi.GRID_TEMP, temp)
@@ -205,9 +223,10 @@ def main():
     def step():
         lib.grid_copy(_capi.GRID_XH_AV, _capi.GRID_XH)
         lib.grid_copy(_capi.GRID_XH_INTERMED, _capi.GRID_XH)
-        lib.raytrace_device(args.R, SIG, dr, 0, args.nsrc, MINLOGTAU, dlog, numtau)
         if comm is not None:
-            comm.allreduce_device_grid(lib, _capi.GRID_PHI_ION, N)
+            comm.raytrace_and_allreduce(lib, N, args.R, SIG, dr, args.nsrc, MINLOGTAU, dlog, numtau, src_i0=src_i0)
+        else:
+            lib.raytrace_device(args.R, SIG, dr, 0, args.nsrc, MINLOGTAU, dlog, numtau)
         return lib.chemistry_device(MYR, BH00, ALBPOW, COLH0, TEMPH0, ABU_C)
 
     def fence():
@@ -278,7 +297,8 @@ def main():
         "config": {
             "workload": workload_label(args.workload, N, args.nsrc, args.R),
             "grid": N, "sources_per_gpu": args.nsrc, "R_cells": args.R, "numtau": NUMTAU,
-            "parallelism": f"sources x{world}" if world > 1 else "single GPU",
+            "parallelism": (f"sources x{world}, rate-grid all-reduce " + ("pipelined with the trace" if overlap else "after the trace"))
+                           if world > 1 else "single GPU",
             "unit_definition": "rate-receiving (source,cell) pairs (|d|<=R) + N^3 chemistry cells per step",
             "raytrace_updates_per_step": tot_gamma,
             "chemistry_updates_per_step": N ** 3,
@@ -330,8 +350,13 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "cell-updates/s", "cores": 1, "kind": "port",
                                    "sample": f"failed: {type(e).__name__}: {e}"}
     p.device_close()
-    print(json.dumps(out))
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+    print(json.dumps(out), flush=True)
     if comm is not None:
+        os.dup2(2, 1)              # nothing after the JSON line may reach stdout
         dist.destroy_process_group()
 
 

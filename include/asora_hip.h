@@ -143,6 +143,22 @@ void *asora_device_ptr(int which);
 int asora_raytrace_device(double R, double sig, double dr, int src_begin, int src_count,
                           double minlogtau, double dlogtau, int NumTau);
 
+/* The same raytrace in three parts, for callers that overlap the multi-GPU sum of the rate grid with the trace
+ * (one process per GPU; pyc2ray_amd/dist.py): with the sources uploaded in ascending order of their first
+ * coordinate, the planes phi_ion[i][:][:] a chunk of sources can no longer reach are final and can be summed
+ * across GPUs (RCCL on asora_device_ptr(ASORA_GRID_PHI_ION), ordered after asora_stream()) while the next chunk
+ * is being traced.
+ *   asora_raytrace_begin  zeroes the accumulators, forms nHI, fixes the parameters of the call;
+ *   asora_raytrace_range  traces sources [src_begin, src_begin + src_count) into the accumulators (asynchronous);
+ *   asora_raytrace_fold   completes planes [i_begin, i_begin + i_count) of phi_ion (adds the z-face accumulator,
+ *                         which is kept in [k][j][i] order); every plane must be folded exactly once per call.
+ * asora_raytrace_device(...) == begin; range(all); fold(0, N). */
+int asora_raytrace_begin(double R, double sig, double dr, double minlogtau, double dlogtau, int NumTau);
+int asora_raytrace_range(int src_begin, int src_count);
+int asora_raytrace_fold(int i_begin, int i_count);
+/* The HIP stream (hipStream_t) all of the library's work is ordered on. */
+void *asora_stream(void);
+
 /* One chemistry pass on the device-resident grids (ndens, temp, xh, xh_av, xh_intermed,
  * phi_ion): global_pass + the three reductions of pyc2ray/evolve.py:216-217.
  * Outputs: conv_flag (chemistry.f90:99-104), sum(xh_intermed), sum(1-xh_intermed). */

@@ -41,6 +41,10 @@ SIGNATURES = {
     "asora_device_ptr": (C.c_void_p, [C.c_int]),
     "asora_raytrace_device": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double,
                                         C.c_double, C.c_int]),
+    "asora_raytrace_begin": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]),
+    "asora_raytrace_range": (C.c_int, [C.c_int, C.c_int]),
+    "asora_raytrace_fold": (C.c_int, [C.c_int, C.c_int]),
+    "asora_stream": (C.c_void_p, []),
     "asora_chemistry_device": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                          C.POINTER(C.c_int), _dp, _dp]),
     "asora_set_option": (C.c_int, [C.c_int, C.c_int]),

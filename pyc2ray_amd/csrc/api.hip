@@ -26,6 +26,7 @@ static int flush_timers()
     State &st = g_state;
     if (st.pending_timers.empty()) return 0;
     ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    for (hipStream_t s : st.side) if (s) ASORA_HIP_TRY(hipStreamSynchronize(s));
     for (auto &pt : st.pending_timers) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, pt.e0, pt.e1) == hipSuccess) {
@@ -48,18 +49,19 @@ static hipEvent_t take_event()
     return e;
 }
 
-KernelTimer::KernelTimer(int w) : which(w), on(g_state.opt[ASORA_OPT_TIMING] != 0 && g_state.stream != nullptr)
+KernelTimer::KernelTimer(int w, hipStream_t s)
+    : which(w), on(g_state.opt[ASORA_OPT_TIMING] != 0 && g_state.stream != nullptr), stream(s ? s : g_state.stream)
 {
     if (!on) return;
     if (g_state.pending_timers.size() >= 4096) (void)flush_timers();
     e0 = take_event();
     e1 = take_event();
-    (void)hipEventRecord(e0, g_state.stream);
+    (void)hipEventRecord(e0, stream);
 }
 KernelTimer::~KernelTimer()
 {
     if (!on) return;
-    (void)hipEventRecord(e1, g_state.stream);
+    (void)hipEventRecord(e1, stream);
     g_state.pending_timers.push_back({which, e0, e1});
 }
 
@@ -73,6 +75,11 @@ static int ensure_runtime()
     ASORA_HIP_TRY(hipGetDeviceProperties(&prop, st.device));
     st.cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ASORA_HIP_TRY(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
+    for (int q = 0; q < 2; ++q) {
+        ASORA_HIP_TRY(hipStreamCreateWithFlags(&st.side[q], hipStreamNonBlocking));
+        ASORA_HIP_TRY(hipEventCreateWithFlags(&st.side_done[q], hipEventDisableTiming));
+    }
+    ASORA_HIP_TRY(hipEventCreateWithFlags(&st.main_ready, hipEventDisableTiming));
     st.red_blocks = chemistry_reduction_blocks(st);
     ASORA_HIP_TRY(hipMalloc(&st.red_partial, sizeof(double) * 3 * st.red_blocks));
     ASORA_HIP_TRY(hipMalloc(&st.red_final, sizeof(double) * 3));
@@ -95,6 +102,7 @@ static int release_all()
     drop(st.shell_scratch); st.shell_scratch_bytes = 0;
     release_geometry(st);
     st.init = false; st.N = 0; st.ncell = 0;
+    st.rt_open = false;
     return 0;
 }
 
@@ -112,18 +120,20 @@ static int check_N(const char *who, int N)
     return 0;
 }
 
-static int do_raytrace(double R, double sig, double dr, int src_begin, int src_count, double minlogtau,
-                       double dlogtau, int NumTau, double *dump)
+// A raytrace call in three parts, so that a caller can overlap the multi-GPU sum of finished slabs of the
+// rate grid with the tracing of later sources (asora_raytrace_begin / _range / _fold):
+//   rt_begin  checks, zeroes the accumulators (raytracing.cu:113), forms nHI, fixes the parameters;
+//   rt_range  traces a range of the uploaded sources into the accumulators (asynchronous);
+//   rt_fold   adds the [k][j][i] accumulator of the z-faces into phi_ion for a slab of i-planes.
+static int rt_begin(double R, double sig, double dr, double minlogtau, double dlogtau, int NumTau, double *dump,
+                    bool pipelined = false)
 {
     State &st = g_state;
+    st.rt_open = false;
     if (!st.grid_valid[ASORA_GRID_NDENS]) return fail(4, "raytrace: density not on device (density_to_device)");
     if (!st.grid_valid[ASORA_GRID_XH_AV]) return fail(4, "raytrace: xh_av not on device");
     if (!st.opt[ASORA_OPT_GREY_NOTABLES] && !st.tables)
         return fail(4, "raytrace: radiation tables not on device (photo_table_to_device)");
-    if (src_begin < 0 || src_count < 0 || src_begin + src_count > st.num_src)
-        return fail(4, "raytrace: source range [" + std::to_string(src_begin) + "," +
-                           std::to_string(src_begin + src_count) + ") outside the " + std::to_string(st.num_src) +
-                           " uploaded sources (source_data_to_device)");
     if (!(R >= 0.0)) return fail(4, "raytrace: R must be >= 0");
     if (NumTau < 1 && !st.opt[ASORA_OPT_GREY_NOTABLES]) return fail(4, "raytrace: NumTau must be >= 1");
 
@@ -141,7 +151,7 @@ static int do_raytrace(double R, double sig, double dr, int src_begin, int src_c
     ASORA_HIP_TRY(hipMemsetAsync(st.counters, 0, sizeof(unsigned long long) * 2, st.stream));
     if (int rc = launch_prepare_nhi(st, zt)) return rc;
 
-    RtParams p;
+    RtParams &p = st.rt_params;
     std::memset(&p, 0, sizeof p);
     p.N = st.N;
     p.R = R; p.sig = sig; p.dr = dr;
@@ -151,7 +161,6 @@ static int do_raytrace(double R, double sig, double dr, int src_begin, int src_c
     p.fortran_consts = st.opt[ASORA_OPT_FORTRAN_CONSTANTS];
     p.grey = st.opt[ASORA_OPT_GREY_NOTABLES];
     p.z_transposed = zt ? 1 : 0;
-    p.src_begin = src_begin; p.src_count = src_count;
     p.ncell = (unsigned)st.ncell;
     p.nhi = st.nhi;
     p.phi = st.grid[ASORA_GRID_PHI_ION];
@@ -163,14 +172,73 @@ static int do_raytrace(double R, double sig, double dr, int src_begin, int src_c
 #ifdef ASORA_ENABLE_ABLATION
     { const char *ab = getenv("ASORA_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
 #endif
-    if (int rc = launch_raytrace(st, p, dump != nullptr, heat)) return rc;
-    if (zt) {
-        if (int rc = launch_finish_phi(st)) return rc;
-        if (heat)
-            if (int rc = launch_fold_transposed(st, st.heat_t, st.grid[ASORA_GRID_PHI_HEAT])) return rc;
+    st.rt_heat = heat;
+    st.rt_pipelined = pipelined;
+    if (pipelined) {       // the side streams start behind the zeroed accumulators and nHI
+        ASORA_HIP_TRY(hipEventRecord(st.main_ready, st.stream));
+        for (int q = 0; q < 2; ++q) {
+            ASORA_HIP_TRY(hipStreamWaitEvent(st.side[q], st.main_ready, 0));
+            st.side_pending[q] = false;
+        }
+        st.side_next = 0;
+    }
+    st.rt_open = true;
+    return 0;
+}
+
+static int rt_range(int src_begin, int src_count)
+{
+    State &st = g_state;
+    if (!st.rt_open) return fail(4, "raytrace_range: no raytrace in progress (call asora_raytrace_begin)");
+    if (src_begin < 0 || src_count < 0 || src_begin + src_count > st.num_src)
+        return fail(4, "raytrace: source range [" + std::to_string(src_begin) + "," +
+                           std::to_string(src_begin + src_count) + ") outside the " + std::to_string(st.num_src) +
+                           " uploaded sources (source_data_to_device)");
+    if (src_count == 0) return 0;
+    RtParams p = st.rt_params;
+    p.src_pos = st.src_pos; p.src_flux = st.src_flux;
+    p.src_begin = src_begin; p.src_count = src_count;
+    if (!st.rt_pipelined) return launch_raytrace(st, p, p.dump != nullptr, st.rt_heat);
+    const int q = st.side_next;
+    st.side_next ^= 1;
+    if (int rc = launch_raytrace(st, p, p.dump != nullptr, st.rt_heat, st.side[q])) return rc;
+    ASORA_HIP_TRY(hipEventRecord(st.side_done[q], st.side[q]));
+    st.side_pending[q] = true;
+    return 0;
+}
+
+static int rt_fold(int i_begin, int i_count)
+{
+    State &st = g_state;
+    if (!st.rt_open) return fail(4, "raytrace_fold: no raytrace in progress (call asora_raytrace_begin)");
+    if (i_begin < 0 || i_count < 0 || i_begin + i_count > st.N) return fail(4, "raytrace_fold: bad plane range");
+    for (int q = 0; q < 2; ++q)       // everything traced so far must have landed
+        if (st.side_pending[q]) {
+            ASORA_HIP_TRY(hipStreamWaitEvent(st.stream, st.side_done[q], 0));
+            st.side_pending[q] = false;
+        }
+    if (st.rt_params.z_transposed && i_count > 0) {
+        if (int rc = launch_fold_range(st, st.phi_t, st.grid[ASORA_GRID_PHI_ION], i_begin, i_count)) return rc;
+        if (st.rt_heat)
+            if (int rc = launch_fold_range(st, st.heat_t, st.grid[ASORA_GRID_PHI_HEAT], i_begin, i_count)) return rc;
     }
     st.grid_valid[ASORA_GRID_PHI_ION] = true;
-    if (heat) st.grid_valid[ASORA_GRID_PHI_HEAT] = true;
+    if (st.rt_heat) st.grid_valid[ASORA_GRID_PHI_HEAT] = true;
+    return 0;
+}
+
+static int do_raytrace(double R, double sig, double dr, int src_begin, int src_count, double minlogtau,
+                       double dlogtau, int NumTau, double *dump)
+{
+    State &st = g_state;
+    if (src_begin < 0 || src_count < 0 || src_begin + src_count > st.num_src)
+        return fail(4, "raytrace: source range [" + std::to_string(src_begin) + "," +
+                           std::to_string(src_begin + src_count) + ") outside the " + std::to_string(st.num_src) +
+                           " uploaded sources (source_data_to_device)");
+    if (int rc = rt_begin(R, sig, dr, minlogtau, dlogtau, NumTau, dump)) return rc;
+    if (int rc = rt_range(src_begin, src_count)) return rc;
+    if (int rc = rt_fold(0, st.N)) return rc;
+    st.rt_open = false;
     return 0;
 }
 
@@ -388,6 +456,29 @@ int asora_raytrace_device(double R, double sig, double dr, int src_begin, int sr
     if (int rc = require_init("raytrace_device")) return rc;
     return do_raytrace(R, sig, dr, src_begin, src_count, minlogtau, dlogtau, NumTau, nullptr);
 }
+
+int asora_raytrace_begin(double R, double sig, double dr, double minlogtau, double dlogtau, int NumTau)
+{
+    clear_error();
+    if (int rc = require_init("raytrace_begin")) return rc;
+    return rt_begin(R, sig, dr, minlogtau, dlogtau, NumTau, nullptr, true);
+}
+
+int asora_raytrace_range(int src_begin, int src_count)
+{
+    clear_error();
+    if (int rc = require_init("raytrace_range")) return rc;
+    return rt_range(src_begin, src_count);
+}
+
+int asora_raytrace_fold(int i_begin, int i_count)
+{
+    clear_error();
+    if (int rc = require_init("raytrace_fold")) return rc;
+    return rt_fold(i_begin, i_count);
+}
+
+void *asora_stream(void) { return (void *)g_state.stream; }
 
 int asora_do_all_sources(double R, double *coldensh_out, double sig, double dr, const double *ndens,
                          const double *xh_av, double *phi_ion, int NumSrc, int m1, double minlogtau,

@@ -19,6 +19,34 @@ struct OctGeomDev {
     int info;                    // sign bits of the unit | (merge axis + 1) << 3 | rates-the-source-cell << 5
 };
 
+// Parameters of one raytrace launch (raytrace.hip)
+struct RtParams {
+    int N;
+    int S;                 // last Chebyshev shell over all octants
+    int max_cells;         // largest shell; slot max_cells of a shell buffer holds 0.0
+    double R;
+    double sig, dr;
+    double minlogtau, dlogtau, numtau_f;
+    double lut_k1, lut_k0; // table index = 1 + (log10 tau - minlogtau)/dlogtau = lut_k1*log2(tau) + lut_k0
+    int NumTau, table_len;
+    int fortran_consts, grey, z_transposed;
+    int src_begin, src_count;
+    int ablate;            // diagnostics only (env ASORA_ABLATE): 1 = no rate atomics, 2 = no rates
+    OctGeomDev geom[24];        // by value: pointers read from the kernarg segment are known-global to the compiler
+    int units;                  // workgroups per source: 8 octants, 24 octant-sectors, or 12 mirrored sector pairs
+    const double2 *logtab;      // 128 x {1/c, log2 c}
+    unsigned ncell;             // N^3: the [k][j][i] copy of a grid starts ncell elements after its [i][j][k] form
+    const double *nhi;          // nHI, [i][j][k] then [k][j][i]
+    double *phi;                // Gamma accumulator, [i][j][k] then [k][j][i]
+    const double2 *tables;      // pairs {T[i], T[i+1]-T[i]}: thick at [0, len), thin at [len, 2 len), heat thick at [2 len, 3 len), heat thin at [3 len, 4 len)
+    double *heat;               // heating accumulator (HEAT kernels), [i][j][k] then [k][j][i]
+    const int32_t *src_pos;
+    const double *src_flux;
+    double *dump;               // debug: outgoing column density (N^3) or nullptr
+    double *shell_scratch;      // global shell buffers when they do not fit LDS, else nullptr
+    unsigned long long *counters;
+};
+
 // ---------------------------------------------------------------------------------------------
 // Process-global device state (the role of src/asora/memory.cu:20-29)
 // ---------------------------------------------------------------------------------------------
@@ -60,6 +88,17 @@ struct State {
     int geom_N = 0, geom_S = 0, geom_max_cells = 0, geom_threads = 0;
     double geom_R = 0.0, geom_dr = 0.0;
 
+    // a raytrace call in progress (asora_raytrace_begin ... _range ... _fold)
+    RtParams rt_params;
+    bool rt_open = false, rt_heat = false;
+    // pipelined calls put consecutive source ranges on two side streams, so that the tail of one range and the
+    // head of the next overlap; folds (main stream) wait for the ranges issued before them
+    bool rt_pipelined = false;
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t side_done[2] = {nullptr, nullptr}, main_ready = nullptr;
+    bool side_pending[2] = {false, false};
+    int side_next = 0;
+
     // shell scratch for traces whose shell buffers exceed LDS
     double *shell_scratch = nullptr;
     size_t shell_scratch_bytes = 0;
@@ -98,46 +137,22 @@ void clear_error();
 struct KernelTimer {
     int which;
     bool on;
+    hipStream_t stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    explicit KernelTimer(int w);
+    explicit KernelTimer(int w, hipStream_t s = nullptr);   // s = nullptr: the library's main stream
     ~KernelTimer();
 };
 
 // ---------------------------------------------------------------------------------------------
 // Raytracing (raytrace.hip)
 // ---------------------------------------------------------------------------------------------
-struct RtParams {
-    int N;
-    int S;                 // last Chebyshev shell over all octants
-    int max_cells;         // largest shell; slot max_cells of a shell buffer holds 0.0
-    double R;
-    double sig, dr;
-    double minlogtau, dlogtau, numtau_f;
-    double lut_k1, lut_k0; // table index = 1 + (log10 tau - minlogtau)/dlogtau = lut_k1*log2(tau) + lut_k0
-    int NumTau, table_len;
-    int fortran_consts, grey, z_transposed;
-    int src_begin, src_count;
-    int ablate;            // diagnostics only (env ASORA_ABLATE): 1 = no rate atomics, 2 = no rates
-    OctGeomDev geom[24];        // by value: pointers read from the kernarg segment are known-global to the compiler
-    int units;                  // workgroups per source: 8 octants, 24 octant-sectors, or 12 mirrored sector pairs
-    const double2 *logtab;      // 128 x {1/c, log2 c}
-    unsigned ncell;             // N^3: the [k][j][i] copy of a grid starts ncell elements after its [i][j][k] form
-    const double *nhi;          // nHI, [i][j][k] then [k][j][i]
-    double *phi;                // Gamma accumulator, [i][j][k] then [k][j][i]
-    const double2 *tables;      // pairs {T[i], T[i+1]-T[i]}: thick at [0, len), thin at [len, 2 len), heat thick at [2 len, 3 len), heat thin at [3 len, 4 len)
-    double *heat;               // heating accumulator (HEAT kernels), [i][j][k] then [k][j][i]
-    const int32_t *src_pos;
-    const double *src_flux;
-    double *dump;               // debug: outgoing column density (N^3) or nullptr
-    double *shell_scratch;      // global shell buffers when they do not fit LDS, else nullptr
-    unsigned long long *counters;
-};
 
 void release_geometry(State &st);
+int launch_fold_range(State &st, const double *src_t, double *dst, int i_begin, int i_count);   // dst[i][j][k] += src_t[k][j][i], i in the range
 int ensure_logtab(State &st);
 int launch_prepare_nhi(State &st, bool need_transposed);
 int launch_finish_phi(State &st);
-int launch_raytrace(State &st, RtParams &p, bool dump, bool heat);
+int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t side = nullptr);   // side: stream to launch on when no shared scratch is needed
 int launch_fold_transposed(State &st, const double *src_t, double *dst);   // dst[i][j][k] += src_t[k][j][i]
 int launch_transpose(State &st, const double *src, double *dst, int N);   // dst[k][j][i] = src[i][j][k]
 

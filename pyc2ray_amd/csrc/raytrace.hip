@@ -817,6 +817,35 @@ int launch_fold_transposed(State &st, const double *src_t, double *dst)
     return 0;
 }
 
+// dst[i][j][k] += src_t[k][j][i] for i in [i_begin, i_begin + i_count): the slab's share of the fold
+__global__ void __launch_bounds__(256) fold_range_kernel(const double *__restrict__ src_t, double *__restrict__ dst, int N,
+                                                         int i_begin, int i_end)
+{
+    __shared__ double tile[32][33];
+    const int j = blockIdx.y;
+    const int kb = blockIdx.z * 32, ib = i_begin + blockIdx.x * 32;       // src_t tile: rows k, columns i
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int k = kb + r, i = ib + threadIdx.x;
+        if (k < N && i < i_end) tile[r][threadIdx.x] = src_t[((size_t)k * N + j) * N + i];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int i = ib + r, k = kb + threadIdx.x;
+        if (i < i_end && k < N) dst[((size_t)i * N + j) * N + k] += tile[threadIdx.x][r];
+    }
+}
+
+int launch_fold_range(State &st, const double *src_t, double *dst, int i_begin, int i_count)
+{
+    if (i_count <= 0) return 0;
+    KernelTimer kt(ASORA_KERNEL_FINISH);
+    const unsigned tk = (st.N + 31) / 32, ti = (i_count + 31) / 32;
+    hipLaunchKernelGGL(fold_range_kernel, dim3(ti, st.N, tk), dim3(32, 8), 0, st.stream, src_t, dst, st.N, i_begin,
+                       i_begin + i_count);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_transpose(State &st, const double *src, double *dst, int N)
 {
     hipLaunchKernelGGL(transpose_ik_kernel<false>, tile_grid(N), dim3(32, 8), 0, st.stream, src, dst, N);
@@ -857,14 +886,15 @@ static void pick_launch_shape(const State &st, double R, int N, bool dump, int &
 constexpr size_t lds_table_bytes(int tabcap) { return LOG_TABLE_SIZE * sizeof(double2) + (size_t)tabcap * (sizeof(double) + 4 * sizeof(int)); }
 
 template <int T, int TABCAP>
-static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t lds_bytes, bool use_lds, bool dump, bool heat)
+static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t lds_bytes, bool use_lds, bool dump, bool heat,
+                          hipStream_t stream)
 {
 #define ASORA_LAUNCH(GS, DP, HT)                                                                                   \
     do {                                                                                                           \
         ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, GS, DP, HT, TABCAP>,             \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));            \
         hipLaunchKernelGGL((raytrace_octant_kernel<T, GS, DP, HT, TABCAP>), dim3(grid), dim3(T), lds_bytes,        \
-                           st.stream, q);                                                                          \
+                           stream, q);                                                                          \
     } while (0)
     if (T == 256 && dump) { if (use_lds) ASORA_LAUNCH(false, true, false); else ASORA_LAUNCH(true, true, false); }
     else if (heat)        { if (use_lds) ASORA_LAUNCH(false, false, true); else ASORA_LAUNCH(true, false, true); }
@@ -874,7 +904,7 @@ static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t ld
     return 0;
 }
 
-int launch_raytrace(State &st, RtParams &p, bool dump, bool heat)
+int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t side)
 {
     int units, threads;   // one workgroup per (source, octant) or per (source, octant, sector)
     pick_launch_shape(st, p.R, p.N, dump, units, threads);
@@ -896,6 +926,12 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat)
     const size_t shell_bytes = 2 * slots * sizeof(double);
     const bool use_lds = shell_bytes + fixed_bytes <= LDS_LIMIT_BYTES;
     const size_t lds_bytes = (use_lds ? shell_bytes : 0) + fixed_bytes;
+    // launches that share the global shell scratch stay on the main stream (one at a time)
+    hipStream_t stream = (side && use_lds) ? side : st.stream;
+    if (side && !use_lds) {       // ... behind whatever the side streams still run, and the side streams behind it
+        for (int q = 0; q < 2; ++q)
+            if (st.side_pending[q]) ASORA_HIP_TRY(hipStreamWaitEvent(st.stream, st.side_done[q], 0));
+    }
 
     int done = 0;
     while (done < p.src_count) {
@@ -922,16 +958,16 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat)
         q.shell_scratch = use_lds ? nullptr : st.shell_scratch;
         const unsigned grid = 8u * (unsigned)units * (unsigned)((batch + 7) / 8);
         {
-            KernelTimer kt(ASORA_KERNEL_RAYTRACE);
+            KernelTimer kt(ASORA_KERNEL_RAYTRACE, stream);
             int rc = 0;
             if (big_tables) {
-                if (threads == 512) rc = launch_variant<512, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat);
-                else                rc = launch_variant<256, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat);
+                if (threads == 512) rc = launch_variant<512, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat, stream);
+                else                rc = launch_variant<256, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat, stream);
             } else switch (threads) {
-                case 64:  rc = launch_variant<64, 256>(st, q, grid, lds_bytes, use_lds, dump, heat); break;
-                case 128: rc = launch_variant<128, 256>(st, q, grid, lds_bytes, use_lds, dump, heat); break;
-                case 512: rc = launch_variant<512, 256>(st, q, grid, lds_bytes, use_lds, dump, heat); break;
-                default:  rc = launch_variant<256, 256>(st, q, grid, lds_bytes, use_lds, dump, heat); break;
+                case 64:  rc = launch_variant<64, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream); break;
+                case 128: rc = launch_variant<128, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream); break;
+                case 512: rc = launch_variant<512, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream); break;
+                default:  rc = launch_variant<256, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream); break;
             }
             if (rc) return rc;
         }

@@ -6,6 +6,12 @@ iteration -- the sum of the per-rank photo-ionisation rate grids -- so that is t
 here: an all-reduce (backend "nccl" == RCCL over xGMI) applied IN PLACE to the device-resident
 phi_ion grid.  With the "gloo" backend (CPU tests) the grid is staged through the host.
 
+``TorchComm.raytrace_and_allreduce`` optionally PIPELINES that all-reduce with the raytrace
+(``PYC2RAY_AMD_OVERLAP=1`` or ``TorchComm(overlap=True)``): with a rank's sources sorted by their first
+coordinate and traced in chunks, the planes of the rate grid that later chunks can no longer reach are final
+on every rank, so their sum over ranks runs on a second stream while the next chunk is being traced; only the
+planes the last chunks touch are summed after the trace.
+
 ``TorchComm`` also offers the handful of mpi4py-style methods the reference's evolve3D_MPI calls
 (Get_rank, Get_size, Reduce, Bcast, Allreduce, Barrier), and ``MPI`` the constants it reads, so
 reference-style driver code can pass ``use_mpi=dist.MPI, comm=dist.TorchComm()``.
@@ -63,13 +69,18 @@ class _DevicePointer:
 class TorchComm:
     """Communicator over a torch.distributed process group."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, overlap=None, chunks=8):
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError("TorchComm: torch.distributed is not initialised "
                                "(call pyc2ray_amd.dist.init_process_group_from_env() first)")
         self._dist = dist
         self._group = group
+        if overlap is None:
+            overlap = os.environ.get("PYC2RAY_AMD_OVERLAP", "0") == "1"
+        self.overlap = bool(overlap)
+        self.chunks = int(os.environ.get("PYC2RAY_AMD_OVERLAP_CHUNKS", chunks))
+        self._comm_stream = None
 
     # -- mpi4py-flavoured surface ---------------------------------------------------------------
     def Get_rank(self):
@@ -139,3 +150,90 @@ class TorchComm:
             t = torch.from_numpy(host)
             self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
             libasora.grid_to_device(which, host)
+
+    # -- raytrace + sum over ranks, optionally pipelined ------------------------------------------------
+    @staticmethod
+    def sort_sources_for_overlap(src_pos, src_flux):
+        """Order a rank's sources by their first coordinate (what the pipelined path needs).  src_pos is
+        (3, n) 1-based; returns (src_pos, src_flux) reordered.  The sum over sources is order-independent
+        up to floating-point rounding."""
+        order = np.argsort(np.asarray(src_pos)[0], kind="stable")
+        return np.asarray(src_pos)[:, order], np.asarray(src_flux)[order]
+
+    @staticmethod
+    def final_plane_runs(N, chunks, R, c, reduced):
+        """Planes of the rate grid that are final once the sources of chunks 0..c (sources with 0-based first
+        coordinate < (c+1)*N//chunks) have been traced and that have not been summed yet, as a list of
+        half-open runs.  A later source sits at i >= (c+1)*N//chunks and reaches the planes i-R..i+R, wrapping
+        at most onto planes < R; the last chunk releases everything that is left.  Depends on (N, chunks, R)
+        only, so every rank derives the same runs."""
+        margin = int(np.ceil(R)) + 1
+        if c == chunks - 1:
+            want = ~reduced
+        else:
+            want = np.zeros(N, dtype=bool)
+            lo, hi = margin, (c + 1) * N // chunks - margin
+            if hi > lo:
+                want[lo:hi] = True
+            want &= ~reduced
+        runs, i = [], 0
+        while i < N:
+            if want[i]:
+                j = i
+                while j < N and want[j]:
+                    j += 1
+                runs.append((i, j))
+                i = j
+            else:
+                i += 1
+        return runs
+
+    def raytrace_and_allreduce(self, libasora, N, R, sig, dr, num_src_local, minlogtau, dlogtau, NumTau,
+                               src_i0=None):
+        """Trace this rank's sources and leave the sum over ranks of the rate grids in the device-resident
+        phi_ion grid.  Pipelined when self.overlap is set and `src_i0` (0-based first coordinates of the local
+        sources, ascending, in upload order) is given; otherwise trace, then all-reduce."""
+        from . import _capi
+        if not self.overlap or src_i0 is None:
+            libasora.raytrace_device(R, sig, dr, 0, num_src_local, minlogtau, dlogtau, NumTau)
+            self.allreduce_device_grid(libasora, _capi.GRID_PHI_ION, N)
+            return
+        import torch
+        src_i0 = np.asarray(src_i0)
+        if src_i0.size and np.any(np.diff(src_i0) < 0):
+            raise ValueError("raytrace_and_allreduce: sources must be uploaded in ascending order of their first "
+                             "coordinate (TorchComm.sort_sources_for_overlap)")
+        K = max(1, min(self.chunks, N))
+        starts = np.searchsorted(src_i0, [c * N // K for c in range(K + 1)], side="left")
+        starts[-1] = src_i0.size
+        nccl = self._backend() == "nccl"
+        force = os.environ.get("PYC2RAY_AMD_FORCE_COLLECTIVE", "0") == "1"
+        collective = self.Get_size() > 1 or force
+        if nccl and collective:
+            lib_stream = torch.cuda.ExternalStream(libasora.stream_ptr())
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream()
+            view = torch.as_tensor(_DevicePointer(libasora.device_ptr(_capi.GRID_PHI_ION), N ** 3), device="cuda")
+        reduced = np.zeros(N, dtype=bool)
+        libasora.raytrace_begin(R, sig, dr, minlogtau, dlogtau, NumTau)
+        for c in range(K):
+            libasora.raytrace_range(int(starts[c]), int(starts[c + 1] - starts[c]))
+            for a, b in self.final_plane_runs(N, K, R, c, reduced):
+                libasora.raytrace_fold(a, b - a)
+                reduced[a:b] = True
+                if not collective:
+                    continue
+                if nccl:
+                    done = torch.cuda.Event()
+                    done.record(lib_stream)                    # the slab is final once the library stream gets here
+                    self._comm_stream.wait_event(done)
+                    with torch.cuda.stream(self._comm_stream):
+                        self._dist.all_reduce(view[a * N * N:b * N * N], op=self._dist.ReduceOp.SUM, group=self._group)
+                else:                                          # gloo (CPU tests): staged through the host
+                    host = libasora.grid_to_host(_capi.GRID_PHI_ION, np.empty((N, N, N)))
+                    t = torch.from_numpy(host[a:b])
+                    self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
+                    libasora.grid_to_device(_capi.GRID_PHI_ION, host)
+        assert reduced.all()
+        if nccl and collective:
+            lib_stream.wait_stream(self._comm_stream)         # the chemistry (library stream) needs the sums

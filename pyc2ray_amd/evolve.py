@@ -151,7 +151,14 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
     else:
         i_start, i_end = 0, NumSrc
     NumSrc_local = i_end - i_start
-    srcpos_flat, normflux_flat = format_sources(np.asarray(src_pos)[:, i_start:i_end], src_flux[i_start:i_end])
+    my_pos, my_flux = np.asarray(src_pos)[:, i_start:i_end], src_flux[i_start:i_end]
+    # pipelined raytrace + all-reduce (pyc2ray_amd.dist, opt-in): the shard is traced in order of the first coordinate
+    pipelined = distributed and getattr(comm, "overlap", False) and hasattr(comm, "raytrace_and_allreduce")
+    src_i0 = None
+    if pipelined:
+        my_pos, my_flux = comm.sort_sources_for_overlap(my_pos, my_flux)
+        src_i0 = np.asarray(my_pos[0]).astype(np.int64) - 1
+    srcpos_flat, normflux_flat = format_sources(my_pos, my_flux)
     if distributed:
         printlog(f"...rank={rank:n} has {NumSrc_local:n} sources.", logfile, quiet)
 
@@ -185,12 +192,17 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
             printlog(f"Doing Raytracing (rank={rank:n})...", logfile, quiet, ' ')
         else:
             printlog("Doing Raytracing...", logfile, quiet, ' ')
-        libasora.raytrace_device(R_max_LLS, sig, dr, 0, NumSrc_local, minlogtau, dlogtau, NumTau)
-        if distributed:
+        if pipelined:
+            comm.raytrace_and_allreduce(libasora, N, R_max_LLS, sig, dr, NumSrc_local, minlogtau, dlogtau, NumTau,
+                                        src_i0=src_i0)
+            printlog(f"rank={rank:n} took {(time.time()-trt0) : .1e} s (sum over ranks pipelined).", logfile, quiet)
+        elif distributed:
+            libasora.raytrace_device(R_max_LLS, sig, dr, 0, NumSrc_local, minlogtau, dlogtau, NumTau)
             libasora.synchronize()
             printlog(f"rank={rank:n} took {(time.time()-trt0) : .1e} s.", logfile, quiet)
             _allreduce_phi(libasora, N, use_mpi, comm, rank)
         else:
+            libasora.raytrace_device(R_max_LLS, sig, dr, 0, NumSrc_local, minlogtau, dlogtau, NumTau)
             libasora.synchronize()
             printlog(f"took {(time.time()-trt0) : .1f} s.", logfile, quiet)
 

@@ -136,6 +136,19 @@ class _LibAsora:
                                                     float(minlogtau), float(dlogtau), int(NumTau)),
                     "raytrace_device")
 
+    def raytrace_begin(self, R, sig, dr, minlogtau, dlogtau, NumTau):
+        _capi.check(self._lib.asora_raytrace_begin(float(R), float(sig), float(dr), float(minlogtau), float(dlogtau),
+                                                   int(NumTau)), "raytrace_begin")
+
+    def raytrace_range(self, src_begin, src_count):
+        _capi.check(self._lib.asora_raytrace_range(int(src_begin), int(src_count)), "raytrace_range")
+
+    def raytrace_fold(self, i_begin, i_count):
+        _capi.check(self._lib.asora_raytrace_fold(int(i_begin), int(i_count)), "raytrace_fold")
+
+    def stream_ptr(self):
+        return self._lib.asora_stream()
+
     def chemistry_device(self, dt, bh00, albpow, colh0, temph0, abu_c):
         conv = C.c_int(0)
         s1 = C.c_double(0.0)

@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    overlap = len(sys.argv) > 5 and sys.argv[5] == "overlap"
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     import cases
@@ -20,7 +21,7 @@ def main():
 
     r, w, _ = pd.init_process_group_from_env("gloo")
     assert (r, w) == (rank, world)
-    comm = pd.TorchComm()
+    comm = pd.TorchComm(overlap=overlap, chunks=4)
     assert comm.Get_rank() == rank and comm.Get_size() == world
 
     # mpi4py-flavoured surface

@@ -42,6 +42,30 @@ class OracleAsora:
                                            self.flux[src_begin:src_begin + src_count], self.thin, self.thick,
                                            minlogtau, dlogtau, NumTau=NumTau, flags=O.ASORA_MODE)["phi_ion"]
 
+    # the three-part raytrace of the pipelined path
+    def raytrace_begin(self, R, sig, dr, minlogtau, dlogtau, NumTau):
+        N = self.g[0].shape[0]
+        self._rt = (R, sig, dr, minlogtau, dlogtau, NumTau)
+        self.g[2] = np.zeros((N, N, N))
+        self._folded = np.zeros(N, dtype=bool)
+
+    def raytrace_range(self, src_begin, src_count):
+        if src_count == 0:
+            return
+        R, sig, dr, minlogtau, dlogtau, NumTau = self._rt
+        sl = slice(3 * src_begin, 3 * (src_begin + src_count))
+        self.g[2] = self.g[2] + O.asora_do_all_sources(R, sig, dr, self.g[0], self.g[1], self.pos[sl],
+                                                       self.flux[src_begin:src_begin + src_count], self.thin,
+                                                       self.thick, minlogtau, dlogtau, NumTau=NumTau,
+                                                       flags=O.ASORA_MODE)["phi_ion"]
+
+    def raytrace_fold(self, i_begin, i_count):
+        assert not self._folded[i_begin:i_begin + i_count].any(), "a plane was folded twice"
+        self._folded[i_begin:i_begin + i_count] = True
+
+    def stream_ptr(self):
+        return 0
+
     def chemistry_device(self, dt, bh00, albpow, colh0, temph0, abu_c):
         xa, xi, conv, _ = O.global_pass(dt, self.g[0], self.g[3], self.g[4], self.g[1], self.g[5], self.g[2],
                                         bh00, albpow, colh0, temph0, abu_c)

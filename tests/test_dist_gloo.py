@@ -23,13 +23,36 @@ def _free_port():
     return str(port)
 
 
-def test_two_ranks_match_single_process(tmp_path):
+import pytest
+
+
+def test_final_plane_runs_cover_every_plane_once_and_never_early():
+    """The slab schedule of the pipelined all-reduce: every plane is released exactly once, and never before
+    the last source that can reach it (periodically) has been traced."""
+    from pyc2ray_amd.dist import TorchComm
+    for N, K, R in ((256, 8, 32.0), (256, 8, 16.0), (48, 5, 9.5), (32, 4, 3.2), (17, 3, 2.0), (16, 8, 40.0), (64, 1, 5.0)):
+        reduced = np.zeros(N, dtype=bool)
+        reach = int(np.floor(R))
+        for c in range(K):
+            runs = TorchComm.final_plane_runs(N, K, R, c, reduced)
+            for a, b in runs:
+                assert 0 <= a < b <= N and not reduced[a:b].any()
+                # a source traced later sits at i >= (c+1)*N//K and touches (i + d) mod N, |d| <= floor(R)
+                for i in range((c + 1) * N // K, N):
+                    touched = {(i + d) % N for d in range(-reach, reach + 1)}
+                    assert not touched.intersection(range(a, b)), (N, K, R, c, a, b, i)
+                reduced[a:b] = True
+        assert reduced.all()
+
+
+@pytest.mark.parametrize("mode", ["plain", "overlap"])
+def test_two_ranks_match_single_process(tmp_path, mode):
     world = 2
     port = _free_port()
     outs = [str(tmp_path / f"r{r}.npz") for r in range(world)]
     env = dict(os.environ, PYC2RAY_AMD_NO_TORCH="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), str(r), str(world), port,
-                               outs[r]], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                               outs[r], mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(world)]
     logs = [p.communicate(timeout=240)[0].decode() for p in procs]
     for p, log in zip(procs, logs):

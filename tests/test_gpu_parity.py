@@ -577,3 +577,53 @@ def test_heating_rates_match_fortran_path(asora, name, tmp_path):
                                   c["sig"], logfile=str(tmp_path / "log"), quiet=True)
     assert heat2 is None
     p.device_close()
+
+
+def test_pipelined_raytrace_allreduce_world1(asora, monkeypatch):
+    """The opt-in pipelined path (chunks of sources in order of their first coordinate, finished slabs of the
+    rate grid summed over ranks on a second stream while the next chunk is traced): one rank only, with the
+    collective forced, so that the chunking, the slab folds, the stream/event hand-over and RCCL on sub-ranges
+    of the library's grid are exercised; the result must equal the plain raytrace."""
+    import socket
+    import torch.distributed as dist
+    from pyc2ray_amd import dist as pd
+    p, lib, capi = asora
+    N = 48
+    nd, xh, dr = cases.grid(N, "lognormal", 61, 0.12)
+    pos, flux = cases.sources(N, 40, 62, flux=2.0)
+    flux = flux * (1.0 + 0.1 * np.arange(40))
+    thin, thick, dlog = cases.soft_tables()
+    c = dict(N=N, ndens=nd, xh=xh, dr=dr, pos=pos, flux=flux, thin=thin, thick=thick)
+    if not dist.is_initialized():
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        pd.init_process_group_from_env("nccl")
+    monkeypatch.setenv("PYC2RAY_AMD_FORCE_COLLECTIVE", "1")
+    numtau = thin.shape[0] - 1
+    for R in (5.0, 9.5, 30.0):                     # slabs final early / late / only at the end
+        _setup(p, lib, c, N)
+        lib.grid_to_device(capi.GRID_XH_AV, xh)
+        lib.raytrace_device(R, cases.SIG, dr, 0, 40, cases.MINLOGTAU, dlog, numtau)
+        plain = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+        for chunks in (8, 5, 1):
+            comm = pd.TorchComm(overlap=True, chunks=chunks)
+            spos, sflux = comm.sort_sources_for_overlap(pos, flux)
+            p0, f0 = cases.flat_sources(spos, sflux)
+            lib.source_data_to_device(p0, f0, 40)
+            comm.raytrace_and_allreduce(lib, N, R, cases.SIG, dr, 40, cases.MINLOGTAU, dlog, numtau,
+                                        src_i0=spos[0].astype(np.int64) - 1)
+            lib.synchronize()
+            piped = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+            np.testing.assert_allclose(piped, plain, rtol=1e-12, atol=1e-300)
+            assert np.array_equal(piped != 0, plain != 0)
+        with pytest.raises(ValueError, match="ascending"):
+            comm.raytrace_and_allreduce(lib, N, R, cases.SIG, dr, 40, cases.MINLOGTAU, dlog, numtau,
+                                        src_i0=(spos[0].astype(np.int64) - 1)[::-1])
+    # the three-part C-ABI refuses to be used out of order
+    p.device_close()
+    p.device_init(N, 8)
+    with pytest.raises(RuntimeError, match="no raytrace in progress"):
+        lib.raytrace_range(0, 0)
+    with pytest.raises(RuntimeError, match="no raytrace in progress"):
+        lib.raytrace_fold(0, N)
+    p.device_close()
