@@ -149,7 +149,72 @@ def cpu_baseline(kind, N, ndens, xh, temp, dr, pos, flux, thin, thick, dlog, R, 
     return use_ref, ns, t_rt, t_chem
 
 
+# ---- all host cores: independent processes over sources (the reference is single-threaded, sources are independent)
+def _cpu_worker():
+    """`python bench.py --cpu-worker`: one host core's share of the CPU sample.  Reads its job (one JSON line),
+    prepares the inputs, reports "ready", waits for "go", then times the reference raytracer on its sources and
+    one global_pass on its slab of the grid.  Never touches the GPU."""
+    job = json.loads(sys.stdin.readline())
+    from oracle import ref_fortran as F
+    from oracle import oracle as O
+    mod = F if F.available() else O
+    N = job["N"]
+    ndens, xh, temp, dr, pos, flux = make_workload(job["kind"], N, job["nsrc_total"])
+    t = np.load(job["tables"])
+    thin, thick, dlog = t["thin"], t["thick"], float(t["dlog"])
+    lo, hi = job["sources"]
+    a, b = job["planes"]
+    nd_f, xh_f = np.asfortranarray(ndens), np.asfortranarray(xh)
+    sl = lambda g: np.asfortranarray(g[a:b])
+    Ri = int(np.ceil(job["R"]))
+    print("ready", flush=True)
+    sys.stdin.readline()
+    t0 = time.time()
+    r = mod.do_all_sources(flux[lo:hi], pos[:, lo:hi], max_subbox=Ri, subboxsize=Ri, sig=SIG, dr=dr, ndens=nd_f,
+                           xh_av=xh_f, loss_fraction=0.0, thin=thin, thick=thick, minlogtau=MINLOGTAU, dlogtau=dlog,
+                           R_max_LLS=job["R"], NumTau=thin.shape[0] - 1)
+    t1 = time.time()
+    mod.global_pass(MYR, sl(ndens), sl(temp), sl(xh), sl(xh), sl(xh), sl(r["phi_ion"]), BH00, ALBPOW, COLH0, TEMPH0, ABU_C)
+    t2 = time.time()
+    print(json.dumps({"t_rt": t1 - t0, "t_chem": t2 - t1, "sources": hi - lo, "reference": bool(F.available())}), flush=True)
+
+
+def start_cpu_workers(cores, kind, N, nsrc_total, R, sample_sources, tables_path):
+    """Started BEFORE anything initialises the GPU in this process (no exec afterwards)."""
+    import subprocess
+    procs = []
+    for w in range(cores):
+        job = {"kind": kind, "N": N, "nsrc_total": nsrc_total, "R": R, "tables": tables_path,
+               "sources": [w * sample_sources // cores, (w + 1) * sample_sources // cores],
+               "planes": [w * N // cores, (w + 1) * N // cores]}
+        pr = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker"], stdin=subprocess.PIPE,
+                              stdout=subprocess.PIPE, text=True, cwd=ROOT)
+        pr.stdin.write(json.dumps(job) + "\n")
+        pr.stdin.flush()
+        procs.append(pr)
+    return procs
+
+
+def run_cpu_workers(procs):
+    """Wall-clock time of the sample on all workers at once; returns (wall_rt, wall_total, results)."""
+    for pr in procs:
+        if pr.stdout.readline().strip() != "ready":
+            raise RuntimeError("cpu worker failed to start")
+    t0 = time.time()
+    for pr in procs:
+        pr.stdin.write("go\n")
+        pr.stdin.flush()
+    res = [json.loads(pr.stdout.readline()) for pr in procs]
+    wall = time.time() - t0
+    for pr in procs:
+        pr.stdin.close()
+        pr.wait(timeout=60)
+    return wall, res
+
+
 def main():
+    if "--cpu-worker" in sys.argv:
+        return _cpu_worker()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -159,6 +224,8 @@ def main():
     ap.add_argument("--R", type=float, default=32.0)
     ap.add_argument("--workload", choices=["uniform", "cosmo"], default="uniform")
     ap.add_argument("--cpu-sources", type=int, default=64, help="sources in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-cores", type=int, default=0,
+                    help="host cores for the all-cores CPU figure (0 = min(8, cores available); 1 = skip it)")
     ap.add_argument("--z-transposed", type=int, default=1)
     ap.add_argument("--block-threads", type=int, default=0, help="raytrace workgroup size (0 = auto)")
     ap.add_argument("--overlap", type=int, default=-1,
@@ -174,6 +241,26 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     N, K, W = args.N, args.steps, args.warmup
+
+    # the all-cores CPU sample runs in worker processes that are started now, before this process touches the GPU,
+    # and sit idle until the GPU measurement is over
+    cpu_workers, cpu_cores, tables_path = None, 1, None
+    tables = None
+    if world == 1 and args.cpu_sources > 0 and args.cpu_cores != 1:
+        try:
+            avail = len(os.sched_getaffinity(0))
+            cpu_cores = args.cpu_cores if args.cpu_cores > 1 else min(8, avail)
+            if cpu_cores > 1:
+                import tempfile
+                tables = make_tables()
+                fd, tables_path = tempfile.mkstemp(suffix=".npz")
+                os.close(fd)
+                np.savez(tables_path, thin=tables[0], thick=tables[1], dlog=tables[2])
+                cpu_workers = start_cpu_workers(cpu_cores, args.workload, N, args.nsrc, args.R,
+                                                max(args.cpu_sources, cpu_cores), tables_path)
+        except Exception as e:
+            print(f"bench: all-cores CPU sample not started: {type(e).__name__}: {e}", file=sys.stderr)
+            cpu_workers = None
 
     import pyc2ray_amd as p
     from pyc2ray_amd import _capi
@@ -196,7 +283,7 @@ def main():
 
     lib = load_asora()
     p.device_init(N, 64, device_id=local_rank)
-    thin, thick, dlog = make_tables()
+    thin, thick, dlog = tables if tables is not None else make_tables()
     p.photo_table_to_device(thin, thick)
     numtau = thin.shape[0] - 1                  # as raytracing_benchmark/run_test.py:85 passes it
 
@@ -349,6 +436,27 @@ def main():
         except Exception as e:   # the baseline is reporting only; never let it hide the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "cell-updates/s", "cores": 1, "kind": "port",
                                    "sample": f"failed: {type(e).__name__}: {e}"}
+        if cpu_workers:
+            try:
+                wall, res = run_cpu_workers(cpu_workers)
+                ns_all = sum(r["sources"] for r in res)
+                wall_rt = max(r["t_rt"] for r in res)
+                wall_chem = max(r["t_chem"] for r in res)
+                t_job = wall_rt * (args.nsrc / ns_all) + wall_chem
+                out["cpu_baseline"]["all_cores"] = {
+                    "value": (gamma_cells + N ** 3) / t_job, "unit": "cell-updates/s", "cores": cpu_cores,
+                    "kind": "reference" if all(r["reference"] for r in res) else "port",
+                    "sample": (f"{cpu_cores} independent single-threaded processes, one per core: {ns_all} of {args.nsrc} "
+                               f"sources raytraced ({wall_rt:.2f} s for the slowest) and one global_pass over {N}^3 split "
+                               f"into {cpu_cores} slabs ({wall_chem:.2f} s); raytrace time scaled x{args.nsrc / ns_all:.1f}"),
+                }
+            except Exception as e:
+                out["cpu_baseline"]["all_cores"] = {"value": None, "sample": f"failed: {type(e).__name__}: {e}"}
+    if tables_path:
+        try:
+            os.unlink(tables_path)
+        except OSError:
+            pass
     p.device_close()
     if saved_stdout is not None:
         sys.stdout.flush()

@@ -133,12 +133,6 @@ __device__ __forceinline__ double photo_rate_per_atom(double flux, double cd_in,
 #define ASORA_RATE_ATOMIC(dst, v) unsafeAtomicAdd((dst), (v))
 #endif
 
-// 1: a cell's rate lookups are consumed one step after they are issued (hides their latency, costs ~19 VGPRs).
-// Measured on MI355X: no difference in kernel time (the kernel is bound by the atomic request rate), so off.
-#ifndef ASORA_DEFER
-#define ASORA_DEFER 0
-#endif
-
 // waves per SIMD the register allocation must leave room for (2nd argument of __launch_bounds__)
 #ifndef ASORA_MIN_WAVES
 #define ASORA_MIN_WAVES 1
@@ -230,9 +224,9 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
     // ---- shells 1..S, software-pipelined ------------------------------------------------------
     // The tables of a step do not depend on the medium, and the address of a cell's nHI only on
     // its table entry, so both are fetched ahead of the dependent arithmetic: tables two steps
-    // ahead, nHI one step ahead.  Rate evaluation trails the sweep by one step: the table lookups
-    // of step k are issued in step k and consumed (and the atomic issued) in step k+1, so their
-    // latency is covered by the next interpolation and never holds up the shell barrier.
+    // ahead, nHI one step ahead.  The rate lookups of a step are issued after its shell barrier, so
+    // their latency never holds the barrier up.  (Consuming them a step later was tried: no gain,
+    // 19 VGPRs -- the kernel is bound by the atomic request rate)
     // (The tables carry two all-invalid steps of padding at the end: prefetches stay in bounds.)
     auto nhi_address = [&](unsigned abc, unsigned flags, unsigned &idx) -> const double * {
         const bool neg = (flags & CELL_NEG) != 0;
@@ -251,13 +245,6 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
     // step's (its nHI is requested here), `pf_*` the register set the entry two steps ahead is
     // loaded into.  The loop below is unrolled three times with the three register sets rotating,
     // so the pipeline needs no register-to-register copies.
-    bool pend = false;
-    double pend_pref = 0.0, pend_dtau = 0.0;
-    bool pend_thick = false;
-    Lookup pend_A, pend_B;
-    pend_A.t.x = pend_A.t.y = pend_A.residual = 0.0; pend_B = pend_A;
-    double *pend_dst = p.phi;
-
     auto step = [&](unsigned e_pf, const uint4 &cur_A, const uint4 &cur_B, const double cur_nhi, const unsigned cur_idx,
                     const uint4 &nxt_A, double &nxt_nhi, unsigned &nxt_idx, uint4 &pf_A, uint4 &pf_B) {
         pf_A = cellA[e_pf];                                         // two steps ahead
@@ -333,39 +320,30 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
             double *tmp = prev; prev = cur; cur = tmp;
         }
 
-        // ---- rates, raytracing.cu:315-328 + rates.cu:16-41: retire the previous step's lookups,
-        // then issue this step's (consumed one step later)
-        auto retire = [&]() {
-            const double ta = lookup_value(pend_A), tb = lookup_value(pend_B);
-            const double v = pend_thick ? pend_pref * ta - pend_pref * tb : pend_pref * pend_dtau * ta;
-            ASORA_RATE_ATOMIC(pend_dst, v);
-            if (HEAT) {      // photorates.f90:118,124 with the same table index and residual
-                const double ha = lookup_heat(pend_A), hb = lookup_heat(pend_B);
-                const double h = pend_thick ? pend_pref * (ha - hb) : pend_pref * pend_dtau * ha;
-                unsafeAtomicAdd(p.heat + (pend_dst - p.phi), h);
-            }
-        };
-        if (ASORA_DEFER && pend) retire();
+        // ---- rates, raytracing.cu:315-328 + rates.cu:16-41 ---------------------------------------
         if (grey) {
             if (rated) unsafeAtomicAdd(dst, grey_rate_per_atom(flux, cd_in, cd_out, vol_nhi, p));
-            pend = false;
-        } else if (!wave_has_work) {
-            pend = false;
-        } else {
+        } else if (wave_has_work) {
             // (lanes without a rate run the lookups on whatever they hold: the index is clamped for any input)
             const double tau_in = cd_in * sig, tau_out = cd_out * sig;
             // TAU_PHOTO_LIMIT: rates.cu:7 (double 1e-7) or photorates.f90:69 (single 1e-7 promoted)
             const double limit = p.fortran_consts ? (double)1.0e-7f : 1.0e-7;
-            pend_pref = flux / vol_nhi;
-            pend_dtau = tau_out - tau_in;
-            pend_thick = fabs(pend_dtau) > limit;
+            const double pref = flux / vol_nhi;
+            const double dtau = tau_out - tau_in;
+            const bool thick = fabs(dtau) > limit;
             const double tau_thin = p.fortran_consts ? tau_in : tau_out;                 // photorates.f90:121 / rates.cu:37
-            const double2 *tab = p.tables + (pend_thick ? 0 : p.table_len);
-            pend_A = lookup_issue<HEAT>(tab, pend_thick ? tau_in : tau_thin, p, logtab);
-            pend_B = lookup_issue<HEAT>(tab, pend_thick ? tau_out : tau_thin, p, logtab);
-            pend_dst = dst;
-            pend = rated;
-            if (!ASORA_DEFER) { if (pend) retire(); pend = false; }
+            // one code path for both kinds of cell: per-lane table offset and arguments
+            const double2 *tab = p.tables + (thick ? 0 : p.table_len);
+            const Lookup A = lookup_issue<HEAT>(tab, thick ? tau_in : tau_thin, p, logtab);
+            const Lookup B = lookup_issue<HEAT>(tab, thick ? tau_out : tau_thin, p, logtab);
+            if (rated) {
+                const double ta = lookup_value(A), tb = lookup_value(B);
+                ASORA_RATE_ATOMIC(dst, thick ? pref * ta - pref * tb : pref * dtau * ta);
+                if (HEAT) {      // photorates.f90:118,124 with the same table index and residual
+                    const double ha = lookup_heat(A), hb = lookup_heat(B);
+                    unsafeAtomicAdd(p.heat + (dst - p.phi), thick ? pref * (ha - hb) : pref * dtau * ha);
+                }
+            }
         }
     };
 
@@ -383,17 +361,6 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
         step(e + 3 * RT_THREADS, A1, B1, nhi1, idx1, A2, nhi2, idx2, A0, B0);
         step(e + 4 * RT_THREADS, A2, B2, nhi2, idx2, A0, nhi0, idx0, A1, B1);
     }
-    if (pend) {
-        const double ta = lookup_value(pend_A), tb = lookup_value(pend_B);
-        const double v = pend_thick ? pend_pref * ta - pend_pref * tb : pend_pref * pend_dtau * ta;
-        ASORA_RATE_ATOMIC(pend_dst, v);
-        if (HEAT) {
-            const double ha = lookup_heat(pend_A), hb = lookup_heat(pend_B);
-            const double h = pend_thick ? pend_pref * (ha - hb) : pend_pref * pend_dtau * ha;
-            unsafeAtomicAdd(p.heat + (pend_dst - p.phi), h);
-        }
-    }
-
     // work accounting: one atomic per wave
     for (int o = 32; o > 0; o >>= 1) {
         n_gamma += __shfl_down(n_gamma, o);
