@@ -11,7 +11,7 @@
 namespace asora {
 
 // Source-independent geometry of one octant, tabulated on the host (raytrace.hip), device pointers.
-// A flat sequence of steps of 256 entries; see the table description above the kernel.
+// A flat sequence of steps of workgroup-size entries; see the table description above the kernel.
 struct OctGeomDev {
     const uint4 *cellA;          // { |di| | |dj|<<10 | |dk|<<20 | face<<30, own slot | flags, path (double) }
     const uint4 *cellB;          // shell-buffer slots of the four upstream corners in shell s-1

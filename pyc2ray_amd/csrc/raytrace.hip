@@ -7,7 +7,8 @@
 // summed over sources into phi_ion.
 //
 // How it is computed is different:
-//   * work item = (source, octant).  The 8 sign-octants of a source only share the three
+//   * work item = (source, unit), unit = octant, octant sector or pair of mirrored sectors (pick_launch_shape).
+//     The 8 sign-octants of a source only share the three
 //     coordinate planes through the source, and a cell on such a plane depends only on cells
 //     of the same plane (the "upstream" neighbour across a zero offset has bilinear weight
 //     exactly 0, cinterp_gpu raytracing.cu:378-408 with sign(0)=+1), so each octant re-derives
@@ -28,8 +29,8 @@
 //     raytracing.cu:311-315).
 //   * what does not depend on the source or on the medium -- which cells a shell holds, their
 //     path length and the shell-buffer slots of their four upstream corners -- is the same for
-//     all sources.  It is tabulated ONCE per (N, R) on the host (build_octant_geometry below,
-//     28 B per cell) and streamed from L2 by every workgroup, two steps ahead of its use.
+//     all sources.  It is tabulated ONCE per (N, R) on the host (build_unit_geometry below,
+//     32 B per cell) and streamed from L2 by every workgroup, two steps ahead of its use.
 //   * faces dj=s and di=s are rows along k, contiguous in the [i][j][k] grid.  Faces dk=s are
 //     rows along i, so they read nHI and accumulate Gamma through [k][j][i] transposed copies
 //     (rows contiguous again); the transposed accumulator is folded back once per call.
@@ -114,7 +115,7 @@ __device__ __forceinline__ double photo_rate_per_atom(double flux, double cd_in,
 // ---------------------------------------------------------------------------------------------
 // The octant kernel
 // ---------------------------------------------------------------------------------------------
-// Per-octant cell tables (built by build_octant_geometry): a flat sequence of "steps" of RT_THREADS
+// Per-octant cell tables (built by build_unit_geometry): a flat sequence of "steps" of RT_THREADS
 // entries; the cells of a shell fill whole steps (the last one padded with invalid entries), so
 // entry k*RT_THREADS + lane is what `lane` does in step k and the tables can be prefetched blindly.
 //   cellA[e] = { abc, own slot | VALID | LAST_OF_SHELL, path (double, 2 words) }

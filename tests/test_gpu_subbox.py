@@ -267,3 +267,44 @@ def test_do_raytracing_cpu_semantics_with_stats(libs):
                                   c["heat_thin"][:n], c["heat_thick"][:n], c["minlogtau"], c["dlogtau"], c["R"],
                                   c["sig"], logfile=os.devnull, quiet=True)
     _close(heat2, g["sb32_mid__heat"], RATE_RTOL)
+
+
+def test_randomised_subbox_parameters_against_oracle(libs):
+    """Seeded sweep over mesh sizes (odd and even), source counts and positions (corners included), ranges,
+    box steps, loss fractions and opacities: box counts, loss, rates, heating and column densities against the
+    oracle (R_max_LLS covers the boxes, so the loss is defined everywhere)."""
+    p, c2ray, asora, capi = libs
+    rng = np.random.default_rng(2027)
+    thin, thick, dlog = cases.soft_tables(400)
+    n = thin.shape[0]
+    ht, hk = 1e-11 * thin[::-1].copy(), 3e-12 * thick
+    seen_early_stop = seen_full = 0
+    for trial in range(24):
+        N = int(rng.choice([9, 12, 16, 20]))
+        ns = int(rng.integers(1, 5))
+        tau_cell = float(10 ** rng.uniform(-2.0, 0.7))
+        nd, xh, dr = cases.grid(N, "lognormal", 100 + trial, tau_cell)
+        pos = 1 + rng.integers(0, N, size=(3, ns))
+        if trial % 5 == 0:
+            pos[:, 0] = [1, N, 1]                                   # a corner source: the cube wraps on every axis
+        flux = rng.uniform(0.5, 4.0, size=ns)
+        max_subbox = int(rng.choice([1, 2, 3, N // 2 - 1, N // 2, 1000]))
+        subboxsize = int(rng.integers(1, 7))
+        lf = float(rng.choice([0.0, 1e-3, 0.05, 0.3, 0.9]))
+        _fresh(p, N)
+        phi = np.zeros((N, N, N), order="F"); heat = np.zeros((N, N, N), order="F"); cd = np.zeros((N, N, N), order="F")
+        nbox, loss = c2ray.raytracing.do_all_sources(flux, pos, max_subbox, subboxsize, cd, cases.SIG, dr, nd, xh, phi, heat,
+                                                     lf, thin, thick, ht, hk, cases.MINLOGTAU, dlog, 1000.0)
+        ref = O.do_all_sources(flux, pos, max_subbox, subboxsize, cases.SIG, dr, nd, xh, lf, thin, thick, cases.MINLOGTAU,
+                               dlog, 1000.0, heat_thin=ht, heat_thick=hk)
+        tag = f"trial {trial}: N={N} ns={ns} max_subbox={max_subbox} subboxsize={subboxsize} lf={lf} tau={tau_cell:.3g}"
+        assert nbox == ref["nsubbox"], tag
+        np.testing.assert_allclose(loss, ref["photon_loss"], rtol=RATE_RTOL, err_msg=tag)
+        assert np.array_equal(cd != 0, ref["coldens"] != 0), tag
+        np.testing.assert_allclose(cd, ref["coldens"], rtol=1e-11, err_msg=tag)
+        _close(phi, ref["phi_ion"], RATE_RTOL)
+        _close(heat, ref["phi_heat"], RATE_RTOL)
+        full = sum(-(-min(max_subbox, N // 2 - 1 + N % 2) // subboxsize) for _ in range(ns))
+        seen_early_stop += nbox < full
+        seen_full += nbox == full
+    assert seen_early_stop >= 3 and seen_full >= 3            # the sweep exercises both outcomes
