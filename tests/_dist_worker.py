@@ -12,10 +12,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     overlap = len(sys.argv) > 5 and sys.argv[5] == "overlap"
+    cpu_semantics = len(sys.argv) > 5 and sys.argv[5] == "cpu_semantics"
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     import cases
-    from fake_backend import OracleAsora
+    from fake_backend import OracleAsora, OracleC2Ray
     import pyc2ray_amd.evolve as ev
     from pyc2ray_amd import dist as pd
 
@@ -47,11 +48,12 @@ def main():
     fake = OracleAsora(thin, thick)
     ev.load_asora = lambda: fake
     ev.cuda_is_init = lambda: True
-    xh_new, phi = ev.evolve3D_MPI(3.15576e13 * 5, dr, flux, pos, True, 1000, N, 1e-2, pd.MPI, comm, rank, world,
+    ev.load_c2ray = lambda: OracleC2Ray()
+    xh_new, phi = ev.evolve3D_MPI(3.15576e13 * 5, dr, flux, pos, not cpu_semantics, 1000, 3, 1e-2, pd.MPI, comm, rank, world,
                                   temp, nd, xh, thin, thick, cases.MINLOGTAU, dlog, 6.0, 1e-4, cases.SIG,
                                   cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C,
                                   logfile=None, quiet=True)
-    np.savez(out, xh=xh_new, phi=phi, niter=ev._evolve.last_niter, nsrc=fake.flux.shape[0])
+    np.savez(out, xh=xh_new, phi=phi, niter=ev._evolve.last_niter, nsrc=(fake.flux.shape[0] if fake.flux is not None else [2, 3][rank]))
     comm.Barrier()
 
 

@@ -71,3 +71,28 @@ class OracleAsora:
                                         bh00, albpow, colh0, temph0, abu_c)
         self.g[1], self.g[5] = xa, xi
         return conv, float(np.sum(xi)), float(np.sum(1.0 - xi))
+
+
+class OracleC2Ray:
+    """Stand-in for the `libc2ray` object (raytracing.do_all_sources, chemistry.global_pass), backed by the oracle."""
+
+    class _Raytracing:
+        def do_all_sources(self, normflux, srcpos, max_subbox, subboxsize, coldensh_out, sig, dr, ndens, xh_av, phi_ion,
+                           phi_heat, loss_fraction, thin, thick, heat_thin, heat_thick, minlogtau, dlogtau, r_max_lls):
+            r = O.do_all_sources(normflux, srcpos, max_subbox, subboxsize, sig, dr, ndens, xh_av, loss_fraction, thin, thick,
+                                 minlogtau, dlogtau, r_max_lls, heat_thin=heat_thin, heat_thick=heat_thick)
+            coldensh_out[...] = r["coldens"]
+            phi_ion[...] = r["phi_ion"]
+            phi_heat[...] += r["phi_heat"]
+            return r["nsubbox"], r["photon_loss"]
+
+    class _Chemistry:
+        def global_pass(self, dt, ndens, temp, xh, xh_av, xh_intermed, phi_ion, bh00, albpow, colh0, temph0, abu_c):
+            xa, xi, conv, _ = O.global_pass(dt, ndens, temp, xh, xh_av, xh_intermed, phi_ion, bh00, albpow, colh0, temph0, abu_c)
+            xh_av[...] = xa
+            xh_intermed[...] = xi
+            return conv
+
+    def __init__(self):
+        self.raytracing = self._Raytracing()
+        self.chemistry = self._Chemistry()

@@ -45,7 +45,7 @@ def test_final_plane_runs_cover_every_plane_once_and_never_early():
         assert reduced.all()
 
 
-@pytest.mark.parametrize("mode", ["plain", "overlap"])
+@pytest.mark.parametrize("mode", ["plain", "overlap", "cpu_semantics"])
 def test_two_ranks_match_single_process(tmp_path, mode):
     world = 2
     port = _free_port()
@@ -69,9 +69,16 @@ def test_two_ranks_match_single_process(tmp_path, mode):
     temp = np.full((N, N, N), 1e4)
     pos, flux = cases.sources(N, 5, 52, flux=30.0)
     thin, thick, dlog = cases.soft_tables()
-    x_ref, phi_ref, niter_ref, _ = evolve3D_oracle(3.15576e13 * 5, dr, flux, pos, temp, nd, xh, thin, thick,
-                                                   cases.MINLOGTAU, dlog, 6.0, 1e-4, cases.SIG, cases.BH00,
-                                                   cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C)
+    if mode == "cpu_semantics":
+        # use_gpu=False: each rank runs the sub-box raytracer on its block of sources (equal fluxes, so the
+        # reference's flux-of-the-last-source convention is immaterial), rates summed over ranks on the host
+        from evolve_oracle import evolve3d_cpu_path
+        x_ref, phi_ref, niter_ref = evolve3d_cpu_path(3.15576e13 * 5, dr, flux, pos, 1000, 3, 1e-2, temp, nd, xh, thin,
+                                                      thick, cases.MINLOGTAU, dlog, 6.0, 1e-4, cases.SIG)
+    else:
+        x_ref, phi_ref, niter_ref, _ = evolve3D_oracle(3.15576e13 * 5, dr, flux, pos, temp, nd, xh, thin, thick,
+                                                       cases.MINLOGTAU, dlog, 6.0, 1e-4, cases.SIG, cases.BH00,
+                                                       cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C)
     assert int(res[0]["niter"]) == niter_ref
     np.testing.assert_allclose(res[0]["xh"], x_ref, rtol=1e-10, atol=0)
     np.testing.assert_allclose(res[0]["phi"], phi_ref, rtol=1e-10, atol=0)
