@@ -41,6 +41,9 @@ MPI = _MPIShim()
 def init_process_group_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
     Returns (rank, world_size, local_rank).  Backend defaults to nccl when a GPU is visible."""
+    # the host driver of these machines only supports dmabuf IPC: without this, RCCL's buffer registration across
+    # processes fails with "hipIpcGetMemHandle: invalid argument"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))

@@ -78,3 +78,47 @@ def test_c2ray_test_class_drives_the_gpu_path(tmp_path):
         pc2r.device_close()
     finally:
         os.chdir(cwd)
+
+
+@pytest.mark.gpu
+def test_c2ray_test_class_with_use_gpu_false_runs_the_subbox_semantics(tmp_path):
+    """use_gpu=False: the class logs "Using CPU Raytracing", never initialises the ASORA state, and its evolve3D /
+    do_raytracing go through the libc2ray-compatible entry points (sub-box raytracer + global_pass, host arrays in
+    Fortran order).  Against the ASORA path of the same step: the physics is the same, the traversal semantics
+    (cube vs sphere, Fortran constants) differ at the 1e-5 level the reference's two paths differ by."""
+    import pyc2ray_amd as pc2r
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        if pc2r.cuda_is_init():
+            pc2r.device_close()
+        N = 32
+        sim = pc2r.C2Ray_Test(PARAMS, N, False)
+        assert not pc2r.cuda_is_init() and sim.gpu is False
+        assert "Using CPU Raytracing" in open(sim.logfile).read()
+        with open("src.txt", "w") as f:
+            f.write("1\n16 16 16 1e54 1.0\n")
+        srcpos, srcflux = sim.read_sources("src.txt", 1)
+        zs = sim.generate_redshift_array(2, 5e7)
+        dt = sim.set_timestep(zs[0], zs[1], 1)
+        sim.density_init(zs[0])
+        sim.cosmo_evolve(dt)
+        xh0 = np.array(sim.xh, copy=True)
+        sim.evolve3D(dt, srcflux, srcpos)
+        assert sim.xh.flags.f_contiguous and sim.phi_ion.flags.f_contiguous
+        phi_stats = sim.do_raytracing(srcflux, srcpos)
+        assert len(phi_stats) == 2 and np.array_equal(sim.phi_ion, phi_stats[0])
+        log = open(sim.logfile).read()
+        assert "Average number of subboxes" in log and "Total photon loss" in log
+        # the same step on the ASORA path
+        gpu = pc2r.C2Ray_Test(PARAMS, N, True)
+        gpu.density_init(zs[0])
+        gpu.cosmo_evolve(dt)
+        assert np.array_equal(gpu.xh, xh0)
+        gpu.evolve3D(dt, srcflux, srcpos)
+        w = gpu.xh > 1e-3
+        assert w.sum() > 100
+        np.testing.assert_allclose(sim.xh[w], gpu.xh[w], rtol=2e-5)
+        pc2r.device_close()
+    finally:
+        os.chdir(cwd)
