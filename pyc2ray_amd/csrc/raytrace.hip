@@ -122,7 +122,8 @@ __device__ __forceinline__ double photo_rate_per_atom(double flux, double cd_in,
 //   cellB[e] = { slots of the four upstream corners in the previous shell's buffer }
 // Dynamic LDS: [log table: 128 x {1/c, log2 c}][1/s: TABCAP doubles][wrapped i(a), j(b), k(c), mirrored: 4*TABCAP ints]
 //              [shell buffer 0: max_cells+1 doubles][shell buffer 1: same]   (the last two unless GLOBAL_SCRATCH)
-// TABCAP = 256 (S <= 255) or 1024.
+// TABCAP = 64 (S <= 63, workgroups of 64 or 128 threads: small traces, where LDS decides how many workgroups a CU
+// holds), 256 (S <= 255) or 1024.
 // Slot max_cells of each shell buffer holds 0.0: upstream corners of weight 0 point there.
 // Diagnostic builds only (make EXTRA=-DASORA_ENABLE_ABLATION, tools/ablate.sh): ASORA_ABLATE=1 skips the rate
 // atomics, 2 the rates, 4 the shell barriers, to attribute kernel time.  Production builds contain none of it.
@@ -828,17 +829,17 @@ int launch_transpose(State &st, const double *src, double *dst, int N)
 static const size_t LDS_LIMIT_BYTES = 160 * 1024;
 
 // Decomposition and workgroup size.  Shells of a small trace do not fill 256 lanes (R=16: <= 310 cells per
-// octant shell); a large one needs so much LDS per octant that few workgroups fit a CU.  From about R = 28 on,
+// octant shell); a large one needs so much LDS per octant that few workgroups fit a CU.  From about R = 20 on,
 // one workgroup per pair of mirrored sectors wins: its rows are full chords of the sphere, which lowers the
 // number of 64-B atomic requests per rated cell (the binding resource) by ~15 %.
 // Thresholds from sweeps on MI355X (1000 sources, 256^3; tools/sweep_threads.sh):
-//   R <= 22: octants x 64 threads | ..27: octants x 128 | 28..35: sector pairs x 128 | 36..54: x 256 | >= 55: x 512
+//   R <= 19: octants x 64 threads | 20..27: sector pairs x 64 | 28..35: pairs x 128 | 36..54: x 256 | >= 55: x 512
 static void pick_launch_shape(const State &st, double R, int N, bool dump, int &units, int &threads)
 {
     const double r = std::min(R, 0.87 * N);                 // the window cuts the trace at ~sqrt(3)/2 N
     const double est_cells = 1.2 * r * r;                   // largest shell of an octant
-    if (est_cells <= 580.0) { units = 8; threads = 64; }
-    else if (est_cells <= 900.0) { units = 8; threads = 128; }
+    if (est_cells <= 450.0) { units = 8; threads = 64; }
+    else if (est_cells <= 900.0) { units = 12; threads = 64; }
     else if (est_cells <= 1500.0) { units = 12; threads = 128; }
     else if (est_cells <= 3500.0) { units = 12; threads = 256; }
     else { units = 12; threads = 512; }
@@ -889,8 +890,9 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
     const size_t slots = ((size_t)p.max_cells + 2) & ~(size_t)1;   // max_cells + zero slot, rounded to even (16-B alignment)
     // small tables (log table, 1/s, three wrapped-coordinate tables) at fixed capacity, then the shell buffers
     const bool big_tables = p.S + 1 > 256;
+    const bool small_tables = p.S + 1 <= 64 && threads <= 128;
     if (p.S + 1 > 1024) return fail(4, "raytrace: more than 1023 shells (mesh too large for this build)");
-    const size_t fixed_bytes = lds_table_bytes(big_tables ? 1024 : 256);
+    const size_t fixed_bytes = lds_table_bytes(big_tables ? 1024 : small_tables ? 64 : 256);
     const size_t shell_bytes = 2 * slots * sizeof(double);
     const bool use_lds = shell_bytes + fixed_bytes <= LDS_LIMIT_BYTES;
     const size_t lds_bytes = (use_lds ? shell_bytes : 0) + fixed_bytes;
@@ -931,6 +933,9 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
             if (big_tables) {
                 if (threads == 512) rc = launch_variant<512, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat, stream);
                 else                rc = launch_variant<256, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat, stream);
+            } else if (small_tables) {
+                if (threads == 64) rc = launch_variant<64, 64>(st, q, grid, lds_bytes, use_lds, dump, heat, stream);
+                else               rc = launch_variant<128, 64>(st, q, grid, lds_bytes, use_lds, dump, heat, stream);
             } else switch (threads) {
                 case 64:  rc = launch_variant<64, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream); break;
                 case 128: rc = launch_variant<128, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream); break;

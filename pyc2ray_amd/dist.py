@@ -110,7 +110,8 @@ class TorchComm:
     def Allreduce(self, sendbuf, recvbuf, op=None):
         """Sum-allreduce of a numpy buffer (mpi4py calling convention, IN_PLACE supported)."""
         out = self._buf(recvbuf)
-        src = out if sendbuf is MPI.IN_PLACE or sendbuf == MPI.IN_PLACE else self._buf(sendbuf)
+        in_place = isinstance(sendbuf, str) and sendbuf == MPI.IN_PLACE
+        src = out if in_place else self._buf(sendbuf)
         t = self._tensor_of(src)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
         out[...] = t.cpu().numpy().reshape(out.shape)
