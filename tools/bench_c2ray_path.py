@@ -78,4 +78,18 @@ for R in a.R:
             out["phi_max_rel_diff_vs_reference"] = float(np.max(np.abs(phi[w] - ref[w]) / ref[w]))
             out["phi_cells_compared"] = int(w.sum())
             out["same_support"] = bool(np.array_equal(w, phi != 0))
+            # the ASORA path (sphere of radius R only, device-resident) on the same inputs, Fortran-flavoured
+            # constants, against the same reference output
+            from pyc2ray_amd.utils.sourceutils import format_sources
+            p0, f0 = format_sources(pos, flux)
+            asora.photo_table_to_device(thin, thick, thin.shape[0])
+            asora.source_data_to_device(p0, f0, ns)
+            asora.grid_to_device(0, ndens)
+            asora.grid_to_device(1, xh)
+            asora.set_option(0, 1)       # ASORA_OPT_FORTRAN_CONSTANTS
+            asora.raytrace_device(R, bench.SIG, dr, 0, ns, bench.MINLOGTAU, dlog, thin.shape[0])
+            asora.set_option(0, 0)
+            phi_a = asora.grid_to_host(2, np.empty((N, N, N)))
+            out["asora_path_max_rel_diff_vs_reference"] = float(np.max(np.abs(phi_a[w] - ref[w]) / ref[w]))
+            out["asora_path_same_support"] = bool(np.array_equal(w, phi_a != 0))
     print(json.dumps(out), flush=True)
