@@ -182,7 +182,8 @@ enum {
     ASORA_OPT_TIMING = 2,
     /* 0: z-faces read/accumulate through the [k][j][i] transposed copies (default 1). */
     ASORA_OPT_Z_TRANSPOSED = 3,
-    /* Workgroup size of the raytrace kernel: 0 (default) = chosen from R; 64, 128, 256 or 512 force it. */
+    /* Workgroup size of the raytrace kernel: 0 (default) = chosen from R and the number of sources;
+     * 64, 128, 256, 512 or 1024 force it. */
     ASORA_OPT_BLOCK_THREADS = 4,
     /* Decomposition of a source: 0 (default) = chosen from R; 1 = one workgroup per octant;
      * 2 = one per octant and dominant-axis sector (24 per source, diagonal planes re-derived);

@@ -834,7 +834,7 @@ static const size_t LDS_LIMIT_BYTES = 160 * 1024;
 // number of 64-B atomic requests per rated cell (the binding resource) by ~15 %.
 // Thresholds from sweeps on MI355X (1000 sources, 256^3; tools/sweep_threads.sh):
 //   R <= 19: octants x 64 threads | 20..27: sector pairs x 64 | 28..35: pairs x 128 | 36..54: x 256 | >= 55: x 512
-static void pick_launch_shape(const State &st, double R, int N, bool dump, int &units, int &threads)
+static void pick_launch_shape(const State &st, double R, int N, int src_count, bool dump, int &units, int &threads)
 {
     const double r = std::min(R, 0.87 * N);                 // the window cuts the trace at ~sqrt(3)/2 N
     const double est_cells = 1.2 * r * r;                   // largest shell of an octant
@@ -843,12 +843,19 @@ static void pick_launch_shape(const State &st, double R, int N, bool dump, int &
     else if (est_cells <= 1500.0) { units = 12; threads = 128; }
     else if (est_cells <= 3500.0) { units = 12; threads = 256; }
     else { units = 12; threads = 512; }
+    // Few sources (fewer workgroups than CUs): the time of the call is the time of ONE workgroup, so cut a source
+    // into more (24 sectors) and wider pieces.  One source, 128^3, R = 64: 0.235 -> 0.146 ms (tools/sweep_single_source.sh)
+    if ((long)src_count * 12 < (long)st.cu_count) {
+        units = 24;
+        if (est_cells > 900.0) threads = std::max(threads, 512);
+        if (est_cells > 2500.0) threads = 1024;
+    }
     const int want_sectors = st.opt[ASORA_OPT_SECTORS];
     if (want_sectors == 1) units = 8;
     if (want_sectors == 2) units = 24;
     if (want_sectors == 3) units = 12;
     const int forced = st.opt[ASORA_OPT_BLOCK_THREADS];
-    if (forced == 64 || forced == 128 || forced == 256 || forced == 512) threads = forced;
+    if (forced == 64 || forced == 128 || forced == 256 || forced == 512 || forced == 1024) threads = forced;
     if (dump) threads = 256;                                // the column-density dump variant is built for 256 only
 }
 
@@ -876,7 +883,7 @@ static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t ld
 int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t side)
 {
     int units, threads;   // one workgroup per (source, octant) or per (source, octant, sector)
-    pick_launch_shape(st, p.R, p.N, dump, units, threads);
+    pick_launch_shape(st, p.R, p.N, p.src_count, dump, units, threads);
     {   // number of shells, known before the tables are built: the 1024-entry LDS tables exist for 256/512 threads
         const double R2hi = p.R * p.R * (1.0 + 1e-9) + 1e-9;
         const int Emax = p.N / 2;
@@ -931,7 +938,8 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
             KernelTimer kt(ASORA_KERNEL_RAYTRACE, stream);
             int rc = 0;
             if (big_tables) {
-                if (threads == 512) rc = launch_variant<512, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat, stream);
+                if (threads == 1024)     rc = launch_variant<1024, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat, stream);
+                else if (threads == 512) rc = launch_variant<512, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat, stream);
                 else                rc = launch_variant<256, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat, stream);
             } else if (small_tables) {
                 if (threads == 64) rc = launch_variant<64, 64>(st, q, grid, lds_bytes, use_lds, dump, heat, stream);
@@ -940,6 +948,7 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
                 case 64:  rc = launch_variant<64, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream); break;
                 case 128: rc = launch_variant<128, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream); break;
                 case 512: rc = launch_variant<512, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream); break;
+                case 1024: rc = launch_variant<1024, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream); break;
                 default:  rc = launch_variant<256, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream); break;
             }
             if (rc) return rc;

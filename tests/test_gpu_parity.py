@@ -141,7 +141,7 @@ def test_z_transposed_layout_is_only_a_layout(asora):
 
 
 @pytest.mark.parametrize("name", ["u16_1src_R8", "l16_7src_R5.5", "l17_3src_Rbox", "l32_5src_R10", "l16_thick"])
-@pytest.mark.parametrize("threads", [64, 128, 256, 512])
+@pytest.mark.parametrize("threads", [64, 128, 256, 512, 1024])
 def test_decomposition_and_workgroup_size_do_not_change_results(asora, name, threads):
     """One workgroup per octant vs one per (octant, sector), at every workgroup size: same Gamma and the
     same count of rated pairs; the sector form evaluates a few more column densities (re-derived planes)."""
