@@ -198,6 +198,8 @@ static int rt_range(int src_begin, int src_count)
     RtParams p = st.rt_params;
     p.src_pos = st.src_pos; p.src_flux = st.src_flux;
     p.src_begin = src_begin; p.src_count = src_count;
+    // one launch shape (one set of geometry tables) per call: a pipelined call is sized by all of the rank's sources
+    p.shape_src_count = st.rt_pipelined ? st.num_src : src_count;
     if (!st.rt_pipelined) return launch_raytrace(st, p, p.dump != nullptr, st.rt_heat);
     const int q = st.side_next;
     st.side_next ^= 1;

@@ -31,6 +31,7 @@ struct RtParams {
     int NumTau, table_len;
     int fortran_consts, grey, z_transposed;
     int src_begin, src_count;
+    int shape_src_count;   // source count the launch shape is chosen for (the whole call's, not a pipelined range's)
     int ablate;            // diagnostics only (env ASORA_ABLATE): 1 = no rate atomics, 2 = no rates
     OctGeomDev geom[24];        // by value: pointers read from the kernarg segment are known-global to the compiler
     int units;                  // workgroups per source: 8 octants, 24 octant-sectors, or 12 mirrored sector pairs

@@ -883,7 +883,7 @@ static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t ld
 int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t side)
 {
     int units, threads;   // one workgroup per (source, octant) or per (source, octant, sector)
-    pick_launch_shape(st, p.R, p.N, p.src_count, dump, units, threads);
+    pick_launch_shape(st, p.R, p.N, p.shape_src_count > 0 ? p.shape_src_count : p.src_count, dump, units, threads);
     {   // number of shells, known before the tables are built: the 1024-entry LDS tables exist for 256/512 threads
         const double R2hi = p.R * p.R * (1.0 + 1e-9) + 1e-9;
         const int Emax = p.N / 2;
