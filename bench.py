@@ -311,11 +311,12 @@ def main():
     def step():
         lib.grid_copy(_capi.GRID_XH_AV, _capi.GRID_XH)
         lib.grid_copy(_capi.GRID_XH_INTERMED, _capi.GRID_XH)
+        chem = (MYR, BH00, ALBPOW, COLH0, TEMPH0, ABU_C)
         if comm is not None:
-            comm.raytrace_and_allreduce(lib, N, args.R, SIG, dr, args.nsrc, MINLOGTAU, dlog, numtau, src_i0=src_i0)
-        else:
-            lib.raytrace_device(args.R, SIG, dr, 0, args.nsrc, MINLOGTAU, dlog, numtau)
-        return lib.chemistry_device(MYR, BH00, ALBPOW, COLH0, TEMPH0, ABU_C)
+            return comm.raytrace_and_allreduce(lib, N, args.R, SIG, dr, args.nsrc, MINLOGTAU, dlog, numtau,
+                                               src_i0=src_i0, chemistry=chem)
+        lib.raytrace_device(args.R, SIG, dr, 0, args.nsrc, MINLOGTAU, dlog, numtau)
+        return lib.chemistry_device(*chem)
 
     def fence():
         lib.synchronize()

@@ -165,6 +165,14 @@ void *asora_stream(void);
 int asora_chemistry_device(double dt, double bh00, double albpow, double colh0, double temph0,
                            double abu_c, int *conv_flag, double *sum_xh1, double *sum_xh0);
 
+/* The same pass slab by slab (planes [i_begin, i_begin + i_count) of every grid), for callers that start the
+ * chemistry of the planes whose rates are already summed across GPUs while the rest is still in flight.
+ * `first` != 0 resets the three reductions, later calls add to them in call order; asora_chemistry_finish
+ * returns them (and is the only call of the group that waits for the device). */
+int asora_chemistry_range(double dt, double bh00, double albpow, double colh0, double temph0, double abu_c,
+                          int i_begin, int i_count, int first);
+int asora_chemistry_finish(int *conv_flag, double *sum_xh1, double *sum_xh0);
+
 /* ------------------------------------------------------------------------------------------ */
 /* C. Options, measurement and diagnostics                                                     */
 /* ------------------------------------------------------------------------------------------ */

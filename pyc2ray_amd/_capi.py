@@ -47,6 +47,9 @@ SIGNATURES = {
     "asora_stream": (C.c_void_p, []),
     "asora_chemistry_device": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                          C.POINTER(C.c_int), _dp, _dp]),
+    "asora_chemistry_range": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                        C.c_int, C.c_int, C.c_int]),
+    "asora_chemistry_finish": (C.c_int, [C.POINTER(C.c_int), _dp, _dp]),
     "asora_set_option": (C.c_int, [C.c_int, C.c_int]),
     "asora_get_option": (C.c_int, [C.c_int]),
     "asora_kernel_time_ms": (C.c_int, [C.c_int, _dp, C.POINTER(C.c_long)]),

@@ -530,6 +530,43 @@ int asora_chemistry_device(double dt, double bh00, double albpow, double colh0, 
     return 0;
 }
 
+int asora_chemistry_range(double dt, double bh00, double albpow, double colh0, double temph0, double abu_c,
+                          int i_begin, int i_count, int first)
+{
+    clear_error();
+    if (int rc = require_init("chemistry_range")) return rc;
+    State &st = g_state;
+    static const int need[] = {ASORA_GRID_NDENS, ASORA_GRID_TEMP, ASORA_GRID_XH, ASORA_GRID_XH_AV,
+                               ASORA_GRID_XH_INTERMED, ASORA_GRID_PHI_ION};
+    for (int g : need)
+        if (!st.grid_valid[g]) return fail(4, "chemistry_range: grid " + std::to_string(g) + " holds no data");
+    if (i_begin < 0 || i_count < 0 || i_begin + i_count > st.N) return fail(4, "chemistry_range: bad plane range");
+    if (i_count == 0 && !first) return 0;
+    const size_t off = (size_t)i_begin * st.N * st.N;
+    ChemParams p;
+    p.ncell = (size_t)i_count * st.N * st.N;
+    p.dt = dt; p.bh00 = bh00; p.albpow = albpow; p.colh0 = colh0; p.temph0 = temph0; p.abu_c = abu_c;
+    p.ndens = st.grid[ASORA_GRID_NDENS] + off; p.temp = st.grid[ASORA_GRID_TEMP] + off; p.xh = st.grid[ASORA_GRID_XH] + off;
+    p.phi = st.grid[ASORA_GRID_PHI_ION] + off;
+    p.xh_av = st.grid[ASORA_GRID_XH_AV] + off; p.xh_intermed = st.grid[ASORA_GRID_XH_INTERMED] + off;
+    p.red_partial = st.red_partial; p.red_final = st.red_final; p.red_blocks = st.red_blocks;
+    p.accumulate = first ? 0 : 1;
+    return launch_chemistry(st, p, st.stream);
+}
+
+int asora_chemistry_finish(int *conv_flag, double *sum_xh1, double *sum_xh0)
+{
+    clear_error();
+    if (int rc = require_init("chemistry_finish")) return rc;
+    State &st = g_state;
+    ASORA_HIP_TRY(hipMemcpyAsync(st.red_host, st.red_final, sizeof(double) * 3, hipMemcpyDeviceToHost, st.stream));
+    ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    if (sum_xh1) *sum_xh1 = st.red_host[0];
+    if (sum_xh0) *sum_xh0 = st.red_host[1];
+    if (conv_flag) *conv_flag = (int)st.red_host[2];
+    return 0;
+}
+
 int c2ray_global_pass(double dt, const double *ndens, const double *temp, const double *xh, double *xh_av,
                       double *xh_intermed, const double *phi_ion, double bh00, double albpow, double colh0,
                       double temph0, double abu_c, int m1, int m2, int m3, int *conv_flag)

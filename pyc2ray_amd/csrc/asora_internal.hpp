@@ -198,6 +198,7 @@ struct ChemParams {
     double *xh_av, *xh_intermed;
     double *red_partial, *red_final;
     int red_blocks;
+    int accumulate = 0;        // 1: add this launch's reductions to red_final (slab-wise passes) instead of replacing it
 };
 int launch_chemistry(State &st, ChemParams &p, hipStream_t stream);
 int chemistry_reduction_blocks(const State &st);

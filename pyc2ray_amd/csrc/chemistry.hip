@@ -112,7 +112,9 @@ __global__ void __launch_bounds__(CH_THREADS) chemistry_kernel(const ChemParams 
     }
 }
 
-__global__ void __launch_bounds__(CH_THREADS) chemistry_reduce_kernel(const double *partial, int nblocks, double *out)
+// out[q] = (accumulate ? out[q] : 0) + sum of the per-block partials, one block, fixed order
+__global__ void __launch_bounds__(CH_THREADS) chemistry_reduce_kernel(const double *partial, int nblocks, double *out,
+                                                                      int accumulate)
 {
     __shared__ double r[3][CH_THREADS];
     for (int q = 0; q < 3; ++q) {
@@ -126,7 +128,7 @@ __global__ void __launch_bounds__(CH_THREADS) chemistry_reduce_kernel(const doub
             for (int q = 0; q < 3; ++q) r[q][threadIdx.x] += r[q][threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x < 3) out[threadIdx.x] = r[threadIdx.x][0];
+    if (threadIdx.x < 3) out[threadIdx.x] = (accumulate ? out[threadIdx.x] : 0.0) + r[threadIdx.x][0];
 }
 
 int chemistry_reduction_blocks(const State &st) { return st.cu_count * 8; }
@@ -143,7 +145,7 @@ int launch_chemistry(State &st, ChemParams &p, hipStream_t stream)
         ASORA_HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(chemistry_reduce_kernel, dim3(1), dim3(CH_THREADS), 0, stream,
-                       (const double *)p.red_partial, blocks, p.red_final);
+                       (const double *)p.red_partial, blocks, p.red_final, p.accumulate);
     ASORA_HIP_TRY(hipGetLastError());
     return 0;
 }

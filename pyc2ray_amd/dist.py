@@ -72,7 +72,7 @@ class _DevicePointer:
 class TorchComm:
     """Communicator over a torch.distributed process group."""
 
-    def __init__(self, group=None, overlap=None, chunks=8):
+    def __init__(self, group=None, overlap=None, chunks=8, pipeline_chemistry=None):
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError("TorchComm: torch.distributed is not initialised "
@@ -83,6 +83,11 @@ class TorchComm:
             overlap = os.environ.get("PYC2RAY_AMD_OVERLAP", "0") == "1"
         self.overlap = bool(overlap)
         self.chunks = int(os.environ.get("PYC2RAY_AMD_OVERLAP_CHUNKS", chunks))
+        # also start each slab's chemistry behind its sum (measured on one GPU: the chemistry kernels then compete
+        # with the trace for the memory system and the step gets 0.25 ms LONGER, so this stays off)
+        if pipeline_chemistry is None:
+            pipeline_chemistry = os.environ.get("PYC2RAY_AMD_OVERLAP_CHEMISTRY", "0") == "1"
+        self.pipeline_chemistry = bool(pipeline_chemistry)
         self._comm_stream = None
 
     # -- mpi4py-flavoured surface ---------------------------------------------------------------
@@ -193,15 +198,19 @@ class TorchComm:
         return runs
 
     def raytrace_and_allreduce(self, libasora, N, R, sig, dr, num_src_local, minlogtau, dlogtau, NumTau,
-                               src_i0=None):
+                               src_i0=None, chemistry=None):
         """Trace this rank's sources and leave the sum over ranks of the rate grids in the device-resident
         phi_ion grid.  Pipelined when self.overlap is set and `src_i0` (0-based first coordinates of the local
-        sources, ascending, in upload order) is given; otherwise trace, then all-reduce."""
+        sources, ascending, in upload order) is given; otherwise trace, then all-reduce.
+
+        With `chemistry` = (dt, bh00, albpow, colh0, temph0, abu_c) the chemistry pass is run as well and its
+        (conv_flag, sum x, sum 1-x) returned; with self.pipeline_chemistry each slab's chemistry starts as soon as its
+        rates are summed, under the remaining trace and all-reduces."""
         from . import _capi
         if not self.overlap or src_i0 is None:
             libasora.raytrace_device(R, sig, dr, 0, num_src_local, minlogtau, dlogtau, NumTau)
             self.allreduce_device_grid(libasora, _capi.GRID_PHI_ION, N)
-            return
+            return libasora.chemistry_device(*chemistry) if chemistry is not None else None
         import torch
         src_i0 = np.asarray(src_i0)
         if src_i0.size and np.any(np.diff(src_i0) < 0):
@@ -219,25 +228,35 @@ class TorchComm:
                 self._comm_stream = torch.cuda.Stream()
             view = torch.as_tensor(_DevicePointer(libasora.device_ptr(_capi.GRID_PHI_ION), N ** 3), device="cuda")
         reduced = np.zeros(N, dtype=bool)
+        first_slab = True
+        slab_chemistry = chemistry is not None and self.pipeline_chemistry
         libasora.raytrace_begin(R, sig, dr, minlogtau, dlogtau, NumTau)
         for c in range(K):
             libasora.raytrace_range(int(starts[c]), int(starts[c + 1] - starts[c]))
             for a, b in self.final_plane_runs(N, K, R, c, reduced):
                 libasora.raytrace_fold(a, b - a)
                 reduced[a:b] = True
-                if not collective:
-                    continue
-                if nccl:
+                if collective and nccl:
                     done = torch.cuda.Event()
                     done.record(lib_stream)                    # the slab is final once the library stream gets here
                     self._comm_stream.wait_event(done)
                     with torch.cuda.stream(self._comm_stream):
                         self._dist.all_reduce(view[a * N * N:b * N * N], op=self._dist.ReduceOp.SUM, group=self._group)
-                else:                                          # gloo (CPU tests): staged through the host
+                    if slab_chemistry:                         # the slab's chemistry goes behind its sum
+                        summed = torch.cuda.Event()
+                        summed.record(self._comm_stream)
+                        lib_stream.wait_event(summed)
+                elif collective:                               # gloo (CPU tests): staged through the host
                     host = libasora.grid_to_host(_capi.GRID_PHI_ION, np.empty((N, N, N)))
                     t = torch.from_numpy(host[a:b])
                     self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
                     libasora.grid_to_device(_capi.GRID_PHI_ION, host)
+                if slab_chemistry:
+                    libasora.chemistry_range(*chemistry, a, b - a, first_slab)
+                    first_slab = False
         assert reduced.all()
         if nccl and collective:
-            lib_stream.wait_stream(self._comm_stream)         # the chemistry (library stream) needs the sums
+            lib_stream.wait_stream(self._comm_stream)         # whatever follows on the library stream needs the sums
+        if chemistry is None:
+            return None
+        return libasora.chemistry_finish() if slab_chemistry else libasora.chemistry_device(*chemistry)

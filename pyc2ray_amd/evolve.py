@@ -188,32 +188,34 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
 
         # (1) raytracing, evolve.py:174-196
         trt0 = time.time()
-        if distributed:
-            printlog(f"Doing Raytracing (rank={rank:n})...", logfile, quiet, ' ')
-        else:
-            printlog("Doing Raytracing...", logfile, quiet, ' ')
+        chem = (dt, bh00, albpow, colh0, temph0, abu_c)
         if pipelined:
-            comm.raytrace_and_allreduce(libasora, N, R_max_LLS, sig, dr, NumSrc_local, minlogtau, dlogtau, NumTau,
-                                        src_i0=src_i0)
-            printlog(f"rank={rank:n} took {(time.time()-trt0) : .1e} s (sum over ranks pipelined).", logfile, quiet)
-        elif distributed:
-            libasora.raytrace_device(R_max_LLS, sig, dr, 0, NumSrc_local, minlogtau, dlogtau, NumTau)
-            libasora.synchronize()
+            # raytrace, sum over ranks and chemistry slab by slab (pyc2ray_amd.dist): steps (1) and (2) in one
+            printlog(f"Doing Raytracing and Chemistry, pipelined (rank={rank:n})...", logfile, quiet, ' ')
+            conv_flag, sum_xh1_int, sum_xh0_int = comm.raytrace_and_allreduce(
+                libasora, N, R_max_LLS, sig, dr, NumSrc_local, minlogtau, dlogtau, NumTau, src_i0=src_i0, chemistry=chem)
             printlog(f"rank={rank:n} took {(time.time()-trt0) : .1e} s.", logfile, quiet)
-            _allreduce_phi(libasora, N, use_mpi, comm, rank)
         else:
-            libasora.raytrace_device(R_max_LLS, sig, dr, 0, NumSrc_local, minlogtau, dlogtau, NumTau)
-            libasora.synchronize()
-            printlog(f"took {(time.time()-trt0) : .1f} s.", logfile, quiet)
+            if distributed:
+                printlog(f"Doing Raytracing (rank={rank:n})...", logfile, quiet, ' ')
+                libasora.raytrace_device(R_max_LLS, sig, dr, 0, NumSrc_local, minlogtau, dlogtau, NumTau)
+                libasora.synchronize()
+                printlog(f"rank={rank:n} took {(time.time()-trt0) : .1e} s.", logfile, quiet)
+                _allreduce_phi(libasora, N, use_mpi, comm, rank)
+            else:
+                printlog("Doing Raytracing...", logfile, quiet, ' ')
+                libasora.raytrace_device(R_max_LLS, sig, dr, 0, NumSrc_local, minlogtau, dlogtau, NumTau)
+                libasora.synchronize()
+                printlog(f"took {(time.time()-trt0) : .1f} s.", logfile, quiet)
 
-        # (2) chemistry, evolve.py:207-211.  Every rank runs it on the identical summed rates
-        # (the reference runs it on rank 0 and broadcasts two N^3 grids, evolve.py:439-481).
-        tch0 = time.time()
-        if rank == 0:
-            printlog("Doing Chemistry...", logfile, quiet, ' ')
-        conv_flag, sum_xh1_int, sum_xh0_int = libasora.chemistry_device(dt, bh00, albpow, colh0, temph0, abu_c)
-        if rank == 0:
-            printlog(f"took {(time.time()-tch0) : .1f} s.", logfile, quiet)
+            # (2) chemistry, evolve.py:207-211.  Every rank runs it on the identical summed rates
+            # (the reference runs it on rank 0 and broadcasts two N^3 grids, evolve.py:439-481).
+            tch0 = time.time()
+            if rank == 0:
+                printlog("Doing Chemistry...", logfile, quiet, ' ')
+            conv_flag, sum_xh1_int, sum_xh0_int = libasora.chemistry_device(*chem)
+            if rank == 0:
+                printlog(f"took {(time.time()-tch0) : .1f} s.", logfile, quiet)
 
         # (3) global convergence, evolve.py:216-236
         if sum_xh1_int > 0.0:

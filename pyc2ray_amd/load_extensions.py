@@ -158,6 +158,18 @@ class _LibAsora:
                                                      C.byref(s0)), "chemistry_device")
         return conv.value, s1.value, s0.value
 
+    def chemistry_range(self, dt, bh00, albpow, colh0, temph0, abu_c, i_begin, i_count, first):
+        _capi.check(self._lib.asora_chemistry_range(float(dt), float(bh00), float(albpow), float(colh0), float(temph0),
+                                                    float(abu_c), int(i_begin), int(i_count), int(bool(first))),
+                    "chemistry_range")
+
+    def chemistry_finish(self):
+        conv = C.c_int(0)
+        s1 = C.c_double(0.0)
+        s0 = C.c_double(0.0)
+        _capi.check(self._lib.asora_chemistry_finish(C.byref(conv), C.byref(s1), C.byref(s0)), "chemistry_finish")
+        return conv.value, s1.value, s0.value
+
     def set_option(self, option, value):
         _capi.check(self._lib.asora_set_option(int(option), int(value)), "set_option")
 

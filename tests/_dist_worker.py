@@ -22,7 +22,7 @@ def main():
 
     r, w, _ = pd.init_process_group_from_env("gloo")
     assert (r, w) == (rank, world)
-    comm = pd.TorchComm(overlap=overlap, chunks=4)
+    comm = pd.TorchComm(overlap=overlap, chunks=4, pipeline_chemistry=overlap)
     assert comm.Get_rank() == rank and comm.Get_size() == world
 
     # mpi4py-flavoured surface

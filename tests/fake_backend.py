@@ -66,6 +66,22 @@ class OracleAsora:
     def stream_ptr(self):
         return 0
 
+    def chemistry_range(self, dt, bh00, albpow, colh0, temph0, abu_c, i_begin, i_count, first):
+        if first:
+            self._red = [0, 0.0, 0.0]
+        sl = slice(i_begin, i_begin + i_count)
+        if i_count == 0:
+            return
+        xa, xi, conv, _ = O.global_pass(dt, self.g[0][sl], self.g[3][sl], self.g[4][sl], self.g[1][sl], self.g[5][sl],
+                                        self.g[2][sl], bh00, albpow, colh0, temph0, abu_c)
+        self.g[1][sl], self.g[5][sl] = xa, xi
+        self._red[0] += conv
+        self._red[1] += float(np.sum(xi))
+        self._red[2] += float(np.sum(1.0 - xi))
+
+    def chemistry_finish(self):
+        return tuple(self._red)
+
     def chemistry_device(self, dt, bh00, albpow, colh0, temph0, abu_c):
         xa, xi, conv, _ = O.global_pass(dt, self.g[0], self.g[3], self.g[4], self.g[1], self.g[5], self.g[2],
                                         bh00, albpow, colh0, temph0, abu_c)

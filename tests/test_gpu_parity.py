@@ -619,6 +619,29 @@ def test_pipelined_raytrace_allreduce_world1(asora, monkeypatch):
         with pytest.raises(ValueError, match="ascending"):
             comm.raytrace_and_allreduce(lib, N, R, cases.SIG, dr, 40, cases.MINLOGTAU, dlog, numtau,
                                         src_i0=(spos[0].astype(np.int64) - 1)[::-1])
+    # ... and with the chemistry pipelined behind each slab's sum: same grids, same convergence scalars
+    chem = (3.15576e13, cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C)
+    temp = np.full((N, N, N), 1e4)
+    for chunks in (8, 3):
+        res = {}
+        for mode in ("plain", "piped", "piped_chem"):
+            comm = pd.TorchComm(overlap=(mode != "plain"), chunks=chunks, pipeline_chemistry=(mode == "piped_chem"))
+            spos, sflux = comm.sort_sources_for_overlap(pos, flux)
+            p0, f0 = cases.flat_sources(spos, sflux)
+            lib.source_data_to_device(p0, f0, 40)
+            lib.grid_to_device(capi.GRID_TEMP, temp)
+            lib.grid_to_device(capi.GRID_XH, xh)
+            lib.grid_copy(capi.GRID_XH_AV, capi.GRID_XH)
+            lib.grid_copy(capi.GRID_XH_INTERMED, capi.GRID_XH)
+            scal = comm.raytrace_and_allreduce(lib, N, 9.5, cases.SIG, dr, 40, cases.MINLOGTAU, dlog, numtau,
+                                               src_i0=spos[0].astype(np.int64) - 1, chemistry=chem)
+            res[mode] = (scal, lib.grid_to_host(capi.GRID_XH_AV, np.empty((N, N, N))),
+                         lib.grid_to_host(capi.GRID_XH_INTERMED, np.empty((N, N, N))))
+        for mode in ("piped", "piped_chem"):
+            assert res["plain"][0][0] == res[mode][0][0]                                   # conv_flag
+            np.testing.assert_allclose(res["plain"][0][1:], res[mode][0][1:], rtol=1e-12)   # the two sums
+            np.testing.assert_allclose(res[mode][1], res["plain"][1], rtol=1e-10)
+            np.testing.assert_allclose(res[mode][2], res["plain"][2], rtol=1e-10)
     # the three-part C-ABI refuses to be used out of order
     p.device_close()
     p.device_init(N, 8)
