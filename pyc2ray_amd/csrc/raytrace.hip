@@ -40,6 +40,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -133,6 +134,14 @@ __device__ __forceinline__ double photo_rate_per_atom(double flux, double cd_in,
 #else
 #define ASORA_ABLATED(bit) false
 #define ASORA_RATE_ATOMIC(dst, v) unsafeAtomicAdd((dst), (v))
+#endif
+
+// 1: the rate atomic of a step is issued in the NEXT step, right behind that step's table-lookup loads.  Vector
+// memory operations complete in issue order, so a lookup issued after an atomic cannot return before the atomic has
+// gone through the memory-side atomic unit (thousands of cycles under load); issued the other way round the lookup
+// only waits for the atomic of the step before.  Costs 3 VGPRs.
+#ifndef ASORA_LATE_ATOMIC
+#define ASORA_LATE_ATOMIC 1
 #endif
 
 // waves per SIMD the register allocation must leave room for (2nd argument of __launch_bounds__)
@@ -247,6 +256,10 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
     // step's (its nHI is requested here), `pf_*` the register set the entry two steps ahead is
     // loaded into.  The loop below is unrolled three times with the three register sets rotating,
     // so the pipeline needs no register-to-register copies.
+    bool late_ok = false;              // a rate computed in the previous step, not yet added (ASORA_LATE_ATOMIC)
+    double late_v = 0.0, late_h = 0.0;
+    double *late_dst = p.phi;
+
     auto step = [&](unsigned e_pf, const uint4 &cur_A, const uint4 &cur_B, const double cur_nhi, const unsigned cur_idx,
                     const uint4 &nxt_A, double &nxt_nhi, unsigned &nxt_idx, uint4 &pf_A, uint4 &pf_B) {
         pf_A = cellA[e_pf];                                         // two steps ahead
@@ -338,6 +351,22 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
             const double2 *tab = p.tables + (thick ? 0 : p.table_len);
             const Lookup A = lookup_issue<HEAT>(tab, thick ? tau_in : tau_thin, p, logtab);
             const Lookup B = lookup_issue<HEAT>(tab, thick ? tau_out : tau_thin, p, logtab);
+#if ASORA_LATE_ATOMIC
+            if (late_ok) {       // the previous step's rate, behind this step's lookups in the memory pipeline
+                ASORA_RATE_ATOMIC(late_dst, late_v);
+                if (HEAT) unsafeAtomicAdd(p.heat + (late_dst - p.phi), late_h);
+            }
+            {
+                const double ta = lookup_value(A), tb = lookup_value(B);
+                late_v = thick ? pref * ta - pref * tb : pref * dtau * ta;
+                if (HEAT) {      // photorates.f90:118,124 with the same table index and residual
+                    const double ha = lookup_heat(A), hb = lookup_heat(B);
+                    late_h = thick ? pref * (ha - hb) : pref * dtau * ha;
+                }
+                late_dst = dst;
+                late_ok = rated;
+            }
+#else
             if (rated) {
                 const double ta = lookup_value(A), tb = lookup_value(B);
                 ASORA_RATE_ATOMIC(dst, thick ? pref * ta - pref * tb : pref * dtau * ta);
@@ -346,6 +375,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
                     unsafeAtomicAdd(p.heat + (dst - p.phi), thick ? pref * (ha - hb) : pref * dtau * ha);
                 }
             }
+#endif
         }
     };
 
@@ -363,6 +393,11 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
         step(e + 3 * RT_THREADS, A1, B1, nhi1, idx1, A2, nhi2, idx2, A0, B0);
         step(e + 4 * RT_THREADS, A2, B2, nhi2, idx2, A0, nhi0, idx0, A1, B1);
     }
+    if (late_ok) {
+        ASORA_RATE_ATOMIC(late_dst, late_v);
+        if (HEAT) unsafeAtomicAdd(p.heat + (late_dst - p.phi), late_h);
+    }
+
     // work accounting: one atomic per wave
     for (int o = 32; o > 0; o >>= 1) {
         n_gamma += __shfl_down(n_gamma, o);
