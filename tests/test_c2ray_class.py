@@ -122,3 +122,57 @@ def test_c2ray_test_class_with_use_gpu_false_runs_the_subbox_semantics(tmp_path)
         pc2r.device_close()
     finally:
         os.chdir(cwd)
+
+
+@pytest.mark.gpu
+def test_single_black_body_regression_thresholds(tmp_path):
+    """The reference's only self-checking regression (unit_tests_hackathon/1_single_black_body/run_test.py) at
+    reduced size: one 5e4 K black-body source in a uniform medium, 1 Myr steps through C2Ray_Test, final ionised
+    fraction per cell against a golden field under that script's eight thresholds (run_test.py:91-115).  The golden
+    field is the oracle's restatement of the reference's CPU path driven by the same loop (the full-size run against
+    the reference Fortran itself: tools/hackathon_test1.py, profiles/r01_hackathon_test1_128.json)."""
+    import pyc2ray_amd as pc2r
+    from oracle import oracle as O
+    params = os.path.join(os.path.dirname(PARAMS), "parameters_single_black_body.yml")
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        if pc2r.cuda_is_init():
+            pc2r.device_close()
+        N, steps = 48, 3
+        sim = pc2r.C2Ray_Test(params, N, True)
+        with open("src.txt", "w") as f:
+            f.write(f"1\n{3 * N // 4} {3 * N // 4} {N // 2} 10e48 0.0\n")
+        srcpos, srcflux = sim.read_sources("src.txt", 1)
+        zs = sim.generate_redshift_array(2, 1e7)
+        sim.ndens = 1e-3 * np.ones((N, N, N))
+        dt = sim.set_timestep(zs[0], zs[1], 10)
+        for _ in range(steps):
+            sim.cosmo_evolve(dt)
+            sim.evolve3D(dt, srcflux, srcpos)
+        x_gpu = np.array(sim.xh)
+        pc2r.device_close()
+        # golden: the reference's use_gpu=False loop (evolve.py:116-245) on the oracle
+        xh = np.full((N, N, N), 1.2e-3)
+        for _ in range(steps):
+            xh_av, xh_int = xh.copy(), xh.copy()
+            prev1 = prev0 = 2 * N ** 3
+            while True:
+                r = O.do_all_sources(srcflux, srcpos, sim.max_subbox, sim.subboxsize, sim.sig, sim.dr, sim.ndens, xh_av,
+                                     sim.loss_fraction, sim.photo_thin_table, sim.photo_thick_table, sim.minlogtau,
+                                     sim.dlogtau, sim.R_max_LLS)
+                xh_av, xh_int, conv, _ = O.global_pass(dt, sim.ndens, sim.temp, xh, xh_av, xh_int, r["phi_ion"], sim.bh00,
+                                                       sim.albpow, sim.colh0, sim.temph0, sim.abu_c)
+                s1, s0 = np.sum(xh_int), np.sum(1.0 - xh_int)
+                rel1, rel0 = abs((s1 - prev1) / s1), abs((s0 - prev0) / s0)
+                prev1, prev0 = s1, s0
+                if rel1 < sim.convergence_fraction and rel0 < sim.convergence_fraction:
+                    break
+            xh = xh_int
+        abserr = x_gpu - xh
+        relerr = abserr / xh
+        assert abs(abserr.mean()) <= 1e-8 and abserr.std() <= 3e-7 and abs(abserr.max()) <= 5e-6 and abs(abserr.min()) <= 5e-6
+        assert abs(relerr.mean()) <= 1e-7 and relerr.std() <= 3e-6 and abs(relerr.max()) <= 2e-5 and abs(relerr.min()) <= 2e-5
+        assert x_gpu.max() > 0.99 and 1e-3 < x_gpu.mean() < 0.5
+    finally:
+        os.chdir(cwd)
