@@ -211,3 +211,61 @@ def test_paper_test3_mean_ionised_fractions(tmp_path, name, grey, teff, c2ray_me
         pc2r.device_close()
     finally:
         os.chdir(cwd)
+
+
+@pytest.mark.gpu
+def test_paper_test2_cosmological_ionisation_front(tmp_path):
+    """The reference's paper test 2 (test/paper_tests/test2_Ifront_cosmo, coarse mode) at 128^3: one source in an
+    EXPANDING uniform medium from z = 9, ten 50 Myr steps with cosmology on (density dilution, proper cell size,
+    redshift bookkeeping of C2Ray.cosmo_evolve).  The front radius must follow the analytic solution of
+    make_plot.ipynb cell 5, r_I = r_S [lam e^{lam ti/t} (t/ti E2(lam ti/t) - E2(lam))]^(1/3); the reference's own figure
+    (256^3) stays within [0.985, 1.005] (this build at 256^3: 0.991-0.996, profiles/r01_test2_cosmo_ifront_256.json)."""
+    from scipy.special import expn
+    import pyc2ray_amd as pc2r
+    from pyc2ray_amd.c2ray_base import FlatLambdaCDMLite
+    base = open(os.path.join(os.path.dirname(PARAMS), "parameters_single_black_body.yml")).read()
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        if pc2r.cuda_is_init():
+            pc2r.device_close()
+        N = 128
+        with open("parameters.yml", "w") as f:
+            f.write(base.replace("boxsize: 0.014", "boxsize: 22.685455026110553").replace("avg_dens: 1.0e-6", "avg_dens: 1.87e-7")
+                        .replace("NumTau: 10000", "NumTau: 2000").replace("grey: 0", "grey: 1")
+                        .replace("R_max_cMpc: 0.01640625", "R_max_cMpc: 15.0").replace("cosmological: 0", "cosmological: 1")
+                        .replace("h: 1.0", "h: 0.7").replace("Omega_B: 0.044", "Omega_B: 0.043")
+                        .replace("subboxsize: 150", "subboxsize: 128"))
+        with open("source.txt", "w") as f:
+            f.write("1\n64 64 64 1e54 0.0\n")
+        sim = pc2r.C2Ray_Test("parameters.yml", N, True)
+        assert sim.cosmological
+        zs = sim.generate_redshift_array(11, 5e7)
+        srcpos, srcflux = sim.read_sources("source.txt", 1)
+        year, kpc = 3.15576e7, 3.086e21
+        cosmo = FlatLambdaCDMLite(70, 0.27, 2.726, Ob0=0.043)
+        ti = cosmo.age(9) / (1e6 * year)
+        assert ti == pytest.approx(563.9825828256307, rel=1e-9)                 # astropy's value, notebook cell 5 output
+        r_S = ((3 * 1e54) / (4 * np.pi * 2.59e-13 * 1.87e-4 ** 2)) ** (1. / 3) / kpc
+        lam = ti / (1.0 / (2.59e-13 * 1.87e-4 * year * 1e6))
+        assert lam == pytest.approx(0.862007470892602, rel=1e-9)
+        y = lambda t: lam * np.exp(lam * ti / t) * (t / ti * expn(2, lam * ti / t) - expn(2, lam))
+        x = np.linspace(0, 22685 / 10 / 2, N // 2 + 1)
+        ratios = []
+        for k in range(10):
+            dt = sim.set_timestep(zs[k], zs[k + 1], 1)
+            sim.zred = zs[k]
+            sim.set_constant_average_density(1.87e-7, zs[k])
+            dr_before = sim.dr
+            sim.cosmo_evolve(dt)
+            assert sim.dr > dr_before or k == 0                                   # the proper cell size grows
+            sim.evolve3D(dt, srcflux, srcpos)
+            prof = sim.xh[63:, 63, 63]
+            front = np.interp(0.5, np.flip(prof), np.flip(x))
+            ratios.append(front / (r_S * y(ti + 50.0 * (k + 1)) ** (1. / 3)))
+        ratios = np.array(ratios)
+        assert np.all(ratios > 0.975) and np.all(ratios < 1.01), ratios
+        assert 5.5 < sim.zred < 5.8
+        pc2r.device_close()
+    finally:
+        os.chdir(cwd)
