@@ -23,6 +23,9 @@ import pyc2ray_amd as pc2r
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--shadow", action="store_true",
+                help="paper test 4 instead (test/paper_tests/test4_shadow/shadow.py): source at the centre, a clump of 6x "
+                     "the density and radius 8 cells at (76,76,63) casting a shadow, C-ordered density, subboxsize 64")
 ap.add_argument("--N", type=int, default=128)
 a = ap.parse_args()
 PARAMS = os.path.join(ROOT, "tests", "data", "parameters_single_black_body.yml")
@@ -30,14 +33,27 @@ N = a.N
 work = tempfile.mkdtemp()
 os.chdir(work)
 with open("src.txt", "w") as f:
-    f.write(f"1\n{3 * N // 4} {3 * N // 4} {N // 2} 10e48 0.0\n")
+    f.write(f"1\n{N // 2} {N // 2} {N // 2} 10e48 1.0\n" if a.shadow else f"1\n{3 * N // 4} {3 * N // 4} {N // 2} 10e48 0.0\n")
+if a.shadow:
+    txt = open(PARAMS).read().replace("R_max_cMpc: 0.01640625", "R_max_cMpc: 15.0").replace("subboxsize: 150", "subboxsize: 64")
+    PARAMS = os.path.join(work, "parameters.yml")
+    open(PARAMS, "w").write(txt)
+
+
+def density():
+    nd = 1e-3 * np.ones((N, N, N))                      # C-ordered, as the reference's scripts build it
+    if a.shadow:
+        i, j, k = np.ogrid[0:N, 0:N, 0:N]
+        c, r = (np.array([76, 76, 63]) * N) // 128, 8 * N // 128
+        nd[(i - c[0]) ** 2 + (j - c[1]) ** 2 + (k - c[2]) ** 2 < r * r] = 6e-3
+    return nd
 
 
 def drive(use_gpu):
     sim = pc2r.C2Ray_Test(PARAMS, N, use_gpu)
     zs = sim.generate_redshift_array(2, 1e7)
     srcpos, srcflux = sim.read_sources("src.txt", 1)
-    sim.ndens = 1e-3 * np.ones((N, N, N))
+    sim.ndens = density()
     dt = sim.set_timestep(zs[0], zs[1], 10)
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -52,7 +68,8 @@ sim, x_gpu, t_gpu, dt, srcpos, srcflux = drive(True)
 pc2r.device_close()
 _, x_sub, t_sub, *_ = drive(False)
 
-out = {"case": f"unit_tests_hackathon/1_single_black_body at {N}^3, {a.steps} steps of 1 Myr",
+out = {"case": (f"paper test 4 (shadow behind a dense clump) at {N}^3, {a.steps} steps of 1 Myr" if a.shadow else
+                f"unit_tests_hackathon/1_single_black_body at {N}^3, {a.steps} steps of 1 Myr"),
        "mean_x_asora_path": float(x_gpu.mean()), "seconds_asora_path": t_gpu,
        "mean_x_subbox_semantics_path": float(x_sub.mean()), "seconds_subbox_semantics_path": t_sub}
 
