@@ -162,6 +162,19 @@ void *asora_stream(void);
 /* One chemistry pass on the device-resident grids (ndens, temp, xh, xh_av, xh_intermed,
  * phi_ion): global_pass + the three reductions of pyc2ray/evolve.py:216-217.
  * Outputs: conv_flag (chemistry.f90:99-104), sum(xh_intermed), sum(1-xh_intermed). */
+/* The raytracer of libc2ray.raytracing.do_all_sources (cubic sub-boxes, photon loss; see c2ray_do_all_sources in
+ * section A) on device-resident inputs: NDENS and XH_AV on the device, tables from asora_photo_table_to_device
+ * [+ asora_heat_table_to_device with ASORA_OPT_HEATING], sources [src_begin, src_begin + src_count) of
+ * asora_source_data_to_device (0-based positions).  Leaves the rates in ASORA_GRID_PHI_ION (and PHI_HEAT, zeroed
+ * first); returns the number of sub-boxes used and the photon loss.  This is what evolve3D(use_gpu=False) iterates. */
+int asora_subbox_raytrace_device(int max_subbox, int subboxsize, float loss_fraction, double R_max_LLS, double sig,
+                                 double dr, double minlogtau, double dlogtau, int NumTau, int src_begin, int src_count,
+                                 int *sum_nbox, double *photon_loss);
+/* asora_device_init for callers that have no device_init of their own (the libc2ray-compatible entry points):
+ * initialises the library for N if it is not initialised, re-initialises it if it was initialised this way for
+ * another N, and fails if asora_device_init was called for another N. */
+int asora_device_init_auto(int N);
+
 int asora_chemistry_device(double dt, double bh00, double albpow, double colh0, double temph0,
                            double abu_c, int *conv_flag, double *sum_xh1, double *sum_xh0);
 

@@ -45,6 +45,9 @@ SIGNATURES = {
     "asora_raytrace_range": (C.c_int, [C.c_int, C.c_int]),
     "asora_raytrace_fold": (C.c_int, [C.c_int, C.c_int]),
     "asora_stream": (C.c_void_p, []),
+    "asora_subbox_raytrace_device": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_double, C.c_double, C.c_double, C.c_double,
+                                               C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), _dp]),
+    "asora_device_init_auto": (C.c_int, [C.c_int]),
     "asora_chemistry_device": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                          C.POINTER(C.c_int), _dp, _dp]),
     "asora_chemistry_range": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,

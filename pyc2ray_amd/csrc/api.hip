@@ -100,6 +100,7 @@ static int release_all()
     drop(st.tables); st.table_len = 0;
     drop(st.src_pos); drop(st.src_flux); st.num_src = 0;
     drop(st.shell_scratch); st.shell_scratch_bytes = 0;
+    drop(st.sb_active); drop(st.sb_nbox); drop(st.sb_loss); drop(st.sb_loss_final); st.subbox_cap = 0;
     release_geometry(st);
     st.init = false; st.N = 0; st.ncell = 0;
     st.rt_open = false;
@@ -241,6 +242,134 @@ static int do_raytrace(double R, double sig, double dr, int src_begin, int src_c
     if (int rc = rt_range(src_begin, src_count)) return rc;
     if (int rc = rt_fold(0, st.N)) return rc;
     st.rt_open = false;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host driver of subbox.hip on device-resident inputs (do_all_sources / do_source,
+// src/c2ray/raytracing.f90:52-249): NDENS and XH_AV on the device, tables and sources given as device pointers.
+// ---------------------------------------------------------------------------------------------
+struct SubboxCall {
+    int max_subbox, subboxsize;
+    float loss_fraction;
+    double sig, dr, R, minlogtau, dlogtau;
+    int NumTau, table_len;
+    const double2 *tables;          // [thick | thin | heat thick | heat thin] pairs, table_len each
+    const int32_t *src_pos;         // 0-based, xyz-interleaved
+    const double *src_flux;
+    int src_begin, src_count;
+    bool heat, keep_heat;           // keep_heat: add onto PHI_HEAT as it stands (f2py intent(inout)) instead of zeroing it
+    double *dump;                   // N^3 grid receiving the column densities of the last source, or nullptr
+};
+
+static int subbox_core(const SubboxCall &c, long long &total_nbox, double &total_loss)
+{
+    State &st = g_state;
+    const int N = st.N;
+    const size_t bytes = st.ncell * sizeof(double);
+    const bool grey = st.opt[ASORA_OPT_GREY_NOTABLES] != 0;
+    ASORA_HIP_TRY(hipMemsetAsync(st.grid[ASORA_GRID_PHI_ION], 0, 2 * bytes, st.stream));          // f90:95 (+ its [k][j][i] twin)
+    if (c.heat) {
+        if (!c.keep_heat) ASORA_HIP_TRY(hipMemsetAsync(st.grid[ASORA_GRID_PHI_HEAT], 0, bytes, st.stream));
+        ASORA_HIP_TRY(hipMemsetAsync(st.heat_t, 0, bytes, st.stream));
+    }
+    if (c.dump) ASORA_HIP_TRY(hipMemsetAsync(c.dump, 0, bytes, st.stream));
+    if (int rc = launch_prepare_nhi(st, true)) return rc;
+    if (int rc = ensure_logtab(st)) return rc;
+
+    // traversal range per axis side, f90:174-175
+    const int ext_r = std::min(c.max_subbox, N / 2 - 1 + N % 2);
+    const int ext_l = std::min(c.max_subbox, N / 2);
+    const int S_all = std::max(ext_r, ext_l);
+    const bool range_open = ext_r > 0 && ext_l > 0;      // else the while loop of do_source never runs (f90:193-195)
+
+    SubboxParams p;
+    std::memset(&p, 0, sizeof p);
+    p.N = N; p.W = std::max(S_all, 0) + 1;
+    p.ext_r = ext_r; p.ext_l = ext_l;
+    p.sig = c.sig; p.dr = c.dr; p.R = c.R;
+    p.numtau_f = (double)(float)c.NumTau;                                  // photorates.f90:141 real(NumTau)
+    p.lut_k1 = 0.30102999566398119521 / c.dlogtau;
+    p.lut_k0 = 1.0 - c.minlogtau / c.dlogtau;
+    p.table_len = c.table_len;
+    p.grey = grey ? 1 : 0; p.heat = c.heat ? 1 : 0;
+    const int last = c.src_begin + c.src_count - 1;
+    p.flux_src = st.opt[ASORA_OPT_C2RAY_OWN_FLUX] ? -1 : last;            // f90:500,503
+    p.dump_src = last;
+    p.ncell = (unsigned)st.ncell;
+    p.nhi = st.nhi; p.phi = st.grid[ASORA_GRID_PHI_ION]; p.heat_grid = st.grid[ASORA_GRID_PHI_HEAT];
+    p.dump = c.dump;
+    p.tables = c.tables; p.logtab = st.logtab_dev;
+    p.src_pos = c.src_pos; p.src_flux = c.src_flux;
+    p.unit_stride = (size_t)6 * p.W * p.W;
+
+    total_nbox = 0;
+    total_loss = 0.0;
+    // sources in batches bounded by the shell-buffer scratch (8 octants x 2 buffers x 3 W^2 doubles per source)
+    const size_t per_src = 8 * p.unit_stride * sizeof(double);
+    const size_t budget = (size_t)4 << 30;
+    const int max_batch = (int)std::max<size_t>(8, std::min<size_t>((budget / per_src) / 8 * 8, 1 << 20));
+    const int cap = std::min(std::max(c.src_count, 1), max_batch);
+    if ((size_t)cap > st.subbox_cap) {                   // per-source bookkeeping of a batch, kept between calls
+        for (void *q : {(void *)st.sb_active, (void *)st.sb_nbox, (void *)st.sb_loss, (void *)st.sb_loss_final})
+            if (q) (void)hipFree(q);
+        st.sb_active = st.sb_nbox = nullptr; st.sb_loss = st.sb_loss_final = nullptr; st.subbox_cap = 0;
+        ASORA_HIP_TRY(hipMalloc(&st.sb_active, sizeof(int) * cap));
+        ASORA_HIP_TRY(hipMalloc(&st.sb_nbox, sizeof(int) * cap));
+        ASORA_HIP_TRY(hipMalloc(&st.sb_loss, sizeof(double) * cap));
+        ASORA_HIP_TRY(hipMalloc(&st.sb_loss_final, sizeof(double) * cap));
+        st.subbox_cap = (size_t)cap;
+    }
+    if (!st.sb_nactive) ASORA_HIP_TRY(hipMalloc(&st.sb_nactive, sizeof(int)));
+    std::vector<int> h_nbox((size_t)cap);
+    std::vector<double> h_loss((size_t)cap);
+
+    for (int done = 0; done < c.src_count;) {
+        const int batch = std::min(c.src_count - done, max_batch);
+        const size_t need = (size_t)8 * ((batch + 7) / 8) * per_src;
+        if (need > st.shell_scratch_bytes) {
+            if (st.shell_scratch) ASORA_HIP_TRY(hipFree(st.shell_scratch));
+            st.shell_scratch = nullptr; st.shell_scratch_bytes = 0;
+            ASORA_HIP_TRY(hipMalloc(&st.shell_scratch, need));
+            st.shell_scratch_bytes = need;
+        }
+        const int first = c.src_begin + done;
+        p.scratch = st.shell_scratch;
+        p.src_begin = first; p.src_count = batch;
+        p.active = st.sb_active; p.loss = st.sb_loss;
+        int n_active = 0;
+        if (int rc = launch_subbox_decide(st, 0, batch, c.src_flux, first, (double)c.loss_fraction, range_open ? 1 : 0,
+                                          st.sb_active, st.sb_loss, st.sb_loss_final, st.sb_nbox, st.sb_nactive)) return rc;
+        ASORA_HIP_TRY(hipMemcpyAsync(&n_active, st.sb_nactive, sizeof(int), hipMemcpyDeviceToHost, st.stream));
+        ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+        long long box = 0;                                    // half-width of the current sub-box, f90:199-200
+        while (n_active > 0) {
+            const long long prev_box = box;
+            box += c.subboxsize;
+            p.s_begin = (int)std::min<long long>(prev_box, S_all);
+            p.s_end = (int)std::min<long long>(box, S_all);
+            p.edge_r = (int)std::min<long long>(box, ext_r);
+            p.edge_l = (int)std::min<long long>(box, ext_l);
+            if (int rc = launch_subbox_sweep(st, p)) return rc;
+            const int more_range = (box < ext_r && box < ext_l) ? 1 : 0;          // f90:194-195
+            if (int rc = launch_subbox_decide(st, 1, batch, c.src_flux, first, (double)c.loss_fraction, more_range,
+                                              st.sb_active, st.sb_loss, st.sb_loss_final, st.sb_nbox, st.sb_nactive)) return rc;
+            ASORA_HIP_TRY(hipMemcpyAsync(&n_active, st.sb_nactive, sizeof(int), hipMemcpyDeviceToHost, st.stream));
+            ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+        }
+        ASORA_HIP_TRY(hipMemcpy(h_nbox.data(), st.sb_nbox, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost));
+        ASORA_HIP_TRY(hipMemcpy(h_loss.data(), st.sb_loss_final, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost));
+        for (int s = 0; s < batch; ++s) { total_nbox += h_nbox[s]; total_loss += h_loss[s]; }   // f90:246-247, in source order
+        done += batch;
+    }
+
+    // fold the [k][j][i] accumulators
+    if (int rc = launch_finish_phi(st)) return rc;
+    st.grid_valid[ASORA_GRID_PHI_ION] = true;
+    if (c.heat) {
+        if (int rc = launch_fold_transposed(st, st.heat_t, st.grid[ASORA_GRID_PHI_HEAT])) return rc;
+        st.grid_valid[ASORA_GRID_PHI_HEAT] = true;
+    }
     return 0;
 }
 
@@ -629,11 +758,7 @@ int c2ray_do_all_sources(const double *normflux, const int32_t *srcpos, int max_
     if (!grey && (NumTau < 1 || !photo_thin_table || !photo_thick_table))
         return fail(3, std::string(who) + ": empty photo-ionisation tables");
     const bool heat = !grey && phi_heat && heat_thin_table && heat_thick_table;
-    if (!st.init || (st.auto_init && st.N != m1)) {
-        // stateless for the caller, like the f2py function it stands for: the library sets itself up for this mesh
-        if (int rc = asora_device_init(m1, 1)) return rc;
-        st.auto_init = true;
-    } else if (int rc = check_N(who, m1)) return rc;
+    if (int rc = asora_device_init_auto(m1)) return rc;
     const int N = st.N;
     for (int s = 0; s < NumSrc; ++s)
         for (int ax = 0; ax < 3; ++ax)
@@ -647,11 +772,6 @@ int c2ray_do_all_sources(const double *normflux, const int32_t *srcpos, int max_
     if (int rc = asora_grid_to_device(ASORA_GRID_NDENS, ndens, N, 'F')) return rc;
     if (int rc = asora_grid_to_device(ASORA_GRID_XH_AV, xh_av, N, 'F')) return rc;
     if (heat) { if (int rc = asora_grid_to_device(ASORA_GRID_PHI_HEAT, phi_heat, N, 'F')) return rc; }
-    ASORA_HIP_TRY(hipMemsetAsync(st.grid[ASORA_GRID_PHI_ION], 0, 2 * bytes, st.stream));          // f90:95 (+ its [k][j][i] twin)
-    if (heat) ASORA_HIP_TRY(hipMemsetAsync(st.heat_t, 0, bytes, st.stream));
-    ASORA_HIP_TRY(hipMemsetAsync(st.staging, 0, bytes, st.stream));                               // column densities of the last source
-    if (int rc = launch_prepare_nhi(st, true)) return rc;
-    if (int rc = ensure_logtab(st)) return rc;
 
     int32_t *d_pos = nullptr; double *d_flux = nullptr; double2 *d_tables = nullptr;
     if (NumSrc > 0) {
@@ -678,93 +798,17 @@ int c2ray_do_all_sources(const double *normflux, const int32_t *srcpos, int max_
         ASORA_HIP_TRY(hipMemcpy(d_tables, pairs.data(), pairs.size() * sizeof(double2), hipMemcpyHostToDevice));
     }
 
-    // traversal range per axis side, f90:174-175
-    const int ext_r = std::min(max_subbox, N / 2 - 1 + N % 2);
-    const int ext_l = std::min(max_subbox, N / 2);
-    const int S_all = std::max(ext_r, ext_l);
-    const bool range_open = ext_r > 0 && ext_l > 0;      // else the while loop of do_source never runs (f90:193-195)
-
-    SubboxParams p;
-    std::memset(&p, 0, sizeof p);
-    p.N = N; p.W = std::max(S_all, 0) + 1;
-    p.ext_r = ext_r; p.ext_l = ext_l;
-    p.sig = sig; p.dr = dr; p.R = R_max_LLS;
-    p.numtau_f = (double)(float)NumTau;                                    // photorates.f90:141 real(NumTau)
-    p.lut_k1 = 0.30102999566398119521 / dlogtau;
-    p.lut_k0 = 1.0 - minlogtau / dlogtau;
-    p.table_len = len;
-    p.grey = grey ? 1 : 0; p.heat = heat ? 1 : 0;
-    p.flux_src = st.opt[ASORA_OPT_C2RAY_OWN_FLUX] ? -1 : NumSrc - 1;
-    p.dump_src = NumSrc - 1;
-    p.ncell = (unsigned)st.ncell;
-    p.nhi = st.nhi; p.phi = st.grid[ASORA_GRID_PHI_ION]; p.heat_grid = st.grid[ASORA_GRID_PHI_HEAT];
-    p.dump = st.staging;
-    p.tables = d_tables; p.logtab = st.logtab_dev;
-    p.src_pos = d_pos; p.src_flux = d_flux;
-    p.unit_stride = (size_t)6 * p.W * p.W;
-
+    SubboxCall c;
+    c.max_subbox = max_subbox; c.subboxsize = subboxsize; c.loss_fraction = loss_fraction;
+    c.sig = sig; c.dr = dr; c.R = R_max_LLS; c.minlogtau = minlogtau; c.dlogtau = dlogtau; c.NumTau = NumTau;
+    c.table_len = len; c.tables = d_tables; c.src_pos = d_pos; c.src_flux = d_flux;
+    c.src_begin = 0; c.src_count = NumSrc;
+    c.heat = heat; c.keep_heat = true;                  // phi_heat is intent(inout): added onto what was uploaded
+    c.dump = st.staging;                                // column densities of the last source
     long long total_nbox = 0;
     double total_loss = 0.0;
-    // sources in batches bounded by the shell-buffer scratch (8 octants x 2 buffers x 3 W^2 doubles per source)
-    const size_t per_src = 8 * p.unit_stride * sizeof(double);
-    const size_t budget = (size_t)4 << 30;
-    const int max_batch = (int)std::max<size_t>(8, std::min<size_t>((budget / per_src) / 8 * 8, 1 << 20));
-    int *d_active = nullptr, *d_nbox = nullptr, *d_nactive = nullptr;
-    double *d_loss = nullptr, *d_loss_final = nullptr;
-    const int cap = std::min(std::max(NumSrc, 1), max_batch);
-    if (int rc = tmp.alloc(d_active, (size_t)cap)) return rc;
-    if (int rc = tmp.alloc(d_nbox, (size_t)cap)) return rc;
-    if (int rc = tmp.alloc(d_nactive, 1)) return rc;
-    if (int rc = tmp.alloc(d_loss, (size_t)cap)) return rc;
-    if (int rc = tmp.alloc(d_loss_final, (size_t)cap)) return rc;
-    std::vector<int> h_nbox((size_t)cap);
-    std::vector<double> h_loss((size_t)cap);
+    if (int rc = subbox_core(c, total_nbox, total_loss)) return rc;
 
-    for (int done = 0; done < NumSrc;) {
-        const int batch = std::min(NumSrc - done, max_batch);
-        const size_t need = (size_t)8 * ((batch + 7) / 8) * per_src;
-        if (need > st.shell_scratch_bytes) {
-            if (st.shell_scratch) ASORA_HIP_TRY(hipFree(st.shell_scratch));
-            st.shell_scratch = nullptr; st.shell_scratch_bytes = 0;
-            ASORA_HIP_TRY(hipMalloc(&st.shell_scratch, need));
-            st.shell_scratch_bytes = need;
-        }
-        p.scratch = st.shell_scratch;
-        p.src_begin = done; p.src_count = batch;
-        p.active = d_active; p.loss = d_loss;
-        int n_active = 0;
-        if (int rc = launch_subbox_decide(st, 0, batch, d_flux, done, (double)loss_fraction, range_open ? 1 : 0, d_active,
-                                          d_loss, d_loss_final, d_nbox, d_nactive)) return rc;
-        ASORA_HIP_TRY(hipMemcpyAsync(&n_active, d_nactive, sizeof(int), hipMemcpyDeviceToHost, st.stream));
-        ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
-        long long box = 0;                                    // half-width of the current sub-box, f90:199-200
-        while (n_active > 0) {
-            const long long prev_box = box;
-            box += subboxsize;
-            p.s_begin = (int)std::min<long long>(prev_box, S_all);
-            p.s_end = (int)std::min<long long>(box, S_all);
-            p.edge_r = (int)std::min<long long>(box, ext_r);
-            p.edge_l = (int)std::min<long long>(box, ext_l);
-            if (int rc = launch_subbox_sweep(st, p)) return rc;
-            const int more_range = (box < ext_r && box < ext_l) ? 1 : 0;          // f90:194-195
-            if (int rc = launch_subbox_decide(st, 1, batch, d_flux, done, (double)loss_fraction, more_range, d_active,
-                                              d_loss, d_loss_final, d_nbox, d_nactive)) return rc;
-            ASORA_HIP_TRY(hipMemcpyAsync(&n_active, d_nactive, sizeof(int), hipMemcpyDeviceToHost, st.stream));
-            ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
-        }
-        ASORA_HIP_TRY(hipMemcpy(h_nbox.data(), d_nbox, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost));
-        ASORA_HIP_TRY(hipMemcpy(h_loss.data(), d_loss_final, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost));
-        for (int s = 0; s < batch; ++s) { total_nbox += h_nbox[s]; total_loss += h_loss[s]; }   // f90:246-247, in source order
-        done += batch;
-    }
-
-    // fold the [k][j][i] accumulators, return the grids in Fortran order
-    if (int rc = launch_finish_phi(st)) return rc;
-    st.grid_valid[ASORA_GRID_PHI_ION] = true;
-    if (heat) {
-        if (int rc = launch_fold_transposed(st, st.heat_t, st.grid[ASORA_GRID_PHI_HEAT])) return rc;
-        st.grid_valid[ASORA_GRID_PHI_HEAT] = true;
-    }
     // the last source's column densities sit in the staging grid, which the 'F' download path below reuses:
     // take them out first, through nHI's transposed half (free once the sweep is over)
     if (int rc = launch_transpose(st, st.staging, st.nhi_t, N)) return rc;
@@ -772,6 +816,50 @@ int c2ray_do_all_sources(const double *normflux, const int32_t *srcpos, int max_
     if (int rc = asora_grid_to_host(ASORA_GRID_PHI_ION, phi_ion, N, 'F')) return rc;
     if (heat) { if (int rc = asora_grid_to_host(ASORA_GRID_PHI_HEAT, phi_heat, N, 'F')) return rc; }
     ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    if (sum_nbox) *sum_nbox = (int)total_nbox;
+    if (photon_loss) *photon_loss = total_loss;
+    return 0;
+}
+
+int asora_device_init_auto(int N)
+{
+    clear_error();
+    State &st = g_state;
+    if (!st.init || (st.auto_init && st.N != N)) {
+        // stateless for the caller, like the f2py functions it serves: the library sets itself up for this mesh
+        if (int rc = asora_device_init(N, 1)) return rc;
+        st.auto_init = true;
+        return 0;
+    }
+    return check_N("device_init_auto", N);
+}
+
+int asora_subbox_raytrace_device(int max_subbox, int subboxsize, float loss_fraction, double R_max_LLS, double sig, double dr,
+                                 double minlogtau, double dlogtau, int NumTau, int src_begin, int src_count,
+                                 int *sum_nbox, double *photon_loss)
+{
+    clear_error();
+    if (int rc = require_init("subbox_raytrace_device")) return rc;
+    State &st = g_state;
+    const char *who = "subbox_raytrace_device";
+    if (!st.grid_valid[ASORA_GRID_NDENS]) return fail(4, std::string(who) + ": density not on device");
+    if (!st.grid_valid[ASORA_GRID_XH_AV]) return fail(4, std::string(who) + ": xh_av not on device");
+    if (subboxsize < 1) return fail(3, std::string(who) + ": subboxsize must be >= 1");
+    const bool grey = st.opt[ASORA_OPT_GREY_NOTABLES] != 0;
+    if (!grey && (!st.tables || NumTau < 1)) return fail(4, std::string(who) + ": radiation tables not on device");
+    if (src_begin < 0 || src_count < 0 || src_begin + src_count > st.num_src)
+        return fail(4, std::string(who) + ": source range outside the uploaded sources");
+    const bool heat = !grey && st.opt[ASORA_OPT_HEATING] != 0;
+    if (heat && !st.have_heat_tables) return fail(4, std::string(who) + ": heating requested but no heating tables on device");
+    SubboxCall c;
+    c.max_subbox = max_subbox; c.subboxsize = subboxsize; c.loss_fraction = loss_fraction;
+    c.sig = sig; c.dr = dr; c.R = R_max_LLS; c.minlogtau = minlogtau; c.dlogtau = dlogtau; c.NumTau = NumTau;
+    c.table_len = st.table_len > 0 ? st.table_len : 1; c.tables = st.tables;
+    c.src_pos = st.src_pos; c.src_flux = st.src_flux; c.src_begin = src_begin; c.src_count = src_count;
+    c.heat = heat; c.keep_heat = false; c.dump = nullptr;
+    long long total_nbox = 0;
+    double total_loss = 0.0;
+    if (int rc = subbox_core(c, total_nbox, total_loss)) return rc;
     if (sum_nbox) *sum_nbox = (int)total_nbox;
     if (photon_loss) *photon_loss = total_loss;
     return 0;

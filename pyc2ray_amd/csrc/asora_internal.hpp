@@ -100,6 +100,11 @@ struct State {
     bool side_pending[2] = {false, false};
     int side_next = 0;
 
+    // per-source bookkeeping of the sub-box raytracer (subbox.hip), sized for the largest batch so far
+    int *sb_active = nullptr, *sb_nbox = nullptr, *sb_nactive = nullptr;
+    double *sb_loss = nullptr, *sb_loss_final = nullptr;
+    size_t subbox_cap = 0;
+
     // shell scratch for traces whose shell buffers exceed LDS
     double *shell_scratch = nullptr;
     size_t shell_scratch_bytes = 0;

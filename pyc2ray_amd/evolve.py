@@ -24,12 +24,13 @@ def _evolve_cpu_semantics(dt, dr, src_flux, src_pos, max_subbox, subboxsize, los
                           photo_thin_table, photo_thick_table, minlogtau, dlogtau, R_max_LLS, convergence_fraction,
                           sig, bh00, albpow, colh0, temph0, abu_c, logfile, quiet,
                           use_mpi=None, comm=None, rank=0, nprocs=1):
-    """The use_gpu=False branch of the reference (pyc2ray/evolve.py:168-245, :401-498): host arrays, one call of
-    libc2ray.raytracing.do_all_sources (cubic sub-boxes, photon-loss statistics) and one of
-    libc2ray.chemistry.global_pass per iteration.  Both keep the semantics of the reference's Fortran
-    functions but are evaluated on the GPU, so this branch pays two PCIe round trips of the grids per
-    iteration; use_gpu=True is the device-resident path."""
-    libc2ray = load_c2ray()
+    """The use_gpu=False branch of the reference (pyc2ray/evolve.py:168-245, :401-498): per iteration one pass of
+    the CPU library's raytracer -- cubic sub-boxes grown until the photon loss is below loss_fraction, photon-loss
+    statistics, Fortran-flavoured constants, every source rated with the flux of the last one as the Fortran does
+    -- and one global_pass.  Both are evaluated on the GPU, and like the use_gpu=True loop this one keeps the grids
+    on the device for the whole step (the reference's host round trips are what
+    ``libc2ray.raytracing.do_all_sources`` / ``libc2ray.chemistry.global_pass`` of this package still offer)."""
+    libasora = load_asora()
     distributed = bool(use_mpi) and comm is not None and nprocs > 1
     NumSrc = src_flux.shape[0]
     N = temp.shape[0]
@@ -40,9 +41,6 @@ def _evolve_cpu_semantics(dt, dr, src_flux, src_pos, max_subbox, subboxsize, los
     prev_sum_xh0_int = 2 * NumCells
     converged = False
     niter = 0
-    xh_av = np.copy(xh, order='F')                                                      # evolve.py:136-137
-    xh_intermed = np.copy(xh, order='F')
-    ndens_f, temp_f, xh_f = (np.asfortranarray(a, dtype=np.float64) for a in (ndens, temp, xh))
     if distributed:                                                                     # evolve.py:360-371
         perrank = NumSrc // nprocs
         i_start = int(rank * perrank)
@@ -50,7 +48,19 @@ def _evolve_cpu_semantics(dt, dr, src_flux, src_pos, max_subbox, subboxsize, los
         my_flux, my_pos = src_flux[i_start:i_end], np.asarray(src_pos)[:, i_start:i_end]
         printlog(f"...rank={rank:n} has {i_end - i_start:n} sources.", logfile, quiet)
     else:
-        my_flux, my_pos = src_flux, src_pos
+        my_flux, my_pos = src_flux, np.asarray(src_pos)
+    n_local = my_flux.shape[0]
+
+    # this branch has no device_init of its own in the reference: the library sets itself up for the mesh
+    libasora.device_init_auto(N)
+    libasora.photo_table_to_device(photo_thin_table, photo_thick_table, NumTau)
+    srcpos_flat, normflux_flat = format_sources(my_pos, my_flux)
+    libasora.source_data_to_device(srcpos_flat, normflux_flat, n_local)
+    libasora.grid_to_device(_capi.GRID_NDENS, ndens)
+    libasora.grid_to_device(_capi.GRID_TEMP, temp)
+    libasora.grid_to_device(_capi.GRID_XH, xh)
+    libasora.grid_copy(_capi.GRID_XH_AV, _capi.GRID_XH)          # xh_av = copy(xh)        evolve.py:136
+    libasora.grid_copy(_capi.GRID_XH_INTERMED, _capi.GRID_XH)    # xh_intermed = copy(xh)  evolve.py:137
     if rank == 0:
         printlog("Calling evolve3D...", logfile, quiet)
         printlog(f"dr [Mpc]: {dr/3.086e24:.3e}", logfile, quiet)
@@ -58,39 +68,23 @@ def _evolve_cpu_semantics(dt, dr, src_flux, src_pos, max_subbox, subboxsize, los
         printlog(f"Running on {NumSrc:n} source(s), total normalized ionizing flux: {src_flux.sum():.2e}", logfile, quiet)
         printlog(f"Mean density (cgs): {ndens.mean():.3e}, Mean ionized fraction: {xh.mean():.3e}", logfile, quiet)
         printlog(f"Convergence Criterion (Number of points): {conv_criterion : n}", logfile, quiet, end='\n\n')
-    phi_ion = np.zeros((N, N, N), order='F')
     while not converged:
         niter += 1
         trt0 = time.time()
         printlog("Doing Raytracing...", logfile, quiet, ' ')
-        phi_ion = np.zeros((N, N, N), order='F')                                        # evolve.py:178-182
-        phi_heat = np.zeros((N, N, N), order='F')
-        coldensh_out = np.zeros((N, N, N), order='F')
-        nsubbox, photonloss = libc2ray.raytracing.do_all_sources(
-            my_flux, my_pos, max_subbox, subboxsize, coldensh_out, sig, dr, ndens_f, xh_av, phi_ion, phi_heat,
-            loss_fraction, photo_thin_table, photo_thick_table, np.zeros(NumTau), np.zeros(NumTau),
-            minlogtau, dlogtau, R_max_LLS)
+        nsubbox, photonloss = libasora.subbox_raytrace_device(max_subbox, subboxsize, loss_fraction, R_max_LLS, sig, dr,
+                                                              minlogtau, dlogtau, NumTau, 0, n_local)
         printlog(f"took {(time.time()-trt0) : .1f} s.", logfile, quiet)
-        printlog(f"Average number of subboxes: {nsubbox/max(len(my_flux), 1):n}, Total photon loss: {photonloss:.3e}",
+        printlog(f"Average number of subboxes: {nsubbox/max(n_local, 1):n}, Total photon loss: {photonloss:.3e}",
                  logfile, quiet)
         if distributed:                                                                 # evolve.py:433-437
-            if hasattr(comm, "allreduce_device_grid"):
-                comm.Allreduce(use_mpi.IN_PLACE, [phi_ion, use_mpi.DOUBLE], op=use_mpi.SUM)
-            else:
-                if rank == 0:
-                    comm.Reduce(use_mpi.IN_PLACE, [phi_ion, use_mpi.DOUBLE], op=use_mpi.SUM, root=0)
-                else:
-                    comm.Reduce([phi_ion, use_mpi.DOUBLE], None, op=use_mpi.SUM, root=0)
-                comm.Bcast([phi_ion, use_mpi.DOUBLE], root=0)
+            _allreduce_phi(libasora, N, use_mpi, comm, rank)
         tch0 = time.time()
         if rank == 0:
             printlog("Doing Chemistry...", logfile, quiet, ' ')
-        conv_flag = libc2ray.chemistry.global_pass(dt, ndens_f, temp_f, xh_f, xh_av, xh_intermed, phi_ion,
-                                                   bh00, albpow, colh0, temph0, abu_c)  # evolve.py:210
+        conv_flag, sum_xh1_int, sum_xh0_int = libasora.chemistry_device(dt, bh00, albpow, colh0, temph0, abu_c)
         if rank == 0:
             printlog(f"took {(time.time()-tch0) : .1f} s.", logfile, quiet)
-        sum_xh1_int = np.sum(xh_intermed)                                               # evolve.py:216-217
-        sum_xh0_int = np.sum(1.0 - xh_intermed)
         rel_change_xh1 = np.abs((sum_xh1_int - prev_sum_xh1_int) / sum_xh1_int) if sum_xh1_int > 0.0 else 1.0
         rel_change_xh0 = np.abs((sum_xh0_int - prev_sum_xh0_int) / sum_xh0_int) if sum_xh0_int > 0.0 else 1.0
         if rank == 0:
@@ -102,8 +96,11 @@ def _evolve_cpu_semantics(dt, dr, src_flux, src_pos, max_subbox, subboxsize, los
         prev_sum_xh0_int = sum_xh0_int
     if rank == 0:
         printlog("Multiple source convergence reached.", logfile, quiet)
+    # Fortran-ordered results, as the reference's CPU branch returns them (evolve.py:178)
+    xh_new = libasora.grid_to_host(_capi.GRID_XH_INTERMED, np.empty((N, N, N), order='F'))
+    phi_ion = libasora.grid_to_host(_capi.GRID_PHI_ION, np.empty((N, N, N), order='F'))
     _evolve.last_niter = niter
-    return xh_intermed, phi_ion
+    return xh_new, phi_ion
 
 
 def _allreduce_phi(libasora, N, use_mpi, comm, rank):

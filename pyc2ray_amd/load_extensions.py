@@ -158,6 +158,20 @@ class _LibAsora:
                                                      C.byref(s0)), "chemistry_device")
         return conv.value, s1.value, s0.value
 
+    def device_init_auto(self, N):
+        _capi.check(self._lib.asora_device_init_auto(int(N)), "device_init_auto")
+
+    def subbox_raytrace_device(self, max_subbox, subboxsize, loss_fraction, R, sig, dr, minlogtau, dlogtau, NumTau,
+                               src_begin, src_count):
+        """(sum_nbox, photon_loss): the sub-box raytracer on the device-resident grids and uploaded sources."""
+        nbox = C.c_int(0)
+        loss = C.c_double(0.0)
+        _capi.check(self._lib.asora_subbox_raytrace_device(int(max_subbox), int(subboxsize), float(loss_fraction), float(R),
+                                                           float(sig), float(dr), float(minlogtau), float(dlogtau),
+                                                           int(NumTau), int(src_begin), int(src_count), C.byref(nbox),
+                                                           C.byref(loss)), "subbox_raytrace_device")
+        return nbox.value, loss.value
+
     def chemistry_range(self, dt, bh00, albpow, colh0, temph0, abu_c, i_begin, i_count, first):
         _capi.check(self._lib.asora_chemistry_range(float(dt), float(bh00), float(albpow), float(colh0), float(temph0),
                                                     float(abu_c), int(i_begin), int(i_count), int(bool(first))),

@@ -42,6 +42,25 @@ class OracleAsora:
                                            self.flux[src_begin:src_begin + src_count], self.thin, self.thick,
                                            minlogtau, dlogtau, NumTau=NumTau, flags=O.ASORA_MODE)["phi_ion"]
 
+    # the sub-box raytracer on resident grids (evolve3D with use_gpu=False)
+    def device_init_auto(self, N):
+        pass
+
+    def photo_table_to_device(self, thin, thick, NumTau):
+        self.thin, self.thick = np.array(thin), np.array(thick)
+
+    def subbox_raytrace_device(self, max_subbox, subboxsize, loss_fraction, R, sig, dr, minlogtau, dlogtau, NumTau,
+                               src_begin, src_count):
+        N = self.g[0].shape[0]
+        if src_count == 0:
+            self.g[2] = np.zeros((N, N, N))
+            return 0, 0.0
+        pos1 = self.pos[3 * src_begin:3 * (src_begin + src_count)].reshape(src_count, 3).T + 1
+        r = O.do_all_sources(self.flux[src_begin:src_begin + src_count], pos1, max_subbox, subboxsize, sig, dr, self.g[0],
+                             self.g[1], loss_fraction, self.thin, self.thick, minlogtau, dlogtau, R, NumTau=NumTau)
+        self.g[2] = np.ascontiguousarray(r["phi_ion"])
+        return r["nsubbox"], r["photon_loss"]
+
     # the three-part raytrace of the pipelined path
     def raytrace_begin(self, R, sig, dr, minlogtau, dlogtau, NumTau):
         N = self.g[0].shape[0]

@@ -64,7 +64,7 @@ def test_cpu_semantics_path_has_no_cpu_fallback(built):
     import pyc2ray_amd as p
     N = 8
     g = np.ones((N, N, N)) * 0.5
-    with pytest.raises(RuntimeError, match="do_all_sources failed"):
+    with pytest.raises(RuntimeError, match="device_init_auto failed"):
         p.evolve3D(1.0, 1.0, np.ones(1), np.ones((3, 1)), False, 10, 4, 0.01, g, g, g, np.ones(5), np.ones(5),
                    -20.0, 0.1, 4.0, 1e-4, 1e-18, 1.0, 1.0, 1.0, 1.0, 1.0, quiet=True, logfile=None)
     with pytest.raises(RuntimeError, match="do_all_sources failed"):
