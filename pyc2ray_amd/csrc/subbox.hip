@@ -29,7 +29,6 @@
 
 namespace asora {
 
-constexpr int SB_THREADS = 256;
 constexpr double S_STAR = 1e48;                     // photon-number normalisation, f90:28 / photorates.f90
 
 // dist2 exactly as the reference forms it (f90:452-456): no fused multiply-adds
@@ -39,6 +38,9 @@ __device__ __forceinline__ double dist2_reference(int a, int b, int c, double dr
     return __dadd_rn(__dadd_rn(__dmul_rn(xs, xs), __dmul_rn(ys, ys)), __dmul_rn(zs, zs));
 }
 
+// SB_THREADS = 256, or 1024 when there are fewer workgroups than CUs (a handful of sources: the launch then lasts
+// as long as one workgroup, so wider workgroups shorten it)
+template <int SB_THREADS>
 __global__ void __launch_bounds__(SB_THREADS) subbox_sweep_kernel(const SubboxParams p)
 {
     __shared__ double2 logtab[LOG_TABLE_SIZE];
@@ -247,7 +249,10 @@ int launch_subbox_sweep(State &st, const SubboxParams &p)
 {
     const unsigned grid = 64u * (unsigned)((p.src_count + 7) / 8);
     KernelTimer kt(ASORA_KERNEL_RAYTRACE);
-    hipLaunchKernelGGL(subbox_sweep_kernel, dim3(grid), dim3(SB_THREADS), 0, st.stream, p);
+    if ((long)p.src_count * 8 < (long)st.cu_count)
+        hipLaunchKernelGGL(subbox_sweep_kernel<1024>, dim3(grid), dim3(1024), 0, st.stream, p);
+    else
+        hipLaunchKernelGGL(subbox_sweep_kernel<256>, dim3(grid), dim3(256), 0, st.stream, p);
     ASORA_HIP_TRY(hipGetLastError());
     return 0;
 }
