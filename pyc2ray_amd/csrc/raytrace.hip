@@ -77,7 +77,10 @@ __device__ __forceinline__ RateJob rate_issue(double flux, double cd_in, double 
 __device__ __forceinline__ double rate_value(const RateJob &J)
 {
     const double a = lookup_value(J.A), b = lookup_value(J.B);
-    return J.thick ? J.pref * a - J.pref * b : J.pref * J.dtau * a;
+    // (pref*(a - b), not pref*a - pref*b: the compiler would fuse the latter into fma(pref, a, -(pref*b)), which
+    //  leaves the rounding error of pref*b -- a random-signed ~1e-16 relative speck -- where a == b, e.g. beyond the
+    //  last table entry, where the reference's un-fused arithmetic gives exactly 0)
+    return J.thick ? J.pref * (a - b) : J.pref * J.dtau * a;
 }
 
 // photoion_rates_test_gpu rates.cu:48-64 (analytic grey rates, GREY_NOTABLES builds), per atom
@@ -358,7 +361,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
             }
             {
                 const double ta = lookup_value(A), tb = lookup_value(B);
-                late_v = thick ? pref * ta - pref * tb : pref * dtau * ta;
+                late_v = thick ? pref * (ta - tb) : pref * dtau * ta;     // see rate_value on the form of the difference
                 if (HEAT) {      // photorates.f90:118,124 with the same table index and residual
                     const double ha = lookup_heat(A), hb = lookup_heat(B);
                     late_h = thick ? pref * (ha - hb) : pref * dtau * ha;
@@ -369,7 +372,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
 #else
             if (rated) {
                 const double ta = lookup_value(A), tb = lookup_value(B);
-                ASORA_RATE_ATOMIC(dst, thick ? pref * ta - pref * tb : pref * dtau * ta);
+                ASORA_RATE_ATOMIC(dst, thick ? pref * (ta - tb) : pref * dtau * ta);
                 if (HEAT) {      // photorates.f90:118,124 with the same table index and residual
                     const double ha = lookup_heat(A), hb = lookup_heat(B);
                     unsafeAtomicAdd(p.heat + (dst - p.phi), thick ? pref * (ha - hb) : pref * dtau * ha);

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(SB_THREADS) subbox_sweep_kernel(const SubboxPa
             if (p.grey) {                                                             // photorates.f90:13-57
                 const double pref = flux * S_STAR / vol;
                 const double phi_in = pref * exp(-tau_in);
-                if (thick) { phi_out = pref * exp(-tau_out); phi = phi_in - phi_out; }
+                if (thick) { const double eo = exp(-tau_out); phi_out = pref * eo; phi = pref * (exp(-tau_in) - eo); }
                 else       { phi = pref * dtau * exp(-tau_in); phi_out = phi_in - phi; }
             } else {                                                                  // photorates.f90:62-125
                 const double pref = flux / vol;
@@ -104,8 +104,11 @@ __global__ void __launch_bounds__(SB_THREADS) subbox_sweep_kernel(const SubboxPa
                                        : lookup_issue<true>(p.tables + p.table_len, tau_in, p, logtab);   // thin, tau_in
                 const double phi_in = pref * lookup_value(A);
                 if (thick) {
-                    phi_out = pref * lookup_value(B);
-                    phi = phi_in - phi_out;
+                    // (pref*(T_in - T_out): phi_in - phi_out would be fused into fma(pref, T_in, -phi_out) and leave the
+                    //  rounding error of phi_out where the two table values are equal, e.g. beyond the last entry)
+                    const double tb = lookup_value(B);
+                    phi_out = pref * tb;
+                    phi = pref * (lookup_value(A) - tb);
                     heat = pref * (lookup_heat(A) - lookup_heat(B));
                 } else {
                     phi = pref * dtau * lookup_value(B);

@@ -650,3 +650,38 @@ def test_pipelined_raytrace_allreduce_world1(asora, monkeypatch):
     with pytest.raises(RuntimeError, match="no raytrace in progress"):
         lib.raytrace_fold(0, N)
     p.device_close()
+
+
+def test_beyond_the_last_table_entry_rates_are_exactly_zero(asora):
+    """A medium so thick that the optical depth passes the last table entry (10^maxlogtau) a dozen cells from the
+    source -- the reference benchmark's own medium does (tau = 228 per cell at 256^3).  Both table lookups then
+    return the last entry and the reference's rate is EXACTLY 0; a fused pref*T_in - pref*T_out would leave the
+    rounding error of one product there (random sign, ~1e-16 of the product).  Both GPU raytracers must give exact
+    zeros on the oracle's zero set and no negative rate anywhere."""
+    p, lib, capi = asora
+    from pyc2ray_amd.load_extensions import load_c2ray
+    N = 32
+    nd, xh, dr = cases.grid(N, "uniform", 0, 900.0)
+    pos, flux = cases.sources(N, 3, 71, flux=1.0)
+    thin, thick, dlog = cases.soft_tables()
+    c = dict(N=N, ndens=nd, xh=xh, dr=dr, pos=pos, flux=flux, thin=thin, thick=thick)
+    pos0, f0 = _setup(p, lib, c, N)
+    lib.grid_to_device(capi.GRID_XH_AV, xh)
+    numtau = thin.shape[0]
+    ref = O.asora_do_all_sources(1000.0, cases.SIG, dr, nd, xh, pos0, f0, thin, thick, cases.MINLOGTAU, dlog, NumTau=numtau,
+                                 flags=O.ASORA_MODE)["phi_ion"]
+    assert (ref == 0).sum() > 0.3 * N ** 3 and (ref > 0).sum() > 1000      # the case does what it is meant to
+    for mode in (1, 2, 3):
+        lib.set_option(capi.OPT_SECTORS, mode)
+        lib.raytrace_device(1000.0, cases.SIG, dr, 0, 3, cases.MINLOGTAU, dlog, numtau)
+        phi = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+        assert not (phi < 0).any()
+        assert np.array_equal(phi == 0, ref == 0)
+        w = ref != 0
+        np.testing.assert_allclose(phi[w], ref[w], rtol=GAMMA_RTOL)
+    lib.set_option(capi.OPT_SECTORS, 0)
+    phi_f = np.zeros((N, N, N), order="F"); heat = np.zeros((N, N, N), order="F"); cd = np.zeros((N, N, N), order="F")
+    load_c2ray().raytracing.do_all_sources(flux, pos, 1000, N, cd, cases.SIG, dr, nd, xh, phi_f, heat, 0.0, thin, thick,
+                                           np.zeros(numtau), np.zeros(numtau), cases.MINLOGTAU, dlog, 1000.0)
+    ref_f = O.do_all_sources(flux, pos, 1000, N, cases.SIG, dr, nd, xh, 0.0, thin, thick, cases.MINLOGTAU, dlog, 1000.0)["phi_ion"]
+    assert not (phi_f < 0).any() and np.array_equal(phi_f == 0, ref_f == 0)
