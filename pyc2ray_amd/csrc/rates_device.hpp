@@ -59,6 +59,21 @@ __device__ __forceinline__ Lookup lookup_issue(const double2 *__restrict__ table
 __device__ __forceinline__ double lookup_value(const Lookup &L) { return fma(L.residual, L.t.y, L.t.x); }
 __device__ __forceinline__ double lookup_heat(const Lookup &L) { return fma(L.residual, L.h.y, L.h.x); }
 
+// Products and sums that must NOT be contracted into a fused multiply-add, where the reference's result depends on
+// each operation being rounded on its own (device code is compiled with -ffp-contract=fast, and HIP's __dmul_rn /
+// __dadd_rn are plain operators that get contracted after inlining).  Instructions emitted under contract(off) carry
+// no `contract` flag, so the backend leaves them alone wherever they are inlined.
+__device__ __forceinline__ double mul_unfused(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ double add_unfused(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a + b;
+}
+
 __device__ __forceinline__ int wrap_once(int x, int N)
 {
     return x < 0 ? x + N : (x >= N ? x - N : x);

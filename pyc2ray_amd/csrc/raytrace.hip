@@ -58,8 +58,11 @@ struct RateJob {
 __device__ __forceinline__ RateJob rate_issue(double flux, double cd_in, double cd_out, double vol_nhi,
                                               const RtParams &p, const double2 *__restrict__ logtab)
 {
-    const double tau_in = cd_in * p.sig;
-    const double tau_out = cd_out * p.sig;
+    // (un-fused products: tau_out - tau_in must be the difference of the two ROUNDED optical depths, as in the
+    //  reference; fused into fma(cd_out, sig, -tau_in) it would carry the rounding error of one product -- a speck
+    //  instead of 0 where nHI = 0, and a 1e-8 relative change of dtau for thin cells)
+    const double tau_in = mul_unfused(cd_in, p.sig);
+    const double tau_out = mul_unfused(cd_out, p.sig);
     // TAU_PHOTO_LIMIT: rates.cu:7 (double 1e-7) or photorates.f90:69 (single 1e-7 promoted)
     const double limit = p.fortran_consts ? (double)1.0e-7f : 1.0e-7;
     RateJob J;
@@ -87,7 +90,7 @@ __device__ __forceinline__ double rate_value(const RateJob &J)
 __device__ __forceinline__ double grey_rate_per_atom(double flux, double cd_in, double cd_out, double vol_nhi,
                                                      const RtParams &p)
 {
-    const double tau_in = cd_in * p.sig, tau_out = cd_out * p.sig;
+    const double tau_in = mul_unfused(cd_in, p.sig), tau_out = mul_unfused(cd_out, p.sig);   // un-fused, see rate_issue
     const double limit = p.fortran_consts ? (double)1.0e-7f : 1.0e-7;
     const double pref = flux * 1e48 / vol_nhi;
     if (fabs(tau_out - tau_in) > limit) return pref * (exp(-tau_in) - exp(-tau_out));
@@ -98,7 +101,7 @@ __device__ __forceinline__ double grey_rate_per_atom(double flux, double cd_in, 
 __device__ __forceinline__ double heat_rate_per_atom(double flux, double cd_in, double cd_out, double vol_nhi,
                                                      const RtParams &p, const double2 *__restrict__ logtab)
 {
-    const double tau_in = cd_in * p.sig, tau_out = cd_out * p.sig;
+    const double tau_in = mul_unfused(cd_in, p.sig), tau_out = mul_unfused(cd_out, p.sig);   // un-fused, see rate_issue
     const double limit = p.fortran_consts ? (double)1.0e-7f : 1.0e-7;
     const double pref = flux / vol_nhi;
     const bool thick = fabs(tau_out - tau_in) > limit;
@@ -343,7 +346,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
             if (rated) unsafeAtomicAdd(dst, grey_rate_per_atom(flux, cd_in, cd_out, vol_nhi, p));
         } else if (wave_has_work) {
             // (lanes without a rate run the lookups on whatever they hold: the index is clamped for any input)
-            const double tau_in = cd_in * sig, tau_out = cd_out * sig;
+            const double tau_in = mul_unfused(cd_in, sig), tau_out = mul_unfused(cd_out, sig);   // un-fused, see rate_issue
             // TAU_PHOTO_LIMIT: rates.cu:7 (double 1e-7) or photorates.f90:69 (single 1e-7 promoted)
             const double limit = p.fortran_consts ? (double)1.0e-7f : 1.0e-7;
             const double pref = flux / vol_nhi;

@@ -34,8 +34,8 @@ constexpr double S_STAR = 1e48;                     // photon-number normalisati
 // dist2 exactly as the reference forms it (f90:452-456): no fused multiply-adds
 __device__ __forceinline__ double dist2_reference(int a, int b, int c, double dr)
 {
-    const double xs = __dmul_rn(dr, (double)a), ys = __dmul_rn(dr, (double)b), zs = __dmul_rn(dr, (double)c);
-    return __dadd_rn(__dadd_rn(__dmul_rn(xs, xs), __dmul_rn(ys, ys)), __dmul_rn(zs, zs));
+    const double xs = mul_unfused(dr, (double)a), ys = mul_unfused(dr, (double)b), zs = mul_unfused(dr, (double)c);
+    return add_unfused(add_unfused(mul_unfused(xs, xs), mul_unfused(ys, ys)), mul_unfused(zs, zs));
 }
 
 // SB_THREADS = 256, or 1024 when there are fewer workgroups than CUs (a handful of sources: the launch then lasts
@@ -88,7 +88,8 @@ __global__ void __launch_bounds__(SB_THREADS) subbox_sweep_kernel(const SubboxPa
         if (dump) p.dump[idx_plain] = cd_out;
         double phi_out = 0.0;     // a cell that deposits nothing leaves the reference's phi_out undefined: 0 here
         if (!stop) {
-            const double tau_in = cd_in * sig, tau_out = cd_out * sig;
+            // (un-fused products: tau_out - tau_in is the difference of the two ROUNDED optical depths, as in the reference)
+            const double tau_in = mul_unfused(cd_in, sig), tau_out = mul_unfused(cd_out, sig);
             const double dtau = tau_out - tau_in;
             const bool thick = fabs(dtau) > limit;
             double phi, heat = 0.0;

@@ -685,3 +685,44 @@ def test_beyond_the_last_table_entry_rates_are_exactly_zero(asora):
                                            np.zeros(numtau), np.zeros(numtau), cases.MINLOGTAU, dlog, 1000.0)
     ref_f = O.do_all_sources(flux, pos, 1000, N, cases.SIG, dr, nd, xh, 0.0, thin, thick, cases.MINLOGTAU, dlog, 1000.0)["phi_ion"]
     assert not (phi_f < 0).any() and np.array_equal(phi_f == 0, ref_f == 0)
+
+
+def test_fully_ionised_and_empty_cells_behave_like_the_reference(asora):
+    """Cells with nHI = 0 (x = 1 exactly, or no gas): the reference divides the cell's rate by nHI unguarded
+    (raytracing.cu:324, raytracing.f90:531), so such a cell ends up with NaN while the column density passes through
+    it unchanged and every other cell is unaffected.  Same here, in both GPU raytracers."""
+    p, lib, capi = asora
+    from pyc2ray_amd.load_extensions import load_c2ray
+    c = cases.rt_case("l16_7src_R5.5", "soft")
+    N = c["N"]
+    xh = c["xh"].copy()
+    nd = c["ndens"].copy()
+    rng = np.random.default_rng(9)
+    holes = rng.integers(0, N, size=(40, 3))
+    for q, (i, j, k) in enumerate(holes):
+        if q % 2:
+            xh[i, j, k] = 1.0
+        else:
+            nd[i, j, k] = 0.0
+    c = dict(c, xh=xh, ndens=nd, R=1000.0)
+    pos0, flux = _setup(p, lib, c, N)
+    numtau = c["thin"].shape[0] - 1
+    with np.errstate(all="ignore"):
+        ref = O.asora_do_all_sources(c["R"], c["sig"], c["dr"], nd, xh, pos0, flux, c["thin"], c["thick"], c["minlogtau"],
+                                     c["dlogtau"], NumTau=numtau, flags=O.ASORA_MODE)["phi_ion"]
+    assert np.isnan(ref).sum() >= 30 and np.isfinite(ref).sum() > 0.9 * N ** 3
+    phi = _asora_call(lib, c, N, numtau)
+    assert np.array_equal(np.isnan(phi), np.isnan(ref))
+    ok = np.isfinite(ref)
+    np.testing.assert_allclose(phi[ok], ref[ok], rtol=GAMMA_RTOL)
+    phi_f = np.zeros((N, N, N), order="F"); heat = np.zeros((N, N, N), order="F"); cd = np.zeros((N, N, N), order="F")
+    load_c2ray().raytracing.do_all_sources(c["flux"], c["pos"], 1000, N, cd, c["sig"], c["dr"], nd, xh, phi_f, heat, 0.0,
+                                           c["thin"][:numtau], c["thick"][:numtau], np.zeros(numtau), np.zeros(numtau),
+                                           c["minlogtau"], c["dlogtau"], 1000.0)
+    with np.errstate(all="ignore"):
+        r = O.do_all_sources(c["flux"], c["pos"], 1000, N, c["sig"], c["dr"], nd, xh, 0.0, c["thin"][:numtau],
+                             c["thick"][:numtau], c["minlogtau"], c["dlogtau"], 1000.0)
+    assert np.array_equal(np.isnan(phi_f), np.isnan(r["phi_ion"]))
+    ok = np.isfinite(r["phi_ion"])
+    np.testing.assert_allclose(phi_f[ok], r["phi_ion"][ok], rtol=1e-8, atol=1e-14 * np.nanmax(r["phi_ion"]))
+    np.testing.assert_allclose(cd, r["coldens"], rtol=1e-11)
