@@ -726,3 +726,75 @@ def test_fully_ionised_and_empty_cells_behave_like_the_reference(asora):
     ok = np.isfinite(r["phi_ion"])
     np.testing.assert_allclose(phi_f[ok], r["phi_ion"][ok], rtol=1e-8, atol=1e-14 * np.nanmax(r["phi_ion"]))
     np.testing.assert_allclose(cd, r["coldens"], rtol=1e-11)
+
+
+def test_randomised_asora_parameters_against_oracle(asora):
+    """Seeded sweep of the ASORA path: mesh sizes (odd and even), radii from below one cell to beyond the box
+    (integers included: cells exactly on the sphere), source counts with corner and duplicate positions, opacities
+    from thin to beyond the last table entry, both NumTau conventions, both constant flavours."""
+    p, lib, capi = asora
+    rng = np.random.default_rng(4242)
+    thin, thick, dlog = cases.soft_tables(500)
+    for trial in range(30):
+        N = int(rng.choice([9, 12, 16, 20, 24]))
+        ns = int(rng.integers(1, 7))
+        R = float(rng.choice([0.4, 1.0, 2.5, 3.0, 5.0, 7.3, N / 2, N * 0.9, 1000.0]))
+        tau_cell = float(10 ** rng.uniform(-9.0, 3.2))
+        kind = "lognormal" if trial % 3 else "uniform"
+        nd, xh, dr = cases.grid(N, kind, 300 + trial, tau_cell)
+        pos = 1 + rng.integers(0, N, size=(3, ns))
+        if trial % 4 == 0:
+            pos[:, 0] = [N, 1, N]
+        if ns > 1 and trial % 5 == 0:
+            pos[:, 1] = pos[:, 0]                               # two sources in one cell
+        flux = rng.uniform(0.2, 5.0, size=ns)
+        numtau = thin.shape[0] - (trial % 2)                    # len (evolve.py:124) or len-1 (the benchmark)
+        fortran = (trial // 2) % 2
+        c = dict(N=N, ndens=nd, xh=xh, dr=dr, pos=pos, flux=flux, thin=thin, thick=thick)
+        pos0, f0 = _setup(p, lib, c, N)
+        lib.grid_to_device(capi.GRID_XH_AV, xh)
+        lib.set_option(capi.OPT_FORTRAN_CONSTANTS, fortran)
+        try:
+            lib.raytrace_device(R, cases.SIG, dr, 0, ns, cases.MINLOGTAU, dlog, numtau)
+            phi = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+            gam, ev = lib.last_raytrace_counts()
+        finally:
+            lib.set_option(capi.OPT_FORTRAN_CONSTANTS, 0)
+        flags = O.PER_SOURCE_FLUX if fortran else O.ASORA_MODE
+        ref = O.asora_do_all_sources(R, cases.SIG, dr, nd, xh, pos0, f0, thin, thick, cases.MINLOGTAU, dlog, NumTau=numtau,
+                                     flags=flags)
+        tag = f"trial {trial}: N={N} ns={ns} R={R} tau={tau_cell:.3g} numtau={numtau} fortran={fortran}"
+        assert np.array_equal(phi != 0, ref["phi_ion"] != 0), tag
+        assert not (phi < 0).any(), tag
+        scale = ref["phi_ion"].max()
+        np.testing.assert_allclose(phi, ref["phi_ion"], rtol=GAMMA_RTOL, atol=1e-13 * scale, err_msg=tag)
+        assert ev >= gam >= (ref["phi_ion"] != 0).sum(), tag
+
+
+def test_randomised_chemistry_extremes_against_oracle(asora):
+    """The fused chemistry kernel over a lattice of extreme inputs drawn cell by cell (rates from 0 to 1 s^-1,
+    ionised fractions from 1e-14 to exactly 1, densities over nine decades, temperatures from 10 K to 1e6 K, time
+    steps from a second to 1e18 s) against the oracle's global_pass: fields to 1e-9 (+1e-15 absolute), the
+    count of non-converged cells to a handful (a cell sitting on one of the three thresholds may fall either way)."""
+    from pyc2ray_amd.load_extensions import load_c2ray
+    chem = load_c2ray().chemistry
+    rng = np.random.default_rng(77)
+    N = 14
+    shape = (N, N, N)
+    for trial, dt in enumerate([1.0, 3.15576e10, 3.15576e13, 1e15, 1e18]):
+        phi = rng.choice([0.0, 1e-30, 1e-18, 1e-14, 1e-12, 1e-9, 1e-6, 1.0], size=shape)
+        x0 = rng.choice([1e-14, 1e-6, 2e-4, 0.3, 1.0 - 1e-9, 1.0], size=shape)
+        xav = np.clip(x0 * rng.uniform(0.3, 1.7, size=shape), 1e-14, 1.0)
+        nd = rng.choice([1e-8, 1e-5, 1e-3, 0.1, 10.0], size=shape)
+        temp = rng.choice([10.0, 1e3, 1e4, 5e4, 1e6], size=shape)
+        xa_ref, xi_ref, conv_ref, _ = O.global_pass(dt, nd, temp, x0, xav, x0, phi, cases.BH00, cases.ALBPOW, cases.COLH0,
+                                                    cases.TEMPH0, cases.ABU_C)
+        xa, xi = xav.copy(), x0.copy()
+        conv = chem.global_pass(dt, nd, temp, x0, xa, xi, phi, cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0,
+                                cases.ABU_C)
+        # (atol: x = (x0 - x_eq) e^{-t/t_i} + x_eq cancels to ~1e-16 absolute when x0 << x_eq and t << t_i; the kernel
+        #  forms it with one fused multiply-add, the reference with two roundings)
+        np.testing.assert_allclose(xa, xa_ref, rtol=1e-9, atol=1e-15, err_msg=f"xh_av, dt={dt}")
+        np.testing.assert_allclose(xi, xi_ref, rtol=1e-9, atol=1e-15, err_msg=f"xh_intermed, dt={dt}")
+        assert abs(conv - conv_ref) <= 3, (dt, conv, conv_ref)
+        assert np.isfinite(xa).all() and (xa >= 1e-14).all() and (xa <= 1.0).all()
