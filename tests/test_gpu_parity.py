@@ -619,6 +619,25 @@ def test_pipelined_raytrace_allreduce_world1(asora, monkeypatch):
         with pytest.raises(ValueError, match="ascending"):
             comm.raytrace_and_allreduce(lib, N, R, cases.SIG, dr, 40, cases.MINLOGTAU, dlog, numtau,
                                         src_i0=(spos[0].astype(np.int64) - 1)[::-1])
+    # ... the heating accumulator is folded slab by slab as well
+    lib.heat_table_to_device(2e-11 * thin, 1e-11 * thick, thin.shape[0])
+    lib.set_option(capi.OPT_HEATING, 1)
+    try:
+        _ = pos  # same sources
+        comm = pd.TorchComm(overlap=True, chunks=6)
+        spos, sflux = comm.sort_sources_for_overlap(pos, flux)
+        p0, f0 = cases.flat_sources(spos, sflux)
+        lib.source_data_to_device(p0, f0, 40)
+        lib.raytrace_device(9.5, cases.SIG, dr, 0, 40, cases.MINLOGTAU, dlog, numtau)
+        heat_plain = lib.grid_to_host(capi.GRID_PHI_HEAT, np.empty((N, N, N)))
+        comm.raytrace_and_allreduce(lib, N, 9.5, cases.SIG, dr, 40, cases.MINLOGTAU, dlog, numtau,
+                                    src_i0=spos[0].astype(np.int64) - 1)
+        lib.synchronize()
+        heat_piped = lib.grid_to_host(capi.GRID_PHI_HEAT, np.empty((N, N, N)))
+        assert heat_plain.max() > 0
+        np.testing.assert_allclose(heat_piped, heat_plain, rtol=1e-12, atol=1e-300)
+    finally:
+        lib.set_option(capi.OPT_HEATING, 0)
     # ... and with the chemistry pipelined behind each slab's sum: same grids, same convergence scalars
     chem = (3.15576e13, cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C)
     temp = np.full((N, N, N), 1e4)
