@@ -116,3 +116,28 @@ def test_tau_and_blackbody_tables():
     pl = BlackBodySource(1e5, False, ev2fr * 13.598, 2.8)
     thin, thick = pl.make_photo_table(tau, ev2fr * 13.598, 10 * ev2fr * 54.416, 1e48)
     assert np.isclose(thick[0], 1e48) and np.all(np.diff(thick) <= 1e-9 * thick[0]) and thin[0] < thick[0]
+
+
+def test_blackbody_heating_tables_grey_closed_form():
+    """Grey opacity: every photon sees the same optical depth, so both heating tables are H0 * exp(-tau) with
+    H0 = int h (nu - nu_HI) S(nu) dnu, and the mean energy per ionisation H0/S_star lies between 0 and
+    h (nu_max - nu_HI)."""
+    from scipy.integrate import quad
+    from pyc2ray_amd.radiation import BlackBodySource, make_tau_table
+    from pyc2ray_amd.radiation.blackbody import hplanck, ion_freq_HI
+    tau, _ = make_tau_table(-20.0, 4.0, 120)
+    ev2fr = 0.241838e15
+    f1, f2 = ev2fr * 13.598, 10 * ev2fr * 54.416
+    src = BlackBodySource(5e4, True, f1, 2.8)
+    hthin, hthick = src.make_heat_table(tau, f1, f2, 1e48)
+    H0 = quad(lambda f: hplanck * (f - ion_freq_HI) * src.SED(f), f1, f2, epsrel=1e-12)[0]
+    assert 0.0 < H0 / 1e48 < hplanck * (f2 - ion_freq_HI)
+    keep = tau < 600.0
+    np.testing.assert_allclose(hthick[keep], H0 * np.exp(-tau[keep]), rtol=1e-8, atol=1e-300)
+    np.testing.assert_allclose(hthin[keep], H0 * np.exp(-tau[keep]), rtol=1e-8, atol=1e-300)
+    # non-grey: harder photons are absorbed less, so the thick table falls more slowly than exp(-tau)
+    src2 = BlackBodySource(5e4, False, f1, 2.8)
+    h2thin, h2thick = src2.make_heat_table(tau, f1, f2, 1e48)
+    i = int(np.searchsorted(tau, 5.0))
+    assert h2thick[i] / h2thick[0] > np.exp(-tau[i])
+    assert np.all(np.diff(h2thick) <= 1e-9 * h2thick[0])
