@@ -279,11 +279,14 @@ def main():
         import torch
         import torch.distributed as dist
         from pyc2ray_amd.dist import TorchComm, init_process_group_from_env
-        init_process_group_from_env("nccl")
+        # (rehearsal of the multi-rank logic on a box with ONE GPU: PYC2RAY_AMD_BENCH_BACKEND=gloo puts every rank on
+        #  device PYC2RAY_AMD_BENCH_DEVICE and stages the sums through the host; never the measured configuration)
+        backend = os.environ.get("PYC2RAY_AMD_BENCH_BACKEND", "nccl")
+        init_process_group_from_env(backend)
         comm = TorchComm()
 
     lib = load_asora()
-    p.device_init(N, 64, device_id=local_rank)
+    p.device_init(N, 64, device_id=int(os.environ.get("PYC2RAY_AMD_BENCH_DEVICE", local_rank)))
     thin, thick, dlog = tables if tables is not None else make_tables()
     p.photo_table_to_device(thin, thick)
     numtau = thin.shape[0] - 1                  # as raytracing_benchmark/run_test.py:85 passes it
@@ -348,7 +351,8 @@ def main():
     if comm is not None:
         import torch
         import torch.distributed as dist
-        t = torch.tensor([elapsed, float(gamma_cells)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, float(gamma_cells)], dtype=torch.float64,
+                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
