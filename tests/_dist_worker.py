@@ -12,7 +12,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     overlap = len(sys.argv) > 5 and sys.argv[5] == "overlap"
-    cpu_semantics = len(sys.argv) > 5 and sys.argv[5] == "cpu_semantics"
+    cpu_semantics = len(sys.argv) > 5 and sys.argv[5] in ("cpu_semantics", "real_cpu_semantics")
+    real = len(sys.argv) > 5 and sys.argv[5].startswith("real_")      # the HIP library itself, every rank on GPU 0
+    overlap = overlap or (len(sys.argv) > 5 and sys.argv[5] == "real_overlap")
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     import cases
@@ -46,9 +48,14 @@ def main():
     pos, flux = cases.sources(N, 5, 52, flux=30.0)       # 5 sources over 2 ranks: 2 + 3
     thin, thick, dlog = cases.soft_tables()
     fake = OracleAsora(thin, thick)
-    ev.load_asora = lambda: fake
-    ev.cuda_is_init = lambda: True
-    ev.load_c2ray = lambda: OracleC2Ray()
+    if real:
+        import pyc2ray_amd as p
+        p.device_init(N, 8, device_id=0)
+        p.photo_table_to_device(thin, thick)
+    else:
+        ev.load_asora = lambda: fake
+        ev.cuda_is_init = lambda: True
+        ev.load_c2ray = lambda: OracleC2Ray()
     xh_new, phi = ev.evolve3D_MPI(3.15576e13 * 5, dr, flux, pos, not cpu_semantics, 1000, 3, 1e-2, pd.MPI, comm, rank, world,
                                   temp, nd, xh, thin, thick, cases.MINLOGTAU, dlog, 6.0, 1e-4, cases.SIG,
                                   cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C,
