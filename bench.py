@@ -358,6 +358,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0].item())
         tot_gamma = int(round(t[1].item()))
+    # after the timed region: every rank must hold the same summed rates and the same chemistry result
+    ranks_agree = None
+    if comm is not None:
+        try:
+            phi_h = lib.grid_to_host(_capi.GRID_PHI_ION, np.empty((N, N, N)))
+            x_h = lib.grid_to_host(_capi.GRID_XH_INTERMED, np.empty((N, N, N)))
+            mine = torch.tensor([float(phi_h.sum()), float(np.abs(phi_h).max()), float(x_h.sum())], dtype=torch.float64,
+                                device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            lo_, hi_ = mine.clone(), mine.clone()
+            dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+            ranks_agree = bool(torch.equal(lo_, hi_)) and bool(np.isfinite(phi_h).all()) and float(phi_h.sum()) > 0.0
+        except Exception as e:    # reporting only
+            print(f"bench: rank-agreement check failed: {type(e).__name__}: {e}", file=sys.stderr)
 
     if comm is not None:
         import torch.distributed as dist
@@ -390,6 +404,7 @@ def main():
         "config": {
             "workload": workload_label(args.workload, N, args.nsrc, args.R),
             "grid": N, "sources_per_gpu": args.nsrc, "R_cells": args.R, "numtau": NUMTAU,
+            "ranks_agree_on_rates_and_ionised_fraction": ranks_agree,
             "parallelism": (f"sources x{world}, rate-grid all-reduce " + ("pipelined with the trace" if overlap else "after the trace"))
                            if world > 1 else "single GPU",
             "unit_definition": "rate-receiving (source,cell) pairs (|d|<=R) + N^3 chemistry cells per step",
