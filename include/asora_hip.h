@@ -186,6 +186,32 @@ int asora_chemistry_range(double dt, double bh00, double albpow, double colh0, d
                           int i_begin, int i_count, int first);
 int asora_chemistry_finish(int *conv_flag, double *sum_xh1, double *sum_xh0);
 
+/* The whole outer loop of evolve3D (pyc2ray/evolve.py:168-240) on the device.  Per iteration the host of the
+ * reference uploads xh_av, downloads phi_ion, reshapes, runs global_pass, forms two sums with numpy and tests
+ * convergence (evolve.py:187,200,210,216-236); here an iteration is three launches -- the raytrace, ONE pass over
+ * the grids that folds the rate accumulators, solves the chemistry, forms nHI of the new xh_av in both layouts for
+ * the next raytrace and zeroes the accumulators, and a one-workgroup kernel that finishes the three reductions and
+ * evaluates the convergence test -- so several iterations can be enqueued without the host in between; launches
+ * enqueued beyond convergence see the device flag and do nothing, so the iteration count is exactly the reference's.
+ *   asora_evolve_begin    NDENS, TEMP, XH must be on the device; xh_av = xh_intermed = xh (evolve.py:136-137) is implied.
+ *                         conv_criterion = min(int(convergence_fraction N^3), (NumSrc-1)/3) (evolve.py:127) is the
+ *                         caller's to compute (NumSrc is the TOTAL source count, evolve.py:346).
+ *   asora_evolve_enqueue  enqueues `iterations` (1..32) outer iterations; asynchronous.
+ *   asora_evolve_poll     waits for what was enqueued; returns the iterations carried out so far, whether the test has
+ *                         passed, and one row {conv_flag, sum(xh_intermed), sum(1-xh_intermed), rel_change_xh1,
+ *                         rel_change_xh0} per iteration not reported yet (at most history_rows rows).
+ * Results: ASORA_GRID_XH_INTERMED (xh_new), ASORA_GRID_XH_AV, ASORA_GRID_PHI_ION. */
+int asora_evolve_begin(double dt, double bh00, double albpow, double colh0, double temph0, double abu_c,
+                       double R, double sig, double dr, double minlogtau, double dlogtau, int NumTau,
+                       int src_begin, int src_count, double conv_criterion, double convergence_fraction);
+int asora_evolve_enqueue(int iterations);
+int asora_evolve_poll(int *niter, int *converged, double *history, int history_rows, int *rows_written);
+
+/* Runs of i-planes [i_begin, i_begin + i_count) of a grid to / from a host buffer of i_count*N*N doubles (C order).
+ * What multi-GPU ranks exchange are such runs: the planes a rank's sources reach, the planes whose chemistry it owns. */
+int asora_planes_to_host(int which, int i_begin, int i_count, double *host);
+int asora_planes_to_device(int which, int i_begin, int i_count, const double *host);
+
 /* ------------------------------------------------------------------------------------------ */
 /* C. Options, measurement and diagnostics                                                     */
 /* ------------------------------------------------------------------------------------------ */

@@ -53,6 +53,11 @@ SIGNATURES = {
     "asora_chemistry_range": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                         C.c_int, C.c_int, C.c_int]),
     "asora_chemistry_finish": (C.c_int, [C.POINTER(C.c_int), _dp, _dp]),
+    "asora_evolve_begin": (C.c_int, [C.c_double] * 11 + [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]),
+    "asora_evolve_enqueue": (C.c_int, [C.c_int]),
+    "asora_evolve_poll": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_int, C.POINTER(C.c_int)]),
+    "asora_planes_to_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp]),
+    "asora_planes_to_device": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp]),
     "asora_set_option": (C.c_int, [C.c_int, C.c_int]),
     "asora_get_option": (C.c_int, [C.c_int]),
     "asora_kernel_time_ms": (C.c_int, [C.c_int, _dp, C.POINTER(C.c_long)]),

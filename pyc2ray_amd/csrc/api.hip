@@ -81,11 +81,24 @@ static int ensure_runtime()
     }
     ASORA_HIP_TRY(hipEventCreateWithFlags(&st.main_ready, hipEventDisableTiming));
     st.red_blocks = chemistry_reduction_blocks(st);
-    ASORA_HIP_TRY(hipMalloc(&st.red_partial, sizeof(double) * 3 * st.red_blocks));
+    st.red_cap = 3 * (size_t)st.red_blocks;
+    ASORA_HIP_TRY(hipMalloc(&st.red_partial, sizeof(double) * st.red_cap));
     ASORA_HIP_TRY(hipMalloc(&st.red_final, sizeof(double) * 3));
     ASORA_HIP_TRY(hipHostMalloc(&st.red_host, sizeof(double) * 3, hipHostMallocDefault));
     ASORA_HIP_TRY(hipMalloc(&st.counters, sizeof(unsigned long long) * 2));
     ASORA_HIP_TRY(hipMemset(st.counters, 0, sizeof(unsigned long long) * 2));
+    return 0;
+}
+
+// per-workgroup partial sums of the chemistry passes: room for `entries` doubles
+static int ensure_red_capacity(size_t entries)
+{
+    State &st = g_state;
+    if (entries <= st.red_cap) return 0;
+    if (st.stream) ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    if (st.red_partial) { (void)hipFree(st.red_partial); st.red_partial = nullptr; st.red_cap = 0; }
+    ASORA_HIP_TRY(hipMalloc(&st.red_partial, sizeof(double) * entries));
+    st.red_cap = entries;
     return 0;
 }
 
@@ -94,7 +107,8 @@ static int release_all()
     State &st = g_state;
     auto drop = [](auto *&ptr) { if (ptr) { (void)hipFree(ptr); ptr = nullptr; } };
     for (int g = 0; g < ASORA_GRID_COUNT; ++g) { drop(st.grid[g]); st.grid_valid[g] = false; }
-    drop(st.nhi); drop(st.staging);
+    drop(st.nhi); drop(st.staging); drop(st.acc);
+    st.ev_open = false;
     st.nhi_t = st.phi_t = st.heat_t = nullptr;    // second halves of nhi / phi_ion / phi_heat
     st.have_heat_tables = false;
     drop(st.tables); st.table_len = 0;
@@ -119,6 +133,31 @@ static int check_N(const char *who, int N)
         return fail(3, std::string(who) + ": mesh size " + std::to_string(N) + " does not match device_init(" +
                            std::to_string(g_state.N) + ")");
     return 0;
+}
+
+// The parameter block of a raytrace of the uploaded sources into PHI_ION (+ its [k][j][i] twin)
+static void fill_rt_params(RtParams &p, double R, double sig, double dr, double minlogtau, double dlogtau, int NumTau)
+{
+    State &st = g_state;
+    std::memset(&p, 0, sizeof p);
+    p.N = st.N;
+    p.R = R; p.sig = sig; p.dr = dr;
+    p.minlogtau = minlogtau; p.dlogtau = dlogtau;
+    p.NumTau = NumTau; p.numtau_f = (double)(float)NumTau;     // min(float(NumTau), ...) rates.cu:79
+    p.table_len = st.table_len > 0 ? st.table_len : 1;
+    p.fortran_consts = st.opt[ASORA_OPT_FORTRAN_CONSTANTS];
+    p.grey = st.opt[ASORA_OPT_GREY_NOTABLES];
+    p.z_transposed = st.opt[ASORA_OPT_Z_TRANSPOSED] != 0 ? 1 : 0;
+    p.ncell = (unsigned)st.ncell;
+    p.nhi = st.nhi;
+    p.phi = st.grid[ASORA_GRID_PHI_ION];
+    p.tables = st.tables;
+    p.heat = st.grid[ASORA_GRID_PHI_HEAT];
+    p.src_pos = st.src_pos; p.src_flux = st.src_flux;
+    p.counters = st.counters;
+#ifdef ASORA_ENABLE_ABLATION
+    { const char *ab = getenv("ASORA_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
+#endif
 }
 
 // A raytrace call in three parts, so that a caller can overlap the multi-GPU sum of finished slabs of the
@@ -153,26 +192,8 @@ static int rt_begin(double R, double sig, double dr, double minlogtau, double dl
     if (int rc = launch_prepare_nhi(st, zt)) return rc;
 
     RtParams &p = st.rt_params;
-    std::memset(&p, 0, sizeof p);
-    p.N = st.N;
-    p.R = R; p.sig = sig; p.dr = dr;
-    p.minlogtau = minlogtau; p.dlogtau = dlogtau;
-    p.NumTau = NumTau; p.numtau_f = (double)(float)NumTau;     // min(float(NumTau), ...) rates.cu:79
-    p.table_len = st.table_len > 0 ? st.table_len : 1;
-    p.fortran_consts = st.opt[ASORA_OPT_FORTRAN_CONSTANTS];
-    p.grey = st.opt[ASORA_OPT_GREY_NOTABLES];
-    p.z_transposed = zt ? 1 : 0;
-    p.ncell = (unsigned)st.ncell;
-    p.nhi = st.nhi;
-    p.phi = st.grid[ASORA_GRID_PHI_ION];
-    p.tables = st.tables;
-    p.heat = st.grid[ASORA_GRID_PHI_HEAT];
-    p.src_pos = st.src_pos; p.src_flux = st.src_flux;
+    fill_rt_params(p, R, sig, dr, minlogtau, dlogtau, NumTau);
     p.dump = dump;
-    p.counters = st.counters;
-#ifdef ASORA_ENABLE_ABLATION
-    { const char *ab = getenv("ASORA_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
-#endif
     st.rt_heat = heat;
     st.rt_pipelined = pipelined;
     if (pipelined) {       // the side streams start behind the zeroed accumulators and nHI
@@ -400,9 +421,10 @@ int asora_device_init_ex(int N, int num_src_par, int device_id)
 {
     clear_error();
     State &st = g_state;
+    // validate everything first: a refused re-initialisation leaves the working state as it was
     if (N < 2 || N > 1280) return fail(1, "device_init: N must be in [2, 1280] (32-bit cell indices over 2 N^3)");
-    if (st.init) release_all();
     if (st.stream && device_id != st.device) return fail(1, "device_init: the device cannot change within a process");
+    if (st.init) release_all();
     st.device = device_id;
     if (int rc = ensure_runtime()) return rc;
     st.N = N;
@@ -420,6 +442,7 @@ int asora_device_init_ex(int N, int num_src_par, int device_id)
     st.phi_t = st.grid[ASORA_GRID_PHI_ION] + st.ncell;
     st.heat_t = st.grid[ASORA_GRID_PHI_HEAT] + st.ncell;
     ASORA_HIP_TRY(hipMalloc(&st.staging, bytes));
+    if (int rc = ensure_red_capacity(3 * chemistry_tile_blocks(st, N, N))) return rc;
     st.init = true;
     return 0;
 }
@@ -671,16 +694,20 @@ int asora_chemistry_range(double dt, double bh00, double albpow, double colh0, d
         if (!st.grid_valid[g]) return fail(4, "chemistry_range: grid " + std::to_string(g) + " holds no data");
     if (i_begin < 0 || i_count < 0 || i_begin + i_count > st.N) return fail(4, "chemistry_range: bad plane range");
     if (i_count == 0 && !first) return 0;
-    const size_t off = (size_t)i_begin * st.N * st.N;
-    ChemParams p;
-    p.ncell = (size_t)i_count * st.N * st.N;
+    if (i_count == 0) {       // an empty first slab still resets the reductions
+        ASORA_HIP_TRY(hipMemsetAsync(st.red_final, 0, sizeof(double) * 3, st.stream));
+        return 0;
+    }
+    ChemTileParams p;
+    p.N = st.N; p.i_begin = i_begin; p.i_end = i_begin + i_count;
     p.dt = dt; p.bh00 = bh00; p.albpow = albpow; p.colh0 = colh0; p.temph0 = temph0; p.abu_c = abu_c;
-    p.ndens = st.grid[ASORA_GRID_NDENS] + off; p.temp = st.grid[ASORA_GRID_TEMP] + off; p.xh = st.grid[ASORA_GRID_XH] + off;
-    p.phi = st.grid[ASORA_GRID_PHI_ION] + off;
-    p.xh_av = st.grid[ASORA_GRID_XH_AV] + off; p.xh_intermed = st.grid[ASORA_GRID_XH_INTERMED] + off;
-    p.red_partial = st.red_partial; p.red_final = st.red_final; p.red_blocks = st.red_blocks;
+    p.ndens = st.grid[ASORA_GRID_NDENS]; p.temp = st.grid[ASORA_GRID_TEMP]; p.xh = st.grid[ASORA_GRID_XH];
+    p.xh_av_in = st.grid[ASORA_GRID_XH_AV];
+    p.gamma = st.grid[ASORA_GRID_PHI_ION];
+    p.xh_av = st.grid[ASORA_GRID_XH_AV]; p.xh_intermed = st.grid[ASORA_GRID_XH_INTERMED];
+    p.red_partial = st.red_partial; p.red_final = st.red_final;
     p.accumulate = first ? 0 : 1;
-    return launch_chemistry(st, p, st.stream);
+    return launch_chemistry_tiles(st, p, st.stream);
 }
 
 int asora_chemistry_finish(int *conv_flag, double *sum_xh1, double *sum_xh0)
@@ -862,6 +889,145 @@ int asora_subbox_raytrace_device(int max_subbox, int subboxsize, float loss_frac
     if (int rc = subbox_core(c, total_nbox, total_loss)) return rc;
     if (sum_nbox) *sum_nbox = (int)total_nbox;
     if (photon_loss) *photon_loss = total_loss;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The evolve loop on the device (pyc2ray/evolve.py:168-240): raytrace -> fused chemistry -> convergence test,
+// nothing in between and nothing on the host
+// ---------------------------------------------------------------------------------------------
+int asora_evolve_begin(double dt, double bh00, double albpow, double colh0, double temph0, double abu_c,
+                       double R, double sig, double dr, double minlogtau, double dlogtau, int NumTau,
+                       int src_begin, int src_count, double conv_criterion, double convergence_fraction)
+{
+    clear_error();
+    if (int rc = require_init("evolve_begin")) return rc;
+    State &st = g_state;
+    st.ev_open = false;
+    static const int need[] = {ASORA_GRID_NDENS, ASORA_GRID_TEMP, ASORA_GRID_XH};
+    for (int g : need)
+        if (!st.grid_valid[g]) return fail(4, "evolve_begin: grid " + std::to_string(g) + " holds no data");
+    if (!st.opt[ASORA_OPT_GREY_NOTABLES] && !st.tables)
+        return fail(4, "evolve_begin: radiation tables not on device (photo_table_to_device)");
+    if (!(R >= 0.0)) return fail(4, "evolve_begin: R must be >= 0");
+    if (NumTau < 1 && !st.opt[ASORA_OPT_GREY_NOTABLES]) return fail(4, "evolve_begin: NumTau must be >= 1");
+    if (src_begin < 0 || src_count < 0 || src_begin + src_count > st.num_src)
+        return fail(4, "evolve_begin: source range outside the " + std::to_string(st.num_src) + " uploaded sources");
+    if (st.opt[ASORA_OPT_HEATING]) return fail(4, "evolve_begin: the fused loop carries no heating rates (use raytrace_device)");
+
+    const size_t bytes = st.ncell * sizeof(double);
+    if (!st.acc) ASORA_HIP_TRY(hipMalloc(&st.acc, 2 * bytes));
+    if (!st.ev_status) {
+        ASORA_HIP_TRY(hipMalloc(&st.ev_status, sizeof(EvolveStatus)));
+        ASORA_HIP_TRY(hipHostMalloc(&st.ev_host, sizeof(EvolveStatus), hipHostMallocDefault));
+    }
+    ASORA_HIP_TRY(hipStreamSynchronize(st.stream));            // ev_host may still be the target of an earlier poll
+    std::memset(st.ev_host, 0, sizeof(EvolveStatus));
+    st.ev_host->prev1 = 2.0 * (double)st.ncell;                // evolve.py:130-131
+    st.ev_host->prev0 = 2.0 * (double)st.ncell;
+    st.ev_host->conv_criterion = conv_criterion;
+    st.ev_host->conv_fraction = convergence_fraction;
+    ASORA_HIP_TRY(hipMemcpyAsync(st.ev_status, st.ev_host, sizeof(EvolveStatus), hipMemcpyHostToDevice, st.stream));
+    ASORA_HIP_TRY(hipMemsetAsync(st.acc, 0, 2 * bytes, st.stream));                       // raytracing.cu:113
+    ASORA_HIP_TRY(hipMemsetAsync(st.counters, 0, sizeof(unsigned long long) * 2, st.stream));
+    // xh_av = copy(xh) (evolve.py:136) is not materialised: nHI of the first trace is formed from xh and the first
+    // chemistry pass takes xh as its starting xh_av; xh_intermed (evolve.py:137) is only ever written
+    if (int rc = launch_prepare_nhi_from(st, st.grid[ASORA_GRID_XH], st.opt[ASORA_OPT_Z_TRANSPOSED] != 0)) return rc;
+
+    fill_rt_params(st.ev_rt, R, sig, dr, minlogtau, dlogtau, NumTau);
+    st.ev_rt.phi = st.acc;
+    st.ev_rt.done_flag = &st.ev_status->done;
+    st.ev_rt.src_begin = src_begin; st.ev_rt.src_count = src_count; st.ev_rt.shape_src_count = src_count;
+    st.ev_src_begin = src_begin; st.ev_src_count = src_count;
+    st.ev_chem[0] = dt; st.ev_chem[1] = bh00; st.ev_chem[2] = albpow; st.ev_chem[3] = colh0; st.ev_chem[4] = temph0;
+    st.ev_chem[5] = abu_c;
+    st.ev_first = true;
+    st.ev_reported = 0;
+    st.ev_open = true;
+    return 0;
+}
+
+int asora_evolve_enqueue(int iterations)
+{
+    clear_error();
+    if (int rc = require_init("evolve_enqueue")) return rc;
+    State &st = g_state;
+    if (!st.ev_open) return fail(4, "evolve_enqueue: no evolve step in progress (call asora_evolve_begin)");
+    if (iterations < 1 || iterations > EVOLVE_HIST / 2) return fail(3, "evolve_enqueue: between 1 and 32 iterations per call");
+    for (int it = 0; it < iterations; ++it) {
+        if (st.ev_src_count > 0) {
+            RtParams p = st.ev_rt;
+            if (int rc = launch_raytrace(st, p, false, false)) return rc;
+        }
+        ChemTileParams c;
+        c.N = st.N; c.i_begin = 0; c.i_end = st.N;
+        c.dt = st.ev_chem[0]; c.bh00 = st.ev_chem[1]; c.albpow = st.ev_chem[2]; c.colh0 = st.ev_chem[3];
+        c.temph0 = st.ev_chem[4]; c.abu_c = st.ev_chem[5];
+        c.ndens = st.grid[ASORA_GRID_NDENS]; c.temp = st.grid[ASORA_GRID_TEMP]; c.xh = st.grid[ASORA_GRID_XH];
+        c.xh_av_in = st.ev_first ? st.grid[ASORA_GRID_XH] : st.grid[ASORA_GRID_XH_AV];
+        c.gamma = st.acc; c.gamma_t = st.acc + st.ncell; c.phi_out = st.grid[ASORA_GRID_PHI_ION];
+        c.xh_av = st.grid[ASORA_GRID_XH_AV]; c.xh_intermed = st.grid[ASORA_GRID_XH_INTERMED];
+        c.nhi = st.nhi; c.nhi_t = st.nhi_t;
+        c.red_partial = st.red_partial; c.red_final = st.red_final;
+        c.status = st.ev_status;
+        c.fold = true; c.emit = true;
+        if (int rc = launch_chemistry_tiles(st, c, st.stream)) return rc;
+        st.ev_first = false;
+    }
+    st.grid_valid[ASORA_GRID_XH_AV] = st.grid_valid[ASORA_GRID_XH_INTERMED] = st.grid_valid[ASORA_GRID_PHI_ION] = true;
+    return 0;
+}
+
+int asora_evolve_poll(int *niter, int *converged, double *history, int history_rows, int *rows_written)
+{
+    clear_error();
+    if (int rc = require_init("evolve_poll")) return rc;
+    State &st = g_state;
+    if (!st.ev_open) return fail(4, "evolve_poll: no evolve step in progress (call asora_evolve_begin)");
+    ASORA_HIP_TRY(hipMemcpyAsync(st.ev_host, st.ev_status, sizeof(EvolveStatus), hipMemcpyDeviceToHost, st.stream));
+    ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    const EvolveStatus &h = *st.ev_host;
+    int rows = 0;
+    for (int it = st.ev_reported; it < h.niter && history && rows < history_rows; ++it, ++rows)
+        for (int q = 0; q < 5; ++q) history[5 * rows + q] = h.hist[it % EVOLVE_HIST][q];
+    if (history) st.ev_reported += rows;
+    if (rows_written) *rows_written = rows;
+    if (niter) *niter = h.niter;
+    if (converged) *converged = h.done;
+    return 0;
+}
+
+// Contiguous runs of i-planes of a grid to / from the host (C order: plane i is N*N consecutive doubles).  What a
+// multi-GPU rank exchanges are such runs (the planes its sources reach, the planes whose chemistry it owns).
+int asora_planes_to_host(int which, int i_begin, int i_count, double *host)
+{
+    clear_error();
+    if (int rc = require_init("planes_to_host")) return rc;
+    State &st = g_state;
+    if (which < 0 || which >= ASORA_GRID_COUNT) return fail(3, "planes_to_host: bad grid selector");
+    if (i_begin < 0 || i_count < 0 || i_begin + i_count > st.N) return fail(3, "planes_to_host: bad plane range");
+    if (i_count == 0) return 0;
+    if (!host) return fail(3, "planes_to_host: null host pointer");
+    const size_t plane = (size_t)st.N * st.N;
+    ASORA_HIP_TRY(hipMemcpyAsync(host, st.grid[which] + (size_t)i_begin * plane, (size_t)i_count * plane * sizeof(double),
+                                 hipMemcpyDeviceToHost, st.stream));
+    ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    return 0;
+}
+
+int asora_planes_to_device(int which, int i_begin, int i_count, const double *host)
+{
+    clear_error();
+    if (int rc = require_init("planes_to_device")) return rc;
+    State &st = g_state;
+    if (which < 0 || which >= ASORA_GRID_COUNT) return fail(3, "planes_to_device: bad grid selector");
+    if (i_begin < 0 || i_count < 0 || i_begin + i_count > st.N) return fail(3, "planes_to_device: bad plane range");
+    if (i_count == 0) return 0;
+    if (!host) return fail(3, "planes_to_device: null host pointer");
+    const size_t plane = (size_t)st.N * st.N;
+    ASORA_HIP_TRY(hipMemcpyAsync(st.grid[which] + (size_t)i_begin * plane, host, (size_t)i_count * plane * sizeof(double),
+                                 hipMemcpyHostToDevice, st.stream));
+    ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
     return 0;
 }
 

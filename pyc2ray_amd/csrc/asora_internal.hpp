@@ -46,6 +46,19 @@ struct RtParams {
     double *dump;               // debug: outgoing column density (N^3) or nullptr
     double *shell_scratch;      // global shell buffers when they do not fit LDS, else nullptr
     unsigned long long *counters;
+    const int *done_flag;       // evolve loop: device flag "the step has converged" -> the launch does nothing; or nullptr
+};
+
+// Device-side bookkeeping of the evolve loop (asora_evolve_begin / _enqueue / _poll): the convergence test of
+// pyc2ray/evolve.py:216-236 is evaluated on the device right behind the chemistry reductions, so that several outer
+// iterations can be enqueued at once; launches that come after convergence see `done` and do nothing.
+constexpr int EVOLVE_HIST = 64;
+struct EvolveStatus {
+    int niter;                         // outer iterations carried out
+    int done;                          // 1 once the test of evolve.py:231-232 has passed
+    double prev1, prev0;               // sum(xh_intermed), sum(1 - xh_intermed) of the previous iteration (evolve.py:130-131,234-235)
+    double conv_criterion, conv_fraction;
+    double hist[EVOLVE_HIST][5];       // ring by iteration: conv_flag, sum1, sum0, rel_change_xh1, rel_change_xh0
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -110,13 +123,25 @@ struct State {
     size_t shell_scratch_bytes = 0;
 
     // chemistry reductions
-    double *red_partial = nullptr; // [3][red_blocks]
+    double *red_partial = nullptr; // [3][red_cap]: per-workgroup partial sums (red_cap >= red_blocks)
+    size_t red_cap = 0;
     double *red_final = nullptr;   // [3]
     double *red_host = nullptr;    // pinned [3]
     int red_blocks = 0;
 
     unsigned long long *counters = nullptr; // [2] device: gamma cells, evaluated cells
     long long last_gamma_cells = 0, last_eval_cells = 0;
+
+    // fused evolve loop (asora_evolve_*): raytrace accumulators of their own ([i][j][k] then [k][j][i]; the chemistry
+    // kernel folds them into PHI_ION and zeroes them), device-side convergence bookkeeping
+    double *acc = nullptr;                  // 2 N^3, allocated on first use
+    EvolveStatus *ev_status = nullptr;      // device
+    EvolveStatus *ev_host = nullptr;        // pinned
+    bool ev_open = false, ev_first = true;
+    int ev_reported = 0;                    // iterations already handed to the caller by asora_evolve_poll
+    double ev_chem[6] = {0, 0, 0, 0, 0, 0}; // dt, bh00, albpow, colh0, temph0, abu_c
+    int ev_src_begin = 0, ev_src_count = 0;
+    RtParams ev_rt;
 
     hipStream_t stream = nullptr;
     struct PendingTimer { int which; hipEvent_t e0, e1; };
@@ -207,5 +232,30 @@ struct ChemParams {
 };
 int launch_chemistry(State &st, ChemParams &p, hipStream_t stream);
 int chemistry_reduction_blocks(const State &st);
+
+// The same pass over the planes [i_begin, i_end) of the N^3 grids, tiled so that the [k][j][i] twins can be read and
+// written with contiguous rows as well (chemistry.hip: chemistry_tile_kernel).
+//   fold   : the rate of a cell is gamma[i][j][k] + gamma_t[k][j][i] (the raytrace's two accumulators), written to phi_out
+//   emit   : additionally form nHI = ndens (1 - xh_av) of the NEW xh_av in both layouts for the next raytrace and
+//            zero both accumulators -- everything the host did between two iterations (pyc2ray/evolve.py:200-240)
+//   status : evaluate the convergence test on the device behind the reductions; launches do nothing once it has passed
+struct ChemTileParams {
+    int N = 0, i_begin = 0, i_end = 0;
+    double dt = 0, bh00 = 0, albpow = 0, colh0 = 0, temph0 = 0, abu_c = 0;
+    const double *ndens = nullptr, *temp = nullptr, *xh = nullptr, *xh_av_in = nullptr;
+    double *gamma = nullptr, *gamma_t = nullptr;     // rates [i][j][k] (+ [k][j][i] accumulator when fold)
+    double *phi_out = nullptr;                       // fold: folded rates
+    double *xh_av = nullptr, *xh_intermed = nullptr;
+    double *nhi = nullptr, *nhi_t = nullptr;         // emit
+    double *red_partial = nullptr, *red_final = nullptr;
+    int red_stride = 0;                              // number of workgroups of the launch (set by the launcher)
+    int accumulate = 0;
+    EvolveStatus *status = nullptr;
+    bool fold = false, emit = false;
+};
+int launch_chemistry_tiles(State &st, ChemTileParams &p, hipStream_t stream);
+size_t chemistry_tile_blocks(const State &st, int N, int planes);
+int launch_prepare_nhi_from(State &st, const double *xh_av, bool need_transposed);
+int launch_prepare_range(State &st, int i_begin, int i_count, bool zero_acc, double *acc);
 
 } // namespace asora

@@ -12,6 +12,8 @@
 // rank of a multi-GPU run derives bit-identical convergence scalars from the same grids.
 #include "asora_internal.hpp"
 
+#include <algorithm>
+
 namespace asora {
 
 constexpr int CH_THREADS = 256;
@@ -112,14 +114,18 @@ __global__ void __launch_bounds__(CH_THREADS) chemistry_kernel(const ChemParams 
     }
 }
 
-// out[q] = (accumulate ? out[q] : 0) + sum of the per-block partials, one block, fixed order
+// out[q] = (accumulate ? out[q] : 0) + sum of the per-block partials, one block, fixed order.
+// With `status` the convergence test of the evolve loop follows at once (pyc2ray/evolve.py:216-236):
+// relative change of the two sums against the previous iteration, `conv_flag < conv_criterion or both changes
+// below convergence_fraction`; the iteration is booked in the status block's history ring.
 __global__ void __launch_bounds__(CH_THREADS) chemistry_reduce_kernel(const double *partial, int nblocks, double *out,
-                                                                      int accumulate)
+                                                                      int accumulate, EvolveStatus *status)
 {
+    if (status && status->done) return;
     __shared__ double r[3][CH_THREADS];
     for (int q = 0; q < 3; ++q) {
         double s = 0.0;
-        for (int b = threadIdx.x; b < nblocks; b += CH_THREADS) s += partial[q * nblocks + b];
+        for (int b = threadIdx.x; b < nblocks; b += CH_THREADS) s += partial[(size_t)q * nblocks + b];
         r[q][threadIdx.x] = s;
     }
     __syncthreads();
@@ -129,6 +135,103 @@ __global__ void __launch_bounds__(CH_THREADS) chemistry_reduce_kernel(const doub
         __syncthreads();
     }
     if (threadIdx.x < 3) out[threadIdx.x] = (accumulate ? out[threadIdx.x] : 0.0) + r[threadIdx.x][0];
+    if (status && threadIdx.x == 0) {
+        const double sum1 = r[0][0], sum0 = r[1][0], nconv = r[2][0];
+        const double rel1 = sum1 > 0.0 ? fabs((sum1 - status->prev1) / sum1) : 1.0;      // evolve.py:219-227
+        const double rel0 = sum0 > 0.0 ? fabs((sum0 - status->prev0) / sum0) : 1.0;
+        const bool converged = (nconv < status->conv_criterion) ||
+                               (rel1 < status->conv_fraction && rel0 < status->conv_fraction);   // evolve.py:232
+        double *h = status->hist[status->niter % EVOLVE_HIST];
+        h[0] = nconv; h[1] = sum1; h[2] = sum0; h[3] = rel1; h[4] = rel0;
+        status->prev1 = sum1; status->prev0 = sum0;                                       // evolve.py:234-235
+        status->niter += 1;
+        if (converged) status->done = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The tiled pass: planes [i_begin, i_end), one 32(i) x 32(k) tile of one j per workgroup iteration
+// ---------------------------------------------------------------------------------------------
+// What the host of the reference does between the raytrace and the next raytrace (pyc2ray/evolve.py:200-240:
+// reshape phi_ion, global_pass, the two sums, ravel xh_av for the next upload) plus this build's own helper
+// passes (fold of the z-face accumulator, nHI in both layouts, zeroing of the accumulators) in ONE sweep over
+// the grids: per cell 6 loads (ndens, temp, xh, xh_av, two accumulators) and 7 stores (xh_av, xh_intermed,
+// phi_ion, nHI twice, two zeros) = 104 B, against 56 + 32 + 24 + 16 B of the four separate passes.
+// The [k][j][i] twins are read and written through LDS tiles so that their rows are contiguous as well.
+template <bool FOLD, bool EMIT>
+__global__ void __launch_bounds__(CH_THREADS) chemistry_tile_kernel(const ChemTileParams p)
+{
+    if (p.status && p.status->done) return;
+    __shared__ double tile_g[32][33], tile_n[32][33];
+    __shared__ double r1[CH_THREADS], r0[CH_THREADS];
+    __shared__ unsigned int rc[CH_THREADS];
+
+    const int N = p.N;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
+    const int kb = blockIdx.x * 32, ib = p.i_begin + blockIdx.z * 32;
+    ChemParams cp;
+    cp.dt = p.dt; cp.bh00 = p.bh00; cp.albpow = p.albpow; cp.colh0 = p.colh0; cp.temph0 = p.temph0; cp.abu_c = p.abu_c;
+
+    double sum1 = 0.0, sum0 = 0.0;
+    unsigned int nconv = 0;
+    for (int j = blockIdx.y; j < N; j += gridDim.y) {
+        if (FOLD) {
+            if (j != (int)blockIdx.y) __syncthreads();             // the tiles of the previous j have been consumed
+            for (int r = ty; r < 32; r += 8) {
+                const int k = kb + r, i = ib + tx;
+                if (k < N && i < p.i_end) {
+                    const size_t o = ((size_t)k * N + j) * N + i;
+                    tile_g[r][tx] = p.gamma_t[o];
+                    if (EMIT) p.gamma_t[o] = 0.0;
+                }
+            }
+            __syncthreads();
+        }
+        for (int r = ty; r < 32; r += 8) {
+            const int i = ib + r, k = kb + tx;
+            if (i < p.i_end && k < N) {
+                const size_t idx = ((size_t)i * N + j) * N + k;
+                double g = p.gamma[idx];
+                if (FOLD) { g += tile_g[tx][r]; p.phi_out[idx] = g; }
+                if (EMIT) p.gamma[idx] = 0.0;
+                const double n = p.ndens[idx];
+                double xav = p.xh_av_in[idx], xint;
+                chemistry_cell(cp, n, p.temp[idx], p.xh[idx], g, xav, xint, nconv);
+                p.xh_intermed[idx] = xint;                           // chemistry.f90:107-108
+                p.xh_av[idx] = xav;
+                sum1 += xint; sum0 += 1.0 - xint;                    // evolve.py:216-217
+                if (EMIT) {
+                    const double v = n * (1.0 - xav);                // raytracing.cu:276, for the next raytrace
+                    p.nhi[idx] = v;
+                    tile_n[r][tx] = v;
+                }
+            }
+        }
+        if (EMIT) {
+            __syncthreads();
+            for (int r = ty; r < 32; r += 8) {
+                const int k = kb + r, i = ib + tx;
+                if (k < N && i < p.i_end) p.nhi_t[((size_t)k * N + j) * N + i] = tile_n[tx][r];
+            }
+        }
+    }
+
+    r1[threadIdx.x] = sum1; r0[threadIdx.x] = sum0; rc[threadIdx.x] = nconv;
+    __syncthreads();
+    for (int off = CH_THREADS / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            r1[threadIdx.x] += r1[threadIdx.x + off];
+            r0[threadIdx.x] += r0[threadIdx.x + off];
+            rc[threadIdx.x] += rc[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        p.red_partial[b] = r1[0];
+        p.red_partial[(size_t)p.red_stride + b] = r0[0];
+        p.red_partial[2 * (size_t)p.red_stride + b] = (double)rc[0];
+    }
 }
 
 int chemistry_reduction_blocks(const State &st) { return st.cu_count * 8; }
@@ -145,7 +248,45 @@ int launch_chemistry(State &st, ChemParams &p, hipStream_t stream)
         ASORA_HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(chemistry_reduce_kernel, dim3(1), dim3(CH_THREADS), 0, stream,
-                       (const double *)p.red_partial, blocks, p.red_final, p.accumulate);
+                       (const double *)p.red_partial, blocks, p.red_final, p.accumulate, (EvolveStatus *)nullptr);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Workgroups of a tiled pass over `planes` i-planes: (k tiles, j chunks, i tiles).  Every workgroup walks its
+// (i,k) tile through N / (j chunks) values of j; the chunk count keeps ~16 workgroups per CU in flight.
+static dim3 tile_pass_grid(const State &st, int N, int planes)
+{
+    const unsigned kt = (N + 31) / 32, it = (planes + 31) / 32;
+    const unsigned want = (unsigned)st.cu_count * 16u;
+    unsigned jc = std::max(1u, std::min((unsigned)N, (want + kt * it - 1) / (kt * it)));
+    return dim3(kt, jc, it);
+}
+
+size_t chemistry_tile_blocks(const State &st, int N, int planes)
+{
+    const dim3 g = tile_pass_grid(st, N, planes);
+    return (size_t)g.x * g.y * g.z;
+}
+
+int launch_chemistry_tiles(State &st, ChemTileParams &p, hipStream_t stream)
+{
+    const int planes = p.i_end - p.i_begin;
+    if (planes <= 0) return 0;
+    const dim3 grid = tile_pass_grid(st, p.N, planes);
+    const size_t blocks = (size_t)grid.x * grid.y * grid.z;
+    if (3 * blocks > st.red_cap) return fail(11, "chemistry: reduction buffer too small (internal error)");
+    ChemTileParams q = p;
+    q.red_stride = (int)blocks;
+    {
+        KernelTimer kt(ASORA_KERNEL_CHEMISTRY, stream);
+        if (p.fold && p.emit)        hipLaunchKernelGGL((chemistry_tile_kernel<true, true>), grid, dim3(CH_THREADS), 0, stream, q);
+        else if (!p.fold && !p.emit) hipLaunchKernelGGL((chemistry_tile_kernel<false, false>), grid, dim3(CH_THREADS), 0, stream, q);
+        else return fail(11, "chemistry: unsupported fold/emit combination (internal error)");
+        ASORA_HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(chemistry_reduce_kernel, dim3(1), dim3(CH_THREADS), 0, stream,
+                       (const double *)p.red_partial, (int)blocks, p.red_final, p.accumulate, p.status);
     ASORA_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -163,6 +163,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
 {
     extern __shared__ double lds_raw[];
 
+    if (p.done_flag && *p.done_flag) return;   // evolve loop: an iteration enqueued beyond convergence does nothing
     const int blk = blockIdx.x;
     // blocks b and b+8 share an XCD (round-robin dispatch): keep the 8 octants of one source
     // on one XCD so that they share its L2 lines of nHI.  Speed only, never correctness.
@@ -745,21 +746,24 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
 // N^3 helper kernels
 // ---------------------------------------------------------------------------------------------
 
-// nhi[i][j][k] = ndens*(1-xh_av);  nhi_t[k][j][i] = same (tiled transpose of the (i,k) planes).
-// block (32,8): tile 32(i) x 32(k) of one j.
-template <bool WITH_T>
+// nhi[i][j][k] = ndens*(1-xh_av);  nhi_t[k][j][i] = same (tiled transpose of the (i,k) planes), for the planes
+// [i_begin, i_end).  block (32,8): tile 32(i) x 32(k) of one j.  ZERO: also zero both layouts of an accumulator
+// on those planes (a multi-GPU rank only touches the planes its sources reach).
+template <bool WITH_T, bool ZERO>
 __global__ void __launch_bounds__(256) prepare_nhi_kernel(const double *__restrict__ nd, const double *__restrict__ xh,
-                                                          double *__restrict__ nhi, double *__restrict__ nhi_t, int N)
+                                                          double *__restrict__ nhi, double *__restrict__ nhi_t, int N,
+                                                          int i_begin, int i_end, double *__restrict__ acc, size_t ncell)
 {
     __shared__ double tile[32][33];
     const int j = blockIdx.y;
-    const int ib = blockIdx.z * 32, kb = blockIdx.x * 32;
+    const int ib = i_begin + blockIdx.z * 32, kb = blockIdx.x * 32;
     for (int r = threadIdx.y; r < 32; r += 8) {
         const int i = ib + r, k = kb + threadIdx.x;
-        if (i < N && k < N) {
+        if (i < i_end && k < N) {
             const size_t idx = ((size_t)i * N + j) * N + k;
             const double v = nd[idx] * (1.0 - xh[idx]);       // raytracing.cu:276
             nhi[idx] = v;
+            if (ZERO) acc[idx] = 0.0;
             if (WITH_T) tile[r][threadIdx.x] = v;
         }
     }
@@ -767,7 +771,11 @@ __global__ void __launch_bounds__(256) prepare_nhi_kernel(const double *__restri
     __syncthreads();
     for (int r = threadIdx.y; r < 32; r += 8) {
         const int k = kb + r, i = ib + threadIdx.x;
-        if (i < N && k < N) nhi_t[((size_t)k * N + j) * N + i] = tile[threadIdx.x][r];
+        if (i < i_end && k < N) {
+            const size_t o = ((size_t)k * N + j) * N + i;
+            nhi_t[o] = tile[threadIdx.x][r];
+            if (ZERO) acc[ncell + o] = 0.0;
+        }
     }
 }
 
@@ -795,16 +803,39 @@ __global__ void __launch_bounds__(256) transpose_ik_kernel(const double *__restr
 
 static dim3 tile_grid(int N) { const unsigned t = (N + 31) / 32; return dim3(t, N, t); }
 
-int launch_prepare_nhi(State &st, bool need_transposed)
+int launch_prepare_nhi_from(State &st, const double *xh_av, bool need_transposed)
 {
     KernelTimer kt(ASORA_KERNEL_PREP);
     const int N = st.N;
     if (need_transposed)
-        hipLaunchKernelGGL(prepare_nhi_kernel<true>, tile_grid(N), dim3(32, 8), 0, st.stream,
-                           st.grid[ASORA_GRID_NDENS], st.grid[ASORA_GRID_XH_AV], st.nhi, st.nhi_t, N);
+        hipLaunchKernelGGL((prepare_nhi_kernel<true, false>), tile_grid(N), dim3(32, 8), 0, st.stream,
+                           st.grid[ASORA_GRID_NDENS], xh_av, st.nhi, st.nhi_t, N, 0, N, (double *)nullptr, st.ncell);
     else
-        hipLaunchKernelGGL(prepare_nhi_kernel<false>, tile_grid(N), dim3(32, 8), 0, st.stream,
-                           st.grid[ASORA_GRID_NDENS], st.grid[ASORA_GRID_XH_AV], st.nhi, st.nhi_t, N);
+        hipLaunchKernelGGL((prepare_nhi_kernel<false, false>), tile_grid(N), dim3(32, 8), 0, st.stream,
+                           st.grid[ASORA_GRID_NDENS], xh_av, st.nhi, st.nhi_t, N, 0, N, (double *)nullptr, st.ncell);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_prepare_nhi(State &st, bool need_transposed)
+{
+    return launch_prepare_nhi_from(st, st.grid[ASORA_GRID_XH_AV], need_transposed);
+}
+
+// nHI in both layouts on the planes [i_begin, i_begin + i_count) only; zero_acc: also zero both layouts of `acc` there
+int launch_prepare_range(State &st, int i_begin, int i_count, bool zero_acc, double *acc)
+{
+    if (i_count <= 0) return 0;
+    KernelTimer kt(ASORA_KERNEL_PREP);
+    const int N = st.N;
+    const unsigned t = (N + 31) / 32;
+    const dim3 grid(t, N, (i_count + 31) / 32);
+    if (zero_acc)
+        hipLaunchKernelGGL((prepare_nhi_kernel<true, true>), grid, dim3(32, 8), 0, st.stream, st.grid[ASORA_GRID_NDENS],
+                           st.grid[ASORA_GRID_XH_AV], st.nhi, st.nhi_t, N, i_begin, i_begin + i_count, acc, st.ncell);
+    else
+        hipLaunchKernelGGL((prepare_nhi_kernel<true, false>), grid, dim3(32, 8), 0, st.stream, st.grid[ASORA_GRID_NDENS],
+                           st.grid[ASORA_GRID_XH_AV], st.nhi, st.nhi_t, N, i_begin, i_begin + i_count, acc, st.ncell);
     ASORA_HIP_TRY(hipGetLastError());
     return 0;
 }

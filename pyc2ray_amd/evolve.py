@@ -7,6 +7,8 @@ and transposes xh_av back on every iteration (evolve.py:187,200,210,240); here n
 xh_intermed and phi_ion stay on the MI355X for the whole step, the chemistry is a HIP kernel, and
 three scalars (conv_flag, sum x, sum 1-x) cross PCIe per iteration.
 """
+import array
+import os
 import time
 
 import numpy as np
@@ -18,6 +20,19 @@ from .utils import printlog
 from .utils.sourceutils import format_sources
 
 __all__ = ['evolve3D', 'evolve3D_MPI']
+
+#: outer iterations enqueued per host round trip of the single-GPU loop (the device evaluates the convergence test
+#: itself; launches enqueued beyond convergence do nothing)
+EVOLVE_BATCH = int(os.environ.get("PYC2RAY_AMD_EVOLVE_BATCH", "8"))
+
+
+def _agree_on_convergence(comm, converged):
+    """Rank 0 decides, everyone follows (pyc2ray/evolve.py:484-489).  Every rank derives `converged` from the same
+    summed rates, but a collective that sums in a rank-dependent order could leave them one ulp apart; a rank that
+    left the loop alone would hang the others in the next collective."""
+    flag = array.array('i', [int(bool(converged))])
+    comm.Bcast(flag, root=0)
+    return bool(flag[0])
 
 
 def _evolve_cpu_semantics(dt, dr, src_flux, src_pos, max_subbox, subboxsize, loss_fraction, temp, ndens, xh,
@@ -92,6 +107,8 @@ def _evolve_cpu_semantics(dt, dr, src_flux, src_pos, max_subbox, subboxsize, los
                      f"Relative change in ionfrac: {rel_change_xh1 : .2e}", logfile, quiet)
         converged = (conv_flag < conv_criterion) or ((rel_change_xh1 < convergence_fraction) and
                                                      (rel_change_xh0 < convergence_fraction))
+        if distributed:
+            converged = _agree_on_convergence(comm, converged)
         prev_sum_xh1_int = sum_xh1_int
         prev_sum_xh0_int = sum_xh0_int
     if rank == 0:
@@ -164,9 +181,10 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
     libasora.grid_to_device(_capi.GRID_NDENS, ndens)
     libasora.grid_to_device(_capi.GRID_TEMP, temp)
     libasora.grid_to_device(_capi.GRID_XH, xh)
-    libasora.grid_copy(_capi.GRID_XH_AV, _capi.GRID_XH)          # xh_av = copy(xh)        evolve.py:136
-    libasora.grid_copy(_capi.GRID_XH_INTERMED, _capi.GRID_XH)    # xh_intermed = copy(xh)  evolve.py:137
-    if not distributed:
+    if distributed:
+        libasora.grid_copy(_capi.GRID_XH_AV, _capi.GRID_XH)          # xh_av = copy(xh)        evolve.py:136
+        libasora.grid_copy(_capi.GRID_XH_INTERMED, _capi.GRID_XH)    # xh_intermed = copy(xh)  evolve.py:137
+    else:
         printlog("Copied source data to device.", logfile, quiet)
 
     if rank == 0:
@@ -180,12 +198,35 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
         printlog(f"Mean density (cgs): {ndens.mean():.3e}, Mean ionized fraction: {xh.mean():.3e}", logfile, quiet)
         printlog(f"Convergence Criterion (Number of points): {conv_criterion : n}", logfile, quiet, end='\n\n')
 
-    while not converged:
+    chem = (dt, bh00, albpow, colh0, temph0, abu_c)
+    if not distributed:
+        # One GPU: the whole loop lives on the device (include/asora_hip.h, asora_evolve_*).  An iteration is the
+        # raytrace plus ONE pass over the grids (rates folded, chemistry, nHI for the next trace, accumulators
+        # zeroed); the convergence test of evolve.py:216-236 is evaluated on the device, so EVOLVE_BATCH iterations
+        # are enqueued per host round trip and those beyond convergence do nothing.
+        libasora.evolve_begin(*chem, R_max_LLS, sig, dr, minlogtau, dlogtau, NumTau, 0, NumSrc_local,
+                              conv_criterion, convergence_fraction)
+        batch = max(1, min(EVOLVE_BATCH, 32))
+        while not converged:
+            t0 = time.time()
+            libasora.evolve_enqueue(batch)
+            _, converged, rows = libasora.evolve_poll(batch)
+            per_iteration = (time.time() - t0) / max(len(rows), 1)
+            for conv_flag, _s1, _s0, rel_change_xh1, _rel0 in rows:
+                niter += 1
+                conv_flag = int(conv_flag)
+                printlog("Doing Raytracing...", logfile, quiet, ' ')
+                printlog(f"took {per_iteration : .1f} s.", logfile, quiet)
+                printlog("Doing Chemistry...", logfile, quiet, ' ')
+                printlog("took  0.0 s. (fused with the raytrace on the device: the time above is for both)", logfile, quiet)
+                printlog(f"Number of non-converged points: {conv_flag} of {NumCells} ({conv_flag / NumCells * 100 : .3f} % ), "
+                         f"Relative change in ionfrac: {rel_change_xh1 : .2e}", logfile, quiet)
+
+    while distributed and not converged:
         niter += 1
 
         # (1) raytracing, evolve.py:174-196
         trt0 = time.time()
-        chem = (dt, bh00, albpow, colh0, temph0, abu_c)
         if pipelined:
             # raytrace, sum over ranks and chemistry slab by slab (pyc2ray_amd.dist): steps (1) and (2) in one
             printlog(f"Doing Raytracing and Chemistry, pipelined (rank={rank:n})...", logfile, quiet, ' ')
@@ -193,17 +234,11 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
                 libasora, N, R_max_LLS, sig, dr, NumSrc_local, minlogtau, dlogtau, NumTau, src_i0=src_i0, chemistry=chem)
             printlog(f"rank={rank:n} took {(time.time()-trt0) : .1e} s.", logfile, quiet)
         else:
-            if distributed:
-                printlog(f"Doing Raytracing (rank={rank:n})...", logfile, quiet, ' ')
-                libasora.raytrace_device(R_max_LLS, sig, dr, 0, NumSrc_local, minlogtau, dlogtau, NumTau)
-                libasora.synchronize()
-                printlog(f"rank={rank:n} took {(time.time()-trt0) : .1e} s.", logfile, quiet)
-                _allreduce_phi(libasora, N, use_mpi, comm, rank)
-            else:
-                printlog("Doing Raytracing...", logfile, quiet, ' ')
-                libasora.raytrace_device(R_max_LLS, sig, dr, 0, NumSrc_local, minlogtau, dlogtau, NumTau)
-                libasora.synchronize()
-                printlog(f"took {(time.time()-trt0) : .1f} s.", logfile, quiet)
+            printlog(f"Doing Raytracing (rank={rank:n})...", logfile, quiet, ' ')
+            libasora.raytrace_device(R_max_LLS, sig, dr, 0, NumSrc_local, minlogtau, dlogtau, NumTau)
+            libasora.synchronize()
+            printlog(f"rank={rank:n} took {(time.time()-trt0) : .1e} s.", logfile, quiet)
+            _allreduce_phi(libasora, N, use_mpi, comm, rank)
 
             # (2) chemistry, evolve.py:207-211.  Every rank runs it on the identical summed rates
             # (the reference runs it on rank 0 and broadcasts two N^3 grids, evolve.py:439-481).
@@ -230,6 +265,7 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
 
         converged = (conv_flag < conv_criterion) or ((rel_change_xh1 < convergence_fraction) and
                                                      (rel_change_xh0 < convergence_fraction))
+        converged = _agree_on_convergence(comm, converged)            # evolve.py:484-489
         prev_sum_xh1_int = sum_xh1_int
         prev_sum_xh0_int = sum_xh0_int
 

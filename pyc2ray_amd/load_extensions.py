@@ -184,6 +184,37 @@ class _LibAsora:
         _capi.check(self._lib.asora_chemistry_finish(C.byref(conv), C.byref(s1), C.byref(s0)), "chemistry_finish")
         return conv.value, s1.value, s0.value
 
+    def evolve_begin(self, dt, bh00, albpow, colh0, temph0, abu_c, R, sig, dr, minlogtau, dlogtau, NumTau,
+                     src_begin, src_count, conv_criterion, convergence_fraction):
+        """Start a time step of the device-resident loop (NDENS, TEMP, XH on the device)."""
+        _capi.check(self._lib.asora_evolve_begin(float(dt), float(bh00), float(albpow), float(colh0), float(temph0),
+                                                 float(abu_c), float(R), float(sig), float(dr), float(minlogtau),
+                                                 float(dlogtau), int(NumTau), int(src_begin), int(src_count),
+                                                 float(conv_criterion), float(convergence_fraction)), "evolve_begin")
+
+    def evolve_enqueue(self, iterations):
+        _capi.check(self._lib.asora_evolve_enqueue(int(iterations)), "evolve_enqueue")
+
+    def evolve_poll(self, max_rows=32):
+        """(niter, converged, rows): rows[q] = (conv_flag, sum_xh1, sum_xh0, rel_change_xh1, rel_change_xh0) of the
+        iterations carried out since the last poll."""
+        niter, done, got = C.c_int(0), C.c_int(0), C.c_int(0)
+        hist = np.zeros((int(max_rows), 5))
+        _capi.check(self._lib.asora_evolve_poll(C.byref(niter), C.byref(done), _capi.dptr(hist), int(max_rows),
+                                                C.byref(got)), "evolve_poll")
+        return niter.value, bool(done.value), hist[:got.value]
+
+    def planes_to_host(self, which, i_begin, i_count, N):
+        out = np.empty((int(i_count), N, N))
+        _capi.check(self._lib.asora_planes_to_host(int(which), int(i_begin), int(i_count), _capi.dptr(out)),
+                    "planes_to_host")
+        return out
+
+    def planes_to_device(self, which, i_begin, planes):
+        a = np.ascontiguousarray(planes, dtype=np.float64)
+        _capi.check(self._lib.asora_planes_to_device(int(which), int(i_begin), int(a.shape[0]), _capi.dptr(a)),
+                    "planes_to_device")
+
     def set_option(self, option, value):
         _capi.check(self._lib.asora_set_option(int(option), int(value)), "set_option")
 

@@ -133,3 +133,64 @@ def subbox_case(name):
         c["flux"] = c["flux"] * (0.5 + np.arange(c["flux"].shape[0]))
     c.update(max_subbox=max_subbox, subboxsize=subboxsize, loss_fraction=loss_fraction)
     return c
+
+
+# ---- evolve3D / do_raytracing cases pinned by the reference's own Python (tests/golden/make_evolve_golden.py) ------
+def blackbody_tables(teff=5e4, num_tau=2000):
+    """The black-body tables of the reference's tests (parameters.yml: Teff, cross_section_pl_index 2.8,
+    integration from the HI threshold to 10 x the HeII threshold), from this package's table builder.  Both sides of
+    every comparison receive the same arrays."""
+    from pyc2ray_amd.radiation import BlackBodySource, make_tau_table
+    ev2fr = 0.241838e15
+    tau, dlog = make_tau_table(MINLOGTAU, MAXLOGTAU, num_tau)
+    src = BlackBodySource(teff, False, ev2fr * 13.598, 2.8)
+    thin, thick = src.make_photo_table(tau, ev2fr * 13.598, 10 * ev2fr * 54.416, 1e48)
+    return thin, thick, dlog
+
+
+MYR = 3.15576e13
+#: name -> dict(N, grid kind/seed/tau_cell or "cfg0", sources, flux, R, use_gpu, order, dt, steps, ...)
+EVOLVE_CASES = {
+    # BASELINE.json configs[0], verbatim: one point source, uniform 64^3 density, r_RT = 32, the Fortran CPU path
+    # (SURVEY 8d(1): ndens 1e-3, xh 1.2e-3, T 1e4, source (32,32,32), normflux 1e6; box, time step and sub-box
+    # parameters of unit_tests_hackathon/1_single_black_body/parameters.yml)
+    "cfg0_64":        dict(kind="cfg0", N=64, use_gpu=False, order="F", steps=2),
+    "l16_cpu_F":      dict(kind="lognormal", N=16, seed=31, tau_cell=0.2, ns=3, sseed=41, flux=2e-4, R=1000.0, use_gpu=False,
+                           order="F", steps=2, dt=2 * MYR, subboxsize=3, max_subbox=1000, loss_fraction=1e-2),
+    "l24_cpu_F_7src": dict(kind="lognormal", N=24, seed=32, tau_cell=0.1, ns=7, sseed=42, flux=4e-5, R=1000.0, use_gpu=False,
+                           order="F", steps=1, dt=3 * MYR, subboxsize=5, max_subbox=1000, loss_fraction=0.05),
+    # (the reference's loop only accepts Fortran-ordered xh: its np.copy(xh) goes to an f2py intent(inout) argument)
+    "l16_gpu_F":      dict(kind="lognormal", N=16, seed=33, tau_cell=0.2, ns=4, sseed=43, flux=1e-4, R=6.5, use_gpu=True,
+                           order="F", steps=2, dt=2 * MYR),
+    "l24_gpu_F_37src": dict(kind="lognormal", N=24, seed=34, tau_cell=0.15, ns=37, sseed=44, flux=1.6e-5, R=9.0, use_gpu=True,
+                            order="F", steps=1, dt=3 * MYR),
+    "l32_gpu_F_5src": dict(kind="lognormal", N=32, seed=35, tau_cell=0.15, ns=5, sseed=45, flux=2.8e-4, R=11.0, use_gpu=True,
+                           order="F", steps=1, dt=3 * MYR),
+}
+RAYTRACING_CASES = ("l16_cpu_F", "l24_cpu_F_7src")
+
+
+def evolve_case(name):
+    s = EVOLVE_CASES[name]
+    N = s["N"]
+    if s["kind"] == "cfg0":
+        nd = np.full((N, N, N), 1e-3)
+        xh = np.full((N, N, N), 1.2e-3)
+        dr = 0.014 * 3.086e24 / N
+        pos = np.array([[32], [32], [32]])
+        flux = np.array([1e6])
+        thin, thick, dlog = blackbody_tables()
+        c = dict(R=32.0, dt=MYR, subboxsize=150, max_subbox=1000, loss_fraction=1e-2)
+    else:
+        nd, xh, dr = grid(N, s["kind"], s["seed"], s["tau_cell"], xlo=1e-4, xhi=2e-3)
+        pos, flux = sources(N, s["ns"], s["sseed"], flux=s["flux"])
+        thin, thick, dlog = soft_tables()
+        c = dict(R=s["R"], dt=s["dt"], subboxsize=s.get("subboxsize", N), max_subbox=s.get("max_subbox", 1000),
+                 loss_fraction=s.get("loss_fraction", 1e-2))
+    order = s["order"]
+    n = thin.shape[0]
+    c.update(N=N, ndens=np.asarray(nd, order=order), xh=np.asarray(xh, order=order),
+             temp=np.asarray(np.full((N, N, N), 1e4), order=order), dr=dr, pos=pos, flux=flux, thin=thin, thick=thick,
+             dlogtau=dlog, use_gpu=s["use_gpu"], order=order, steps=s["steps"], convergence_fraction=1e-4,
+             heat_thin=1e-11 * thin * np.linspace(1.0, 2.0, n), heat_thick=0.7e-11 * thick * np.linspace(2.0, 1.0, n))
+    return c

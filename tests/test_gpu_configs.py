@@ -1,0 +1,233 @@
+"""Every BASELINE.json configuration at its full size, on the GPU, through the C-ABI (pytest -m gpu).
+
+  configs[0]  64^3, one source, r_RT = 32, Fortran CPU path ............ tests/test_evolve_golden.py::cfg0_64
+  configs[1]  128^3, one source, r_RT = 64 (Stroemgren sphere) ........... test_config1_* below
+  configs[2]  256^3 uniform, 1000 RandomState(100) sources, r_RT = 16 / 32 / 64: against sparse fixtures produced
+              by the REFERENCE Fortran at this size (tests/golden/make_fullsize_golden.py)
+  configs[3]  256^3 log-normal density, sources on the densest cells (adjacent sources, same-address atomics):
+              against the oracle on the host cores of the GPU box
+  configs[4]  512^3 (indices beyond 2^31 bytes): corner sources, exact pair counts, one source against the oracle
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = os.path.join(HERE, "golden")
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, G)
+
+
+@pytest.fixture(scope="module")
+def asora():
+    import pyc2ray_amd as p
+    from pyc2ray_amd import _capi
+    from pyc2ray_amd.load_extensions import load_asora
+    lib = load_asora()
+    yield p, lib, _capi
+    if p.cuda_is_init():
+        p.device_close()
+
+
+@pytest.fixture(scope="module")
+def bench_tables():
+    import bench
+    return bench.make_tables()
+
+
+def _fresh(p, N):
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 64)
+
+
+def _lattice_points_within(R):
+    m = int(np.floor(R))
+    r = np.arange(-m, m + 1)
+    return int(((r[:, None, None] ** 2 + r[None, :, None] ** 2 + r[None, None, :] ** 2) <= R * R).sum())
+
+
+# ---- configs[2] ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R", [16, 32, 64])
+def test_config2_256_uniform_1000_sources_against_reference_fortran(asora, bench_tables, R):
+    """The benchmark workload itself.  R selects three different kernel shapes (octants x 64 threads, mirrored
+    sector pairs x 128, pairs x 512 with 1024-entry LDS tables)."""
+    import bench
+    import make_fullsize_golden as MG
+    p, lib, capi = asora
+    N, NS = 256, 1000
+    g = np.load(os.path.join(G, f"fullsize_uniform_R{R}.npz"))
+    thin, thick, dlog = bench_tables
+    np.testing.assert_allclose([thin.sum(), thick.sum()], g["table_sums"], rtol=1e-13)     # same tables as the fixture's
+    ndens, xh, temp, dr, pos, flux = bench.make_workload("uniform", N, NS)
+    _fresh(p, N)
+    p.photo_table_to_device(thin, thick)
+    p0, f0 = cases.flat_sources(pos, flux)
+    lib.source_data_to_device(p0, f0, NS)
+    lib.grid_to_device(capi.GRID_NDENS, ndens)
+    lib.grid_to_device(capi.GRID_XH_AV, xh)
+    lib.set_option(capi.OPT_FORTRAN_CONSTANTS, 1)            # the fixture is the Fortran path: its constants
+    try:
+        lib.raytrace_device(float(R), bench.SIG, dr, 0, NS, bench.MINLOGTAU, dlog, thin.shape[0] - 1)
+    finally:
+        lib.set_option(capi.OPT_FORTRAN_CONSTANTS, 0)
+    phi = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+    gam, ev = lib.last_raytrace_counts()
+    assert gam == NS * _lattice_points_within(float(R))      # R < N/2: no source is clipped by the periodic window
+    flat = phi.ravel()
+    np.testing.assert_allclose(flat[MG.sample_indices(R)], g["vals"], rtol=1e-8, atol=0)
+    src_flat = ((pos[0] - 1) * N + (pos[1] - 1)) * N + (pos[2] - 1)
+    np.testing.assert_allclose(flat[src_flat], g["src_vals"], rtol=1e-8, atol=0)
+    d = MG.digest(phi)
+    assert int(d["nonzero"]) == int(g["nonzero"])
+    np.testing.assert_allclose(d["plane_sums"], g["plane_sums"], rtol=1e-9)
+    np.testing.assert_allclose(d["block_sums"], g["block_sums"], rtol=1e-9)
+    np.testing.assert_allclose(float(d["total"]), float(g["total"]), rtol=1e-10)
+
+
+# ---- configs[3] ---------------------------------------------------------------------------------------------------
+def test_config3_256_lognormal_clustered_sources_against_oracle(asora, bench_tables):
+    """The cosmological-like workload of bench.py: log-normal density, sources ON the densest cells -- neighbouring
+    and near-coincident sources whose spheres overlap almost completely (many atomics on the same addresses), fluxes
+    proportional to the density.  96 of them against the oracle's restatement of the ASORA kernel."""
+    import bench
+    p, lib, capi = asora
+    N, NS, R = 256, 96, 32.0
+    thin, thick, dlog = bench_tables
+    ndens, xh, temp, dr, pos, flux = bench.make_workload("cosmo", N, 1000)
+    pos, flux = pos[:, :NS], flux[:NS]
+    d = np.abs(pos[:, :, None] - pos[:, None, :]).max(axis=0)
+    assert ((d <= 1).sum() - NS) // 2 >= 20                  # the case does contain adjacent sources
+    _fresh(p, N)
+    p.photo_table_to_device(thin, thick)
+    p0, f0 = cases.flat_sources(pos, flux)
+    lib.source_data_to_device(p0, f0, NS)
+    lib.grid_to_device(capi.GRID_NDENS, ndens)
+    lib.grid_to_device(capi.GRID_XH_AV, xh)
+    numtau = thin.shape[0] - 1
+    lib.raytrace_device(R, bench.SIG, dr, 0, NS, bench.MINLOGTAU, dlog, numtau)
+    phi = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+    gam, _ = lib.last_raytrace_counts()
+    assert gam == NS * _lattice_points_within(R)
+    ref = O.asora_do_all_sources(R, bench.SIG, dr, ndens, xh, p0, f0, thin, thick, bench.MINLOGTAU, dlog, NumTau=numtau,
+                                 flags=O.ASORA_MODE)["phi_ion"]
+    w = ref != 0
+    assert np.array_equal(phi != 0, w) and w.sum() > 1e5
+    np.testing.assert_allclose(phi[w], ref[w], rtol=1e-8, atol=0)
+    # and the step the benchmark times: one outer iteration of the device-resident loop on this workload equals
+    # raytrace + chemistry done separately
+    lib.grid_to_device(capi.GRID_TEMP, temp)
+    lib.grid_to_device(capi.GRID_XH, xh)
+    chem = (bench.MYR, bench.BH00, bench.ALBPOW, bench.COLH0, bench.TEMPH0, bench.ABU_C)
+    lib.grid_copy(capi.GRID_XH_AV, capi.GRID_XH)
+    lib.grid_copy(capi.GRID_XH_INTERMED, capi.GRID_XH)
+    lib.raytrace_device(R, bench.SIG, dr, 0, NS, bench.MINLOGTAU, dlog, numtau)
+    conv, s1, s0 = lib.chemistry_device(*chem)
+    x_sep = lib.grid_to_host(capi.GRID_XH_INTERMED, np.empty((N, N, N)))
+    lib.evolve_begin(*chem, R, bench.SIG, dr, bench.MINLOGTAU, dlog, numtau, 0, NS, -1.0, 0.0)
+    lib.evolve_enqueue(1)
+    n_done, done, rows = lib.evolve_poll()
+    assert n_done == 1 and not done and int(rows[0][0]) == conv
+    np.testing.assert_allclose(rows[0][1:3], [s1, s0], rtol=1e-12)
+    x_fused = lib.grid_to_host(capi.GRID_XH_INTERMED, np.empty((N, N, N)))
+    np.testing.assert_allclose(x_fused, x_sep, rtol=1e-11, atol=0)
+    np.testing.assert_allclose(lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))[w], phi[w], rtol=1e-11)
+
+
+# ---- configs[4] ---------------------------------------------------------------------------------------------------
+def test_config4_512_corner_sources_and_large_indices(asora):
+    """512^3: the [k][j][i] twins of the grids start 2^30 bytes in and end beyond 2^31 bytes.  Sources on the first
+    and the last cell (every octant wraps), in the middle and on a face; one of them against the oracle."""
+    p, lib, capi = asora
+    N, R = 512, 32.0
+    thin, thick, dlog = cases.soft_tables(20000)
+    rng = np.random.default_rng(4)
+    nd = 1e-3 * np.exp(0.8 * rng.standard_normal((N, N, N), dtype=np.float32).astype(np.float64) - 0.32)
+    xh = np.full((N, N, N), 2e-4)
+    dr = 0.02 / (cases.SIG * 1e-3)
+    pos = np.array([[512, 512, 512], [1, 1, 1], [256, 256, 256], [512, 300, 1], [17, 512, 400], [300, 1, 512]]).T
+    flux = np.array([1.0, 2.0, 3.0, 1.5, 0.5, 2.5])
+    NS = flux.shape[0]
+    _fresh(p, N)
+    p.photo_table_to_device(thin, thick)
+    p0, f0 = cases.flat_sources(pos, flux)
+    lib.grid_to_device(capi.GRID_NDENS, nd)
+    lib.grid_to_device(capi.GRID_XH_AV, xh)
+    numtau = thin.shape[0] - 1
+
+    def trace(sel):
+        q0, g0 = cases.flat_sources(pos[:, sel], flux[sel])
+        lib.source_data_to_device(q0, g0, g0.shape[0])
+        lib.raytrace_device(R, cases.SIG, dr, 0, g0.shape[0], cases.MINLOGTAU, dlog, numtau)
+        return lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+
+    full = trace(np.arange(NS))
+    gam, ev = lib.last_raytrace_counts()
+    assert gam == NS * _lattice_points_within(R)
+    assert np.isfinite(full).all() and (full >= 0).all()
+    # the last cell of the grid (largest index of both layouts) is a source cell: it holds the largest rate there
+    assert full[511, 511, 511] > 0 and full[0, 0, 0] > 0
+    # the corner source alone against the oracle: its sphere wraps onto all eight corners of the box
+    one = trace(np.array([0]))
+    ref = O.asora_do_all_sources(R, cases.SIG, dr, nd, xh, p0[:3], f0[:1], thin, thick, cases.MINLOGTAU, dlog,
+                                 NumTau=numtau, flags=O.ASORA_MODE)["phi_ion"]
+    w = ref != 0
+    assert np.array_equal(one != 0, w)
+    np.testing.assert_allclose(one[w], ref[w], rtol=1e-8, atol=0)
+    for corner in [(0, 0, 0), (511, 0, 0), (0, 511, 511), (511, 511, 511), (480, 5, 500)]:
+        assert one[corner] > 0
+    # superposition at this size: the sources one by one add up to the joint trace
+    acc = one.copy()
+    for s in range(1, NS):
+        acc += trace(np.array([s]))
+    np.testing.assert_allclose(acc, full, rtol=1e-11, atol=0)
+    p.device_close()
+
+
+# ---- configs[1] ---------------------------------------------------------------------------------------------------
+def test_config1_128_single_source_R64_against_oracle(asora):
+    """Test 1 geometry: 128^3 uniform, ONE source at (64,64,64), r_RT = 64 (the sphere touches the periodic window:
+    24 sector workgroups of 1024 threads).  Raytrace against the oracle, then three steps of the device-resident
+    loop against the oracle's restatement of the reference loop (same iteration counts)."""
+    import evolve_oracle as EO
+    p, lib, capi = asora
+    N, R = 128, 64.0
+    nd = np.full((N, N, N), 1.87e-4)
+    xh = np.full((N, N, N), 1.2e-3)
+    temp = np.full((N, N, N), 1e4)
+    dr = 5e24 / N
+    pos = np.array([[64], [64], [64]])
+    flux = np.array([1e6])
+    thin, thick, dlog = cases.grey_tables(2000)
+    _fresh(p, N)
+    p.photo_table_to_device(thin, thick)
+    p0, f0 = cases.flat_sources(pos, flux)
+    lib.source_data_to_device(p0, f0, 1)
+    lib.grid_to_device(capi.GRID_NDENS, nd)
+    lib.grid_to_device(capi.GRID_XH_AV, xh)
+    lib.raytrace_device(R, cases.SIG, dr, 0, 1, cases.MINLOGTAU, dlog, thin.shape[0])
+    phi = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+    ref = O.asora_do_all_sources(R, cases.SIG, dr, nd, xh, p0, f0, thin, thick, cases.MINLOGTAU, dlog,
+                                 NumTau=thin.shape[0], flags=O.ASORA_MODE)["phi_ion"]
+    w = ref != 0
+    assert np.array_equal(phi != 0, w)
+    np.testing.assert_allclose(phi[w], ref[w], rtol=1e-8, atol=0)
+    dt = 1.578e15 / 10
+    x = xh
+    x_ref = xh
+    for step in range(2):
+        x, _ = p.evolve3D(dt, dr, flux, pos, True, 1000, N, 1e-2, temp, nd, x, thin, thick, cases.MINLOGTAU, dlog, R,
+                          1e-4, cases.SIG, cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C,
+                          logfile=os.devnull, quiet=True)
+        x_ref, _, niter_ref, _ = EO.evolve3D_oracle(dt, dr, flux, pos, temp, nd, x_ref, thin, thick, cases.MINLOGTAU,
+                                                    dlog, R, 1e-4, cases.SIG, cases.BH00, cases.ALBPOW, cases.COLH0,
+                                                    cases.TEMPH0, cases.ABU_C)
+        assert p.evolve._evolve.last_niter == niter_ref
+        np.testing.assert_allclose(x, x_ref, rtol=1e-8, atol=0)

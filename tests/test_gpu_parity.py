@@ -817,3 +817,78 @@ def test_randomised_chemistry_extremes_against_oracle(asora):
         np.testing.assert_allclose(xi, xi_ref, rtol=1e-9, atol=1e-15, err_msg=f"xh_intermed, dt={dt}")
         assert abs(conv - conv_ref) <= 3, (dt, conv, conv_ref)
         assert np.isfinite(xa).all() and (xa >= 1e-14).all() and (xa <= 1.0).all()
+
+
+# ---- the device-resident loop and the tiled chemistry pass ---------------------------------------------------------
+@pytest.mark.parametrize("N", [17, 24])
+def test_chemistry_slabs_equal_the_whole_pass_for_odd_and_even_meshes(asora, N):
+    """asora_chemistry_range over uneven slabs (odd N: odd plane offsets) == asora_chemistry_device == the oracle."""
+    p, lib, capi = asora
+    c = cases.chem_case(N, 23 + N)
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 8)
+
+    def load():
+        for which, key in ((capi.GRID_NDENS, "ndens"), (capi.GRID_TEMP, "temp"), (capi.GRID_XH, "xh"),
+                           (capi.GRID_XH_AV, "xh_av"), (capi.GRID_XH_INTERMED, "xh_intermed"), (capi.GRID_PHI_ION, "phi_ion")):
+            lib.grid_to_device(which, c[key])
+
+    chem = (c["dt"], c["bh00"], c["albpow"], c["colh0"], c["temph0"], c["abu_c"])
+    load()
+    conv, s1, s0 = lib.chemistry_device(*chem)
+    xa = lib.grid_to_host(capi.GRID_XH_AV, np.empty((N, N, N)))
+    xi = lib.grid_to_host(capi.GRID_XH_INTERMED, np.empty((N, N, N)))
+    load()
+    cuts = [0, 1, 4, 9, N - 2, N]
+    for q in range(len(cuts) - 1):
+        lib.chemistry_range(*chem, cuts[q], cuts[q + 1] - cuts[q], q == 0)
+    conv2, s1b, s0b = lib.chemistry_finish()
+    assert conv2 == conv
+    np.testing.assert_allclose([s1b, s0b], [s1, s0], rtol=1e-13)
+    np.testing.assert_allclose(lib.grid_to_host(capi.GRID_XH_AV, np.empty((N, N, N))), xa, rtol=1e-13, atol=0)
+    np.testing.assert_allclose(lib.grid_to_host(capi.GRID_XH_INTERMED, np.empty((N, N, N))), xi, rtol=1e-13, atol=0)
+    xa_ref, xi_ref, conv_ref, _ = O.global_pass(c["dt"], c["ndens"], c["temp"], c["xh"], c["xh_av"], c["xh_intermed"],
+                                                c["phi_ion"], c["bh00"], c["albpow"], c["colh0"], c["temph0"], c["abu_c"])
+    assert abs(conv - conv_ref) <= 1
+    np.testing.assert_allclose(xi, xi_ref, rtol=1e-9, atol=0)
+    np.testing.assert_allclose(xa, xa_ref, rtol=1e-9, atol=0)
+
+
+@pytest.mark.parametrize("N,ns,R", [(17, 3, 1000.0), (32, 5, 9.0), (40, 11, 13.5)])
+def test_device_resident_loop_equals_the_step_by_step_loop(asora, N, ns, R, monkeypatch, tmp_path):
+    """evolve3D on one GPU enqueues batches of outer iterations and lets the device evaluate the convergence test.
+    Batch sizes 1, 3 and 8 must give identical results and the iteration count of the host-driven loop (raytrace_device
+    + chemistry_device + the test of evolve.py:216-236 on the host), which is what the oracle loop restates."""
+    from evolve_oracle import evolve3D_oracle
+    import pyc2ray_amd.evolve as E
+    p, lib, capi = asora
+    nd, xh, dr = cases.grid(N, "lognormal", 70 + N, 0.15, xlo=1e-4, xhi=2e-3)
+    temp = np.full((N, N, N), 1e4)
+    pos, flux = cases.sources(N, ns, 80 + N, flux=3e-4 * (N / 16.0) ** 3 / ns)
+    thin, thick, dlog = cases.soft_tables()
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 8)
+    p.photo_table_to_device(thin, thick)
+    dt = 3.15576e13 * 3
+    args = (dt, dr, flux, pos, True, 1000, N, 1e-2, temp, nd, xh, thin, thick, cases.MINLOGTAU, dlog, R, 1e-4, cases.SIG,
+            cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C)
+    results = []
+    for batch in (1, 3, 8):
+        monkeypatch.setattr(E, "EVOLVE_BATCH", batch)
+        x, phi = p.evolve3D(*args, logfile=str(tmp_path / f"log{batch}"), quiet=True)
+        results.append((x, phi, E._evolve.last_niter))
+    for x, phi, niter in results[1:]:
+        assert niter == results[0][2]
+        assert np.array_equal(x, results[0][0])
+        np.testing.assert_allclose(phi, results[0][1], rtol=1e-11, atol=0)       # atomic summation order only
+    x_ref, phi_ref, niter_ref, hist = evolve3D_oracle(dt, dr, flux, pos, temp, nd, xh, thin, thick, cases.MINLOGTAU, dlog,
+                                                      R, 1e-4, cases.SIG, cases.BH00, cases.ALBPOW, cases.COLH0,
+                                                      cases.TEMPH0, cases.ABU_C)
+    assert results[0][2] == niter_ref and niter_ref >= 3
+    np.testing.assert_allclose(results[0][0], x_ref, rtol=1e-8, atol=0)
+    np.testing.assert_allclose(results[0][1], phi_ref, rtol=1e-7, atol=0)
+    assert 0.02 < results[0][0].mean() < 0.98                                     # a partially ionised box
+    # the log has one convergence line per iteration
+    assert open(tmp_path / "log8").read().count("Number of non-converged points") == niter_ref
