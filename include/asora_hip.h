@@ -155,6 +155,13 @@ int asora_raytrace_device(double R, double sig, double dr, int src_begin, int sr
  * asora_raytrace_device(...) == begin; range(all); fold(0, N). */
 int asora_raytrace_begin(double R, double sig, double dr, double minlogtau, double dlogtau, int NumTau);
 int asora_raytrace_range(int src_begin, int src_count);
+/* asora_raytrace_begin for a rank of a multi-GPU run that only works on SOME planes of the grids: nHI is formed
+ * from ndens and xh_av, and both rate accumulators are zeroed, on the `nruns` runs of planes
+ * [runs[2q], runs[2q] + runs[2q+1]) only -- the planes this rank's sources reach plus the planes whose rates it
+ * collects (pyc2ray_amd/dist.py, SlabPlan).  Everything else of the accumulators must already be zero (it stays
+ * zero: nothing is traced into it), which one call of asora_raytrace_begin at the start of a time step ensures. */
+int asora_raytrace_begin_planes(double R, double sig, double dr, double minlogtau, double dlogtau, int NumTau,
+                                const int *runs, int nruns);
 int asora_raytrace_fold(int i_begin, int i_count);
 /* The HIP stream (hipStream_t) all of the library's work is ordered on. */
 void *asora_stream(void);

@@ -43,6 +43,8 @@ SIGNATURES = {
                                         C.c_double, C.c_int]),
     "asora_raytrace_begin": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]),
     "asora_raytrace_range": (C.c_int, [C.c_int, C.c_int]),
+    "asora_raytrace_begin_planes": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _ip,
+                                              C.c_int]),
     "asora_raytrace_fold": (C.c_int, [C.c_int, C.c_int]),
     "asora_stream": (C.c_void_p, []),
     "asora_subbox_raytrace_device": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_double, C.c_double, C.c_double, C.c_double,

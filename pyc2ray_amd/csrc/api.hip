@@ -618,6 +618,34 @@ int asora_raytrace_begin(double R, double sig, double dr, double minlogtau, doub
     return rt_begin(R, sig, dr, minlogtau, dlogtau, NumTau, nullptr, true);
 }
 
+int asora_raytrace_begin_planes(double R, double sig, double dr, double minlogtau, double dlogtau, int NumTau,
+                                const int *runs, int nruns)
+{
+    clear_error();
+    if (int rc = require_init("raytrace_begin_planes")) return rc;
+    State &st = g_state;
+    st.rt_open = false;
+    if (!st.grid_valid[ASORA_GRID_NDENS]) return fail(4, "raytrace_begin_planes: density not on device");
+    if (!st.grid_valid[ASORA_GRID_XH_AV]) return fail(4, "raytrace_begin_planes: xh_av not on device");
+    if (!st.opt[ASORA_OPT_GREY_NOTABLES] && !st.tables) return fail(4, "raytrace_begin_planes: radiation tables not on device");
+    if (!(R >= 0.0)) return fail(4, "raytrace_begin_planes: R must be >= 0");
+    if (NumTau < 1 && !st.opt[ASORA_OPT_GREY_NOTABLES]) return fail(4, "raytrace_begin_planes: NumTau must be >= 1");
+    if (!st.opt[ASORA_OPT_Z_TRANSPOSED]) return fail(4, "raytrace_begin_planes: needs the [k][j][i] twins (ASORA_OPT_Z_TRANSPOSED = 1)");
+    if (st.opt[ASORA_OPT_HEATING]) return fail(4, "raytrace_begin_planes: no heating rates on this path");
+    if (nruns < 0 || (nruns > 0 && !runs)) return fail(3, "raytrace_begin_planes: bad plane runs");
+    for (int q = 0; q < nruns; ++q)
+        if (runs[2 * q] < 0 || runs[2 * q + 1] < 0 || runs[2 * q] + runs[2 * q + 1] > st.N)
+            return fail(3, "raytrace_begin_planes: plane run outside the mesh");
+    ASORA_HIP_TRY(hipMemsetAsync(st.counters, 0, sizeof(unsigned long long) * 2, st.stream));
+    for (int q = 0; q < nruns; ++q)
+        if (int rc = launch_prepare_range(st, runs[2 * q], runs[2 * q + 1], true, st.grid[ASORA_GRID_PHI_ION])) return rc;
+    fill_rt_params(st.rt_params, R, sig, dr, minlogtau, dlogtau, NumTau);
+    st.rt_heat = false;
+    st.rt_pipelined = false;
+    st.rt_open = true;
+    return 0;
+}
+
 int asora_raytrace_range(int src_begin, int src_count)
 {
     clear_error();

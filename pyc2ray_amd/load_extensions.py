@@ -140,6 +140,13 @@ class _LibAsora:
         _capi.check(self._lib.asora_raytrace_begin(float(R), float(sig), float(dr), float(minlogtau), float(dlogtau),
                                                    int(NumTau)), "raytrace_begin")
 
+    def raytrace_begin_planes(self, R, sig, dr, minlogtau, dlogtau, NumTau, runs):
+        """runs: [(first plane, number of planes), ...] -- see asora_raytrace_begin_planes."""
+        r = np.ascontiguousarray(np.asarray(runs, dtype=np.int32).reshape(-1, 2))
+        _capi.check(self._lib.asora_raytrace_begin_planes(float(R), float(sig), float(dr), float(minlogtau),
+                                                          float(dlogtau), int(NumTau), _capi.iptr(r), int(r.shape[0])),
+                    "raytrace_begin_planes")
+
     def raytrace_range(self, src_begin, src_count):
         _capi.check(self._lib.asora_raytrace_range(int(src_begin), int(src_count)), "raytrace_range")
 

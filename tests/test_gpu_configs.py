@@ -102,9 +102,17 @@ def test_config3_256_lognormal_clustered_sources_against_oracle(asora, bench_tab
     N, NS, R = 256, 96, 32.0
     thin, thick, dlog = bench_tables
     ndens, xh, temp, dr, pos, flux = bench.make_workload("cosmo", N, 1000)
-    pos, flux = pos[:, :NS], flux[:NS]
-    d = np.abs(pos[:, :, None] - pos[:, None, :]).max(axis=0)
-    assert ((d <= 1).sum() - NS) // 2 >= 20                  # the case does contain adjacent sources
+    # the 88 densest cells, plus the densest one three more times (coincident sources: every atomic of theirs hits an
+    # address another workgroup is adding to) and its neighbours along each axis and the diagonal
+    top = pos[:, 0]
+    extra = np.array([top, top, top, top + [1, 0, 0], top + [0, 1, 0], top + [0, 0, 1], top + [1, 1, 1], top - [1, 1, 0]]).T
+    extra = (extra - 1) % N + 1
+    pos = np.concatenate([pos[:, :NS - 8], extra], axis=1)
+    flux = np.concatenate([flux[:NS - 8], flux[0] * np.array([1.0, 0.5, 2.0, 1.0, 1.0, 1.0, 1.0, 1.0])])
+    d = np.abs(pos[:, :, None] - pos[:, None, :])
+    d = np.minimum(d, N - d).max(axis=0)
+    assert ((d <= 1).sum() - NS) // 2 >= 20                  # adjacent or coincident pairs
+    assert ((d <= 32).sum() - NS) // 2 >= 100                # pairs whose spheres overlap by more than half
     _fresh(p, N)
     p.photo_table_to_device(thin, thick)
     p0, f0 = cases.flat_sources(pos, flux)

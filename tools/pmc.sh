@@ -1,5 +1,5 @@
 # usage: bash tools/pmc.sh TAG [ASORA_ABLATE]  -- PMC passes of bench.py (2 timed steps); summaries land in gpurun_out/pmc_TAG_*
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; TAG=$1; export ASORA_ABLATE=${2:-0}
+export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun exports it) to the repository root}; TAG=$1; export ASORA_ABLATE=${2:-0}
 cd /tmp
 i=0
 for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS" \
