@@ -4,18 +4,22 @@
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one outer iteration of evolve3D (pyc2ray/evolve.py:168-240) on device-resident inputs:
-raytrace all of this rank's sources into the rate grid, sum the rate grids over ranks (RCCL
-all-reduce, N>1 only), one chemistry pass over the whole grid with its convergence reductions.
-xh_av / xh_intermed are reset from xh at the start of every step so that all steps do the work of
-the FIRST (most expensive) iteration of a time step.
+One "step" = one outer iteration of evolve3D (pyc2ray/evolve.py:168-240) on device-resident inputs, in its steady
+state: raytrace all of this rank's sources, [N>1: exchange the rates between ranks,] one chemistry pass with its
+convergence reductions -- the same launches evolve3D makes per iteration (asora_evolve_enqueue on one GPU,
+TorchComm.slab_iteration on several).  The convergence test is evaluated but can never pass (criterion -1), so
+every step does its full work.  The FIRST iteration of a time step additionally forms nHI from xh and zeroes the
+accumulators; its time is reported beside (config.first_iteration_of_a_time_step_ms).
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 256^3 grid, uniform
-ndens = 1e-3, xh = 2e-4, T = 1e4 K, dr = 3*3.086e24/256 cm, 1000 equal sources per GPU at
-RandomState(100) positions, R = 32 cells, black-body Teff = 1e5 K table with NumTau = 20000.
-`--workload cosmo` switches to configs[3] (log-normal density, sources on the densest cells).
-Scaling is WEAK: every rank traces --nsrc sources (the global list has gpus*nsrc sources); the
-chemistry is replicated, so it counts once.
+Workload at N=1 (BASELINE.json configs[2], the configuration the metric is quoted on): 256^3 grid, uniform
+ndens = 1e-3, xh = 2e-4, T = 1e4 K, dr = 3*3.086e24/256 cm, 1000 equal sources at RandomState(100) positions,
+R = 32 cells, black-body Teff = 1e5 K table with NumTau = 20000.
+At N>1 the default is the metric's multi-GPU mode, BASELINE configs[3]: the same 1000 sources IN TOTAL, on the
+densest cells of a log-normal 256^3 density, sharded over the ranks in contiguous blocks (pyc2ray/evolve.py:362-367)
+of the list ordered by first coordinate -- STRONG scaling ("scaling": "strong").  The rates are exchanged plane-wise
+(pyc2ray_amd/dist.py SlabPlan: rates to the owners of the planes, slab chemistry, xh_av back); `--exchange allreduce`
+selects the full-grid RCCL all-reduce with replicated chemistry instead.  `--scaling weak` gives every rank --nsrc
+sources (the global list then has gpus*nsrc); `--workload` overrides the density/source model.
 
 Unit of work ("cell-update"):
   raytrace  = one (source, cell) pair that receives a rate: |d| <= R inside the periodic window
@@ -46,6 +50,7 @@ TEMPH0 = 13.598 / 8.617e-05                        # eth0*ev2k                  
 HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: 8 TB/s spec
 RT_BYTES_PER_UPDATE = 32                           # 8 ndens + 8 xh_av + 16 Gamma RMW
 CHEM_BYTES_PER_UPDATE = 56                         # 5 loads + 2 stores
+CHEM_FUSED_BYTES_PER_UPDATE = 104                  # the fused pass: 6 loads + 7 stores
 
 
 def make_tables():
@@ -87,42 +92,47 @@ def make_workload(kind, N, nsrc_total):
     return ndens, xh, temp, dr, pos, flux
 
 
-def workload_label(kind, N, nsrc, R):
-    """Names the BASELINE.json config a run corresponds to (configs[2] is what `metric` is quoted on)."""
+def workload_label(kind, N, nsrc_total, R, world, strong):
+    """Names the BASELINE.json config a run corresponds to (configs[2] is what `metric` is quoted on at one GPU,
+    configs[3] its multi-GPU mode)."""
+    share = (f"{nsrc_total} sources in total, sharded over {world} GPUs" if (world > 1 and strong) else
+             f"{nsrc_total // max(world, 1)} sources per GPU x {world} GPUs" if world > 1 else f"{nsrc_total} sources")
     if kind == "uniform":
-        tag = "BASELINE configs[2]: " if (N, nsrc) == (256, 1000) and R in (16.0, 32.0, 64.0) else ""
-        return (f"{tag}{N}^3 uniform ndens=1e-3 xh=2e-4, {nsrc} random sources/GPU, r_RT={R:g}, "
+        tag = "BASELINE configs[2]: " if (N, nsrc_total, world) == (256, 1000, 1) and R in (16.0, 32.0, 64.0) else ""
+        return (f"{tag}{N}^3 uniform ndens=1e-3 xh=2e-4, {share} at random positions, r_RT={R:g}, "
                 "raytrace + one chemistry pass per step")
-    tag = ("BASELINE configs[3]: " if (N, nsrc, R) == (256, 1000, 32.0) else
-           "BASELINE configs[4] on one GPU: " if (N, nsrc, R) == (512, 100000, 32.0) else "")
-    return (f"{tag}{N}^3 log-normal density, {nsrc} sources/GPU on the densest cells, r_RT={R:g}, "
+    tag = ("BASELINE configs[3]: " if (N, nsrc_total, R) == (256, 1000, 32.0) and (world == 1 or strong) else
+           "BASELINE configs[4] on one GPU: " if (N, nsrc_total, R, world) == (512, 100000, 32.0, 1) else "")
+    return (f"{tag}{N}^3 log-normal density, {share} on the densest cells, r_RT={R:g}, "
             "raytrace + one chemistry pass per step")
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per launch of the raytrace kernel from the committed PMC summary of this round
-    (profiles/r01_pmc_summary.txt: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc passes of
-    this same command).  Counters are in KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section)
-    prescribes for gfx950 -- the doubling was checked on this repository's chemistry kernel, whose
-    2*FETCH_SIZE equals its 5 N^3 float64 loads exactly.  Returns None when the summary is absent."""
-    c = pmc_counters()
-    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
-        return None
-    return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.txt")
 
 
-def pmc_counters():
-    """Mean per launch of every counter the committed PMC summary holds for the raytrace kernel."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.txt")
+def pmc_counters(kernel):
+    """Mean per launch of every counter the committed PMC summary of this round holds for `kernel` (rocprofv3 --pmc
+    passes of this same command, one counter group per pass; tools/pmc.sh)."""
+    path = os.path.join(ROOT, PMC_SUMMARY)
     out = {}
     if not os.path.exists(path):
         return out
     for line in open(path):
-        if "raytrace_octant_kernel" not in line:
-            continue
         parts = line.split()
-        out[parts[1]] = float(parts[-1].split("=")[1])
+        if len(parts) >= 4 and parts[0].startswith(kernel):
+            out[parts[1]] = float(parts[-1].split("=")[1])
     return out
+
+
+def pmc_traffic_bytes(kernel):
+    """HBM bytes per launch of `kernel`: FETCH_SIZE and WRITE_SIZE collected in separate passes; the counters are in
+    KiB and FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes for gfx950 -- the doubling was
+    checked on this repository's streaming chemistry kernel, whose 2*FETCH_SIZE equals its N^3 float64 loads exactly.
+    None when the summary does not hold the counters."""
+    c = pmc_counters(kernel)
+    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+        return None
+    return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
 
 
 def cpu_baseline(kind, N, ndens, xh, temp, dr, pos, flux, thin, thick, dlog, R, nsrc_job, budget_sources):
@@ -221,9 +231,14 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--N", type=int, default=256)
-    ap.add_argument("--nsrc", type=int, default=1000, help="sources per GPU")
+    ap.add_argument("--nsrc", type=int, default=1000, help="sources: in total (strong scaling) or per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N>1: strong = --nsrc sources in total sharded over the ranks (the metric), weak = --nsrc per rank")
+    ap.add_argument("--exchange", choices=["slab", "allreduce"], default="slab",
+                    help="N>1: how the per-rank rates are summed (see the module docstring)")
     ap.add_argument("--R", type=float, default=32.0)
-    ap.add_argument("--workload", choices=["uniform", "cosmo"], default="uniform")
+    ap.add_argument("--workload", choices=["uniform", "cosmo"], default=None,
+                    help="default: uniform (configs[2]) on one GPU, cosmo (configs[3]) on several")
     ap.add_argument("--cpu-sources", type=int, default=64, help="sources in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=0,
                     help="host cores for the all-cores CPU figure (0 = min(8, cores available); 1 = skip it)")
@@ -242,6 +257,10 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     N, K, W = args.N, args.steps, args.warmup
+    if args.workload is None:
+        args.workload = "uniform" if world == 1 else "cosmo"
+    strong = world > 1 and args.scaling == "strong"
+    nsrc_total = args.nsrc if (strong or world == 1) else args.nsrc * world
 
     # the all-cores CPU sample runs in worker processes that are started now, before this process touches the GPU,
     # and sit idle until the GPU measurement is over
@@ -291,11 +310,27 @@ def main():
     p.photo_table_to_device(thin, thick)
     numtau = thin.shape[0] - 1                  # as raytracing_benchmark/run_test.py:85 passes it
 
-    ndens, xh, temp, dr, pos, flux = make_workload(args.workload, N, args.nsrc * world)
-    lo, hi = rank * args.nsrc, (rank + 1) * args.nsrc          # contiguous block per rank (evolve.py:362-367)
-    my_pos, my_flux = pos[:, lo:hi], flux[lo:hi]
+    ndens, xh, temp, dr, pos, flux = make_workload(args.workload, N, nsrc_total)
     overlap = comm is not None and (args.overlap == 1 or (args.overlap < 0 and comm.overlap))
+    slab = comm is not None and args.exchange == "slab" and not overlap
     src_i0 = None
+    plan = None
+    if slab:
+        # contiguous blocks of the list ordered by first coordinate: what each rank exchanges is then a few planes
+        from pyc2ray_amd.dist import SlabPlan
+        comm.exchange = "slab"
+        pos, flux, bounds = comm.shard_sources_by_slab(pos, flux, world)
+        if not strong:                       # weak scaling: exactly --nsrc per rank
+            bounds = [r * args.nsrc for r in range(world + 1)]
+        lo, hi = bounds[rank], bounds[rank + 1]
+        plan = SlabPlan(N, world, args.R, [pos[0, bounds[r]:bounds[r + 1]] - 1 for r in range(world)])
+    elif strong:
+        per = nsrc_total // world                                    # evolve.py:362-367
+        lo, hi = rank * per, ((rank + 1) * per if rank != world - 1 else nsrc_total)
+    else:
+        lo, hi = rank * args.nsrc, (rank + 1) * args.nsrc          # contiguous block per rank (evolve.py:362-367)
+    my_pos, my_flux = pos[:, lo:hi], flux[lo:hi]
+    n_local = hi - lo
     if overlap:
         comm.overlap = True
         my_pos, my_flux = comm.sort_sources_for_overlap(my_pos, my_flux)
@@ -303,7 +338,7 @@ def main():
     elif comm is not None:
         comm.overlap = False
     p0, f0 = format_sources(my_pos, my_flux)
-    lib.source_data_to_device(p0, f0, args.nsrc)
+    lib.source_data_to_device(p0, f0, n_local)
     lib.grid_to_device(_capi.GRID_NDENS, ndens)
     lib.grid_to_device(_capi.GRID_TEMP, temp)
     lib.grid_to_device(_capi.GRID_XH, xh)
@@ -312,16 +347,24 @@ def main():
     lib.set_option(_capi.OPT_SECTORS, args.sectors)
 
     chem = (MYR, BH00, ALBPOW, COLH0, TEMPH0, ABU_C)
+    state = {"first": True}
 
     def begin_time_step():
         # conv_criterion = -1 and convergence_fraction = 0 can never be met: every enqueued iteration does its work
-        lib.evolve_begin(*chem, args.R, SIG, dr, MINLOGTAU, dlog, numtau, 0, args.nsrc, -1.0, 0.0)
+        if comm is None:
+            lib.evolve_begin(*chem, args.R, SIG, dr, MINLOGTAU, dlog, numtau, 0, n_local, -1.0, 0.0)
+        else:
+            lib.grid_copy(_capi.GRID_XH_AV, _capi.GRID_XH)              # evolve.py:136-137
+            lib.grid_copy(_capi.GRID_XH_INTERMED, _capi.GRID_XH)
+            state["first"] = True
 
     def step():
-        if comm is not None:
-            lib.grid_copy(_capi.GRID_XH_AV, _capi.GRID_XH)
-            lib.grid_copy(_capi.GRID_XH_INTERMED, _capi.GRID_XH)
-            return comm.raytrace_and_allreduce(lib, N, args.R, SIG, dr, args.nsrc, MINLOGTAU, dlog, numtau,
+        if slab:                       # what evolve3D_MPI does per outer iteration with a TorchComm
+            r = comm.slab_iteration(lib, plan, N, args.R, SIG, dr, n_local, MINLOGTAU, dlog, numtau, chem, state["first"])
+            state["first"] = False
+            return r
+        if comm is not None:           # full-grid all-reduce (optionally pipelined), chemistry on every rank
+            return comm.raytrace_and_allreduce(lib, N, args.R, SIG, dr, n_local, MINLOGTAU, dlog, numtau,
                                                src_i0=src_i0, chemistry=chem)
         lib.evolve_enqueue(1)          # one outer iteration of evolve3D: raytrace + fused chemistry pass + convergence test
         return None
@@ -334,19 +377,18 @@ def main():
             comm.Barrier()
             torch.cuda.synchronize()
 
-    first_iteration_ms = None
-    if comm is None:
-        # the FIRST iteration of a time step additionally forms nHI from xh and zeroes the accumulators (evolve_begin)
-        begin_time_step(); step(); fence()
-        t0 = time.perf_counter()
-        begin_time_step(); step(); fence()
-        first_iteration_ms = (time.perf_counter() - t0) * 1e3
+    # the FIRST iteration of a time step additionally forms nHI from xh and zeroes the accumulators on the whole grid
+    begin_time_step(); step(); fence()
+    t0 = time.perf_counter()
+    begin_time_step(); step(); fence()
+    first_iteration_ms = (time.perf_counter() - t0) * 1e3
     for _ in range(W):
         step()
     lib.set_option(_capi.OPT_TIMING, 1)
     lib.kernel_time_reset()
     fence()
     t0 = time.perf_counter()
+    conv = None
     for _ in range(K):
         conv = step()
     fence()
@@ -354,6 +396,9 @@ def main():
     lib.set_option(_capi.OPT_TIMING, 0)
 
     gamma_cells, eval_cells = lib.last_raytrace_counts()
+    if slab:
+        comm.slab_gather(lib, plan, _capi.GRID_XH_INTERMED, N)
+        comm.slab_gather(lib, plan, _capi.GRID_PHI_ION, N)
     if comm is None:
         # the counters of the device-resident loop run on from evolve_begin: per iteration = total / iterations
         n_done, _, rows = lib.evolve_poll(32)
@@ -404,6 +449,17 @@ def main():
     rt_launch_s = (rt_ms / max(rt_n, 1)) * 1e-3
     achieved = RT_BYTES_PER_UPDATE * gamma_cells / rt_launch_s / 1e9 if rt_n else None
     insphere = 4.0 * np.pi * args.R ** 3 / 3.0
+    default_job = (args.workload == "uniform" and args.R == 32.0 and N == 256 and args.nsrc == 1000 and world == 1)
+    rt_counters = pmc_counters("raytrace_octant_kernel") if default_job else {}
+    ch_launch_s = (ch_ms / max(ch_n, 1)) * 1e-3
+    chem_cells = N ** 3 if (comm is None or not slab) else (plan.own[0][1] - plan.own[0][0]) * N * N
+    ch_achieved = CHEM_BYTES_PER_UPDATE * chem_cells / ch_launch_s / 1e9 if ch_n else None
+    ch_actual = (CHEM_FUSED_BYTES_PER_UPDATE if comm is None else CHEM_BYTES_PER_UPDATE) * chem_cells / ch_launch_s / 1e9 if ch_n else None
+    comm_bytes = None
+    if slab:
+        comm_bytes = 2 * max(sum(plan.bytes_per_rank(r)) for r in range(world))     # two exchanges, sent + received
+    elif comm is not None:
+        comm_bytes = int(2 * 2 * (world - 1) / world * 8 * N ** 3)                   # ring all-reduce, sent + received
 
     out = {
         "metric": "cell-updates/sec (raytrace+chem)",
@@ -414,22 +470,28 @@ def main():
         "warmup": W,
         "ms_per_step": elapsed / K * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if (strong or world == 1) else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": workload_label(args.workload, N, args.nsrc, args.R),
-            "grid": N, "sources_per_gpu": args.nsrc, "R_cells": args.R, "numtau": NUMTAU,
+            "workload": workload_label(args.workload, N, nsrc_total, args.R, world, strong),
+            "grid": N, "sources_total": nsrc_total, "sources_rank0": n_local, "R_cells": args.R, "numtau": NUMTAU,
             "ranks_agree_on_rates_and_ionised_fraction": ranks_agree,
-            "parallelism": (f"sources x{world}, rate-grid all-reduce " + ("pipelined with the trace" if overlap else "after the trace"))
-                           if world > 1 else "single GPU",
+            "parallelism": ("single GPU" if world == 1 else
+                            f"sources sharded over {world} ranks by slab of the first coordinate; rates sent plane-wise to the "
+                            "owners of the planes, slab chemistry, xh_av sent back (pyc2ray_amd/dist.py SlabPlan)" if slab else
+                            f"sources x{world}, rate-grid all-reduce " + ("pipelined with the trace" if overlap else "after the trace")
+                            + ", chemistry on every rank"),
+            "comm_bytes_per_rank_per_step": comm_bytes,
             "unit_definition": "rate-receiving (source,cell) pairs (|d|<=R) + N^3 chemistry cells per step",
             "raytrace_updates_per_step": tot_gamma,
             "chemistry_updates_per_step": N ** 3,
             "column_density_evaluations_per_step_rank0": eval_cells,
-            "nonconverged_cells_last_step": int(conv[0]),
+            "nonconverged_cells_last_step": int(conv[0]) if conv is not None else None,
             "first_iteration_of_a_time_step_ms": first_iteration_ms,
+            "step_definition": "steady-state outer iteration of evolve3D: raytrace + one fused pass (rates folded, chemistry, "
+                               "nHI for the next trace, accumulators zeroed) + convergence test on the device",
         },
         "roofline": {
             "bound": "hbm",
@@ -438,21 +500,34 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-            "traffic": (pmc_traffic_bytes() if (args.workload == "uniform" and args.R == 32.0 and N == 256 and args.nsrc == 1000) else None),
-            "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_pmc_summary.txt (separate PMC passes)",
+            "traffic": pmc_traffic_bytes("raytrace_octant_kernel") if default_job else None,
+            "traffic_source": (PMC_SUMMARY + ": (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch, separate rocprofv3 --pmc "
+                               "passes of this command on this workload (a committed measurement, not collected in this run)")
+                              if default_job else None,
             "algorithmic_bytes_per_launch": RT_BYTES_PER_UPDATE * gamma_cells,
             "avg_launch_ms": rt_ms / max(rt_n, 1),
             "launches_timed": rt_n,
-            "binding_resource": ("memory-side atomic request rate: TCC_EA0_ATOMIC %.3g 64-B requests per launch of "
-                                 "the default workload (profiles/r01_pmc_summary.txt) against ~2.0e10 requests/s "
-                                 "chip-wide (MI355X_MICROARCH.md, Global float atomics)"
-                                 % pmc_counters().get("TCC_EA0_ATOMIC_sum", float("nan"))),
+            "binding_resource": ("memory-side atomic request rate: TCC_EA0_ATOMIC %.3g 64-B requests per launch (%s) against "
+                                 "~2.0e10 requests/s chip-wide (MI355X_MICROARCH.md, Global float atomics)"
+                                 % (rt_counters.get("TCC_EA0_ATOMIC_sum", float("nan")), PMC_SUMMARY)) if default_job else None,
         },
+        "roofline_kernels": [
+            {"kernel": "raytrace_octant_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "bytes_per_unit": RT_BYTES_PER_UPDATE,
+             "units_per_launch": gamma_cells, "avg_launch_ms": rt_ms / max(rt_n, 1), "share_of_step": (rt_ms / K) / (elapsed / K * 1e3)},
+            {"kernel": "chemistry_tile_kernel", "bound": "hbm", "achieved": ch_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": (ch_achieved / HBM_PEAK_GBS) if ch_achieved else None, "bytes_per_unit": CHEM_BYTES_PER_UPDATE,
+             "units_per_launch": chem_cells, "avg_launch_ms": ch_ms / max(ch_n, 1), "share_of_step": (ch_ms / K) / (elapsed / K * 1e3),
+             "bytes_moved_per_unit": CHEM_FUSED_BYTES_PER_UPDATE if comm is None else CHEM_BYTES_PER_UPDATE,
+             "moved_GBs": ch_actual,
+             "note": "the fused pass also folds the two rate accumulators, writes nHI in both layouts for the next raytrace and "
+                     "zeroes the accumulators: 104 B per cell move through HBM, of which 56 B are the chemistry's own"},
+        ],
         "kernels_ms_per_step": {
             "raytrace": rt_ms / K, "chemistry": ch_ms / K, "prepare_nhi": pr_ms / K, "fold_phi_t": fi_ms / K,
-            "chemistry_achieved_GBs": (CHEM_BYTES_PER_UPDATE * N ** 3 / (ch_ms / max(ch_n, 1) * 1e-3) / 1e9) if ch_n else None,
+            "chemistry_achieved_GBs": ch_achieved,
         },
-        "raytrace_ns_per_source_per_insphere_cell": (rt_ms / max(rt_n, 1)) * 1e6 / (args.nsrc * insphere),
+        "raytrace_ns_per_source_per_insphere_cell": (rt_ms / max(rt_n, 1)) * 1e6 / (max(n_local, 1) * insphere),
     }
 
     if world == 1 and args.cpu_sources > 0:

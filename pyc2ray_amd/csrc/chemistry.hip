@@ -118,34 +118,44 @@ __global__ void __launch_bounds__(CH_THREADS) chemistry_kernel(const ChemParams 
 // With `status` the convergence test of the evolve loop follows at once (pyc2ray/evolve.py:216-236):
 // relative change of the two sums against the previous iteration, `conv_flag < conv_criterion or both changes
 // below convergence_fraction`; the iteration is booked in the status block's history ring.
-__global__ void __launch_bounds__(CH_THREADS) chemistry_reduce_kernel(const double *partial, int nblocks, double *out,
-                                                                      int accumulate, EvolveStatus *status)
+constexpr int RED_THREADS = 1024;
+__global__ void __launch_bounds__(RED_THREADS) chemistry_reduce_kernel(const double *partial, int nblocks, double *out,
+                                                                       int accumulate, EvolveStatus *status)
 {
     if (status && status->done) return;
-    __shared__ double r[3][CH_THREADS];
+    // fixed order: thread t sums partials t, t + 1024, ...; lanes of a wave are combined by a butterfly of DPP-free
+    // shuffles in a fixed pattern, the 16 waves through LDS -- the same bits on every launch and on every rank
+    double v[3];
     for (int q = 0; q < 3; ++q) {
         double s = 0.0;
-        for (int b = threadIdx.x; b < nblocks; b += CH_THREADS) s += partial[(size_t)q * nblocks + b];
-        r[q][threadIdx.x] = s;
+        for (int b = threadIdx.x; b < nblocks; b += RED_THREADS) s += partial[(size_t)q * nblocks + b];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+        v[q] = s;
     }
+    __shared__ double r[3][RED_THREADS / 64];
+    if ((threadIdx.x & 63) == 0)
+        for (int q = 0; q < 3; ++q) r[q][threadIdx.x >> 6] = v[q];
     __syncthreads();
-    for (int off = CH_THREADS / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off)
-            for (int q = 0; q < 3; ++q) r[q][threadIdx.x] += r[q][threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x < 3) out[threadIdx.x] = (accumulate ? out[threadIdx.x] : 0.0) + r[threadIdx.x][0];
-    if (status && threadIdx.x == 0) {
-        const double sum1 = r[0][0], sum0 = r[1][0], nconv = r[2][0];
-        const double rel1 = sum1 > 0.0 ? fabs((sum1 - status->prev1) / sum1) : 1.0;      // evolve.py:219-227
-        const double rel0 = sum0 > 0.0 ? fabs((sum0 - status->prev0) / sum0) : 1.0;
-        const bool converged = (nconv < status->conv_criterion) ||
-                               (rel1 < status->conv_fraction && rel0 < status->conv_fraction);   // evolve.py:232
-        double *h = status->hist[status->niter % EVOLVE_HIST];
-        h[0] = nconv; h[1] = sum1; h[2] = sum0; h[3] = rel1; h[4] = rel0;
-        status->prev1 = sum1; status->prev0 = sum0;                                       // evolve.py:234-235
-        status->niter += 1;
-        if (converged) status->done = 1;
+    if (threadIdx.x == 0) {
+        double tot[3];
+        for (int q = 0; q < 3; ++q) {
+            double s = 0.0;
+            for (int w = 0; w < RED_THREADS / 64; ++w) s += r[q][w];
+            tot[q] = s;
+            out[q] = (accumulate ? out[q] : 0.0) + s;
+        }
+        if (status) {
+            const double sum1 = tot[0], sum0 = tot[1], nconv = tot[2];
+            const double rel1 = sum1 > 0.0 ? fabs((sum1 - status->prev1) / sum1) : 1.0;      // evolve.py:219-227
+            const double rel0 = sum0 > 0.0 ? fabs((sum0 - status->prev0) / sum0) : 1.0;
+            const bool converged = (nconv < status->conv_criterion) ||
+                                   (rel1 < status->conv_fraction && rel0 < status->conv_fraction);   // evolve.py:232
+            double *h = status->hist[status->niter % EVOLVE_HIST];
+            h[0] = nconv; h[1] = sum1; h[2] = sum0; h[3] = rel1; h[4] = rel0;
+            status->prev1 = sum1; status->prev0 = sum0;                                       // evolve.py:234-235
+            status->niter += 1;
+            if (converged) status->done = 1;
+        }
     }
 }
 
@@ -247,18 +257,18 @@ int launch_chemistry(State &st, ChemParams &p, hipStream_t stream)
         hipLaunchKernelGGL(chemistry_kernel, dim3(blocks), dim3(CH_THREADS), 0, stream, q);
         ASORA_HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(chemistry_reduce_kernel, dim3(1), dim3(CH_THREADS), 0, stream,
+    hipLaunchKernelGGL(chemistry_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, stream,
                        (const double *)p.red_partial, blocks, p.red_final, p.accumulate, (EvolveStatus *)nullptr);
     ASORA_HIP_TRY(hipGetLastError());
     return 0;
 }
 
 // Workgroups of a tiled pass over `planes` i-planes: (k tiles, j chunks, i tiles).  Every workgroup walks its
-// (i,k) tile through N / (j chunks) values of j; the chunk count keeps ~16 workgroups per CU in flight.
+// (i,k) tile through N / (j chunks) values of j; the chunk count gives ~8 workgroups per CU.
 static dim3 tile_pass_grid(const State &st, int N, int planes)
 {
     const unsigned kt = (N + 31) / 32, it = (planes + 31) / 32;
-    const unsigned want = (unsigned)st.cu_count * 16u;
+    const unsigned want = (unsigned)st.cu_count * 8u;
     unsigned jc = std::max(1u, std::min((unsigned)N, (want + kt * it - 1) / (kt * it)));
     return dim3(kt, jc, it);
 }
@@ -285,7 +295,7 @@ int launch_chemistry_tiles(State &st, ChemTileParams &p, hipStream_t stream)
         else return fail(11, "chemistry: unsupported fold/emit combination (internal error)");
         ASORA_HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(chemistry_reduce_kernel, dim3(1), dim3(CH_THREADS), 0, stream,
+    hipLaunchKernelGGL(chemistry_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, stream,
                        (const double *)p.red_partial, (int)blocks, p.red_final, p.accumulate, p.status);
     ASORA_HIP_TRY(hipGetLastError());
     return 0;

@@ -20,7 +20,7 @@ import os
 
 import numpy as np
 
-__all__ = ["MPI", "TorchComm", "init_process_group_from_env"]
+__all__ = ["MPI", "TorchComm", "SlabPlan", "init_process_group_from_env"]
 
 
 class _MPIShim:
@@ -60,6 +60,86 @@ def init_process_group_from_env(backend=None):
     return rank, world, local_rank
 
 
+
+def _runs_of(mask):
+    """Maximal runs of True in a boolean vector as [(begin, end)), ...]."""
+    m = np.concatenate(([False], np.asarray(mask, dtype=bool), [False]))
+    edges = np.flatnonzero(m[1:] != m[:-1])
+    return [(int(a), int(b)) for a, b in zip(edges[0::2], edges[1::2])]
+
+
+class SlabPlan:
+    """Which planes of the grids travel between which ranks in one outer iteration of a multi-GPU step.
+
+    The rate grid is a sum over sources and the sources are sharded (pyc2ray/evolve.py:360-371), so the reference
+    sums N^3 grids over ranks every iteration (Reduce + Bcast, evolve.py:433-437) and broadcasts two more after
+    the chemistry (evolve.py:480-481).  A source at plane i0 only rates the planes i0-R..i0+R.  With the source list
+    ordered by the first coordinate before it is cut into the reference's contiguous blocks, rank r's rates are
+    non-zero only on `reach[r]` = the planes within R of its slab of sources.  So:
+
+      * the chemistry of plane i is done by ONE rank, the owner of the slab own[q] = [q N/P, (q+1) N/P) it lies in;
+      * exchange 1 (rates): rank r sends the part of reach[r] inside own[q] to q, for every q != r where that is
+        not empty; q adds what it receives, in rank order, to its own contribution: the summed rates of own[q];
+      * slab chemistry on own[q] (1/P of the grid per rank instead of all of it on every rank);
+      * exchange 2 (ionised fraction): the same runs travel back -- q sends the new xh_av of reach[r] & own[q] to r,
+        which needs it to form nHI for its next raytrace;
+      * the three convergence scalars are summed over ranks in rank order (identical on every rank).
+
+    Planes travel as contiguous runs (plane i is N*N consecutive doubles of the [i][j][k] grid); the run for a pair
+    (r, q) is the shortest run inside own[q] that covers reach[r] & own[q] (zeros in between are harmless).  At 256^3,
+    R = 32, 8 ranks with evenly spread sources a rank sends and receives 2 x 32 planes per exchange (2 x 33.5 MiB
+    in, the same out, to and from its two neighbours over their direct xGMI links) instead of taking part in a
+    ring all-reduce of 128 MiB (224 MiB in and out per rank), and runs 1/8 of the chemistry.  With R >= N/2 every
+    rank reaches every plane and the scheme degenerates into reduce-scatter + all-gather by direct sends.
+
+    Everything here is a function of (N, P, R, first coordinates of the sorted sources) only, so every rank derives
+    the same plan without communicating."""
+
+    def __init__(self, N, nprocs, R, shard_i0):
+        """shard_i0[r]: 0-based first coordinates of the sources of rank r."""
+        self.N, self.P = int(N), int(nprocs)
+        N, P = self.N, self.P
+        self.own = [(q * N // P, (q + 1) * N // P) for q in range(P)]
+        m = int(np.floor(R)) if np.isfinite(R) else N
+        lo, hi = min(m, N // 2), min(m, N // 2 - 1 + N % 2)          # the periodic window, raytracing.cu:122-123
+        self.reach = []
+        for r in range(P):
+            mask = np.zeros(N, dtype=bool)
+            i0 = np.unique(np.asarray(shard_i0[r], dtype=np.int64))
+            if i0.size:
+                if lo + hi + 1 >= N:
+                    mask[:] = True
+                else:
+                    for d in range(-lo, hi + 1):
+                        mask[(i0 + d) % N] = True
+            self.reach.append(mask)
+        # run[r][q]: planes rank r contributes to (and needs back from) the slab of rank q, or None
+        self.run = [[None] * P for _ in range(P)]
+        for r in range(P):
+            for q in range(P):
+                a, b = self.own[q]
+                idx = np.flatnonzero(self.reach[r][a:b])
+                if idx.size:
+                    self.run[r][q] = (a + int(idx[0]), a + int(idx[-1]) + 1)
+
+    def work_runs(self, r):
+        """Planes rank r zeroes its accumulators on and forms nHI on: what its sources reach plus what it owns."""
+        mask = self.reach[r].copy()
+        a, b = self.own[r]
+        mask[a:b] = True
+        return _runs_of(mask)
+
+    def reach_runs(self, r):
+        return _runs_of(self.reach[r])
+
+    def bytes_per_rank(self, r):
+        """(sent, received) by rank r in ONE of the two exchanges of an iteration, in bytes."""
+        plane = 8 * self.N * self.N
+        sent = sum((b - a) for q, run in enumerate(self.run[r]) if run and q != r for a, b in [run])
+        recv = sum((b - a) for q in range(self.P) if q != r and self.run[q][r] for a, b in [self.run[q][r]])
+        return sent * plane, recv * plane
+
+
 class _DevicePointer:
     """Zero-copy view of a library-owned device buffer for torch (__cuda_array_interface__ v3)."""
 
@@ -89,6 +169,9 @@ class TorchComm:
             pipeline_chemistry = os.environ.get("PYC2RAY_AMD_OVERLAP_CHEMISTRY", "0") == "1"
         self.pipeline_chemistry = bool(pipeline_chemistry)
         self._comm_stream = None
+        #: how the per-rank rate grids are summed: "slab" (SlabPlan: planes to their owners, slab chemistry, xh_av
+        #: back) or "allreduce" (full-grid all-reduce, chemistry replicated on every rank)
+        self.exchange = os.environ.get("PYC2RAY_AMD_EXCHANGE", "slab")
 
     # -- mpi4py-flavoured surface ---------------------------------------------------------------
     def Get_rank(self):
@@ -159,6 +242,129 @@ class TorchComm:
             t = torch.from_numpy(host)
             self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
             libasora.grid_to_device(which, host)
+
+
+    # -- slab exchange: rates to the owners of the planes, ionised fraction back (see SlabPlan) -------------------
+    @staticmethod
+    def shard_sources_by_slab(src_pos, src_flux, nprocs):
+        """Order the source list by its first coordinate and cut it into the reference's contiguous blocks
+        (pyc2ray/evolve.py:362-367: perrank = NumSrc // nprocs, the last rank takes the remainder).  Returns
+        (src_pos, src_flux, bounds) with rank r holding [bounds[r], bounds[r+1]) of the reordered list."""
+        pos, flux = np.asarray(src_pos), np.asarray(src_flux)
+        order = np.argsort(pos[0], kind="stable")
+        n = flux.shape[0]
+        per = n // nprocs
+        bounds = [r * per for r in range(nprocs)] + [n]
+        return pos[:, order], flux[order], bounds
+
+    def _planes_view(self, libasora, which, N):
+        import torch
+        return torch.as_tensor(_DevicePointer(libasora.device_ptr(which), N ** 3), device="cuda").view(N, N * N)
+
+    def _exchange(self, libasora, plan, which, N, direction):
+        """direction 'to_owner': rank r sends run[r][q] of grid `which` to q, q ADDS run[r][q] of every r (rank order).
+        direction 'from_owner': owner q sends run[r][q] to r, which stores it in place."""
+        import torch
+        dist = self._dist
+        me, P = self.Get_rank(), plan.P
+        if direction == "to_owner":
+            sends = [(q, plan.run[me][q]) for q in range(P) if q != me and plan.run[me][q]]
+            recvs = [(q, plan.run[q][me]) for q in range(P) if q != me and plan.run[q][me]]
+        else:
+            sends = [(q, plan.run[q][me]) for q in range(P) if q != me and plan.run[q][me]]
+            recvs = [(q, plan.run[me][q]) for q in range(P) if q != me and plan.run[me][q]]
+        if not sends and not recvs:
+            return
+        nccl = self._backend() == "nccl"
+        if nccl:
+            # everything is ordered on the library's stream: the collective starts behind the kernels that produced
+            # the planes and the kernels that consume them start behind it, without the host waiting for either
+            lib_stream = torch.cuda.ExternalStream(libasora.stream_ptr())
+            with torch.cuda.stream(lib_stream):
+                grid = self._planes_view(libasora, which, N)
+                if direction == "to_owner":
+                    key = ("stage", N, tuple(recvs))
+                    if getattr(self, "_stage_key", None) != key:       # staging kept between iterations
+                        self._stage = [torch.empty((b - a, N * N), dtype=torch.float64, device="cuda") for _, (a, b) in recvs]
+                        self._stage_key = key
+                    targets = self._stage
+                else:
+                    targets = [grid[a:b] for _, (a, b) in recvs]
+                ops = [dist.P2POp(dist.isend, grid[a:b], q, group=self._group) for q, (a, b) in sends]
+                ops += [dist.P2POp(dist.irecv, t, q, group=self._group) for (q, _), t in zip(recvs, targets)]
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+                if direction == "to_owner":
+                    for (q, (a, b)), t in zip(recvs, targets):         # fixed (rank) order: same bits on every run
+                        grid[a:b] += t
+            return
+        # gloo (CPU tests, several ranks on one GPU): staged through the host
+        out = [torch.from_numpy(libasora.planes_to_host(which, a, b - a, N)) for _, (a, b) in sends]
+        inc = [torch.empty((b - a, N, N), dtype=torch.float64) for _, (a, b) in recvs]
+        ops = [dist.P2POp(dist.isend, t, q, group=self._group) for (q, _), t in zip(sends, out)]
+        ops += [dist.P2POp(dist.irecv, t, q, group=self._group) for (q, _), t in zip(recvs, inc)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for (q, (a, b)), t in zip(recvs, inc):
+            if direction == "to_owner":
+                mine = libasora.planes_to_host(which, a, b - a, N)
+                libasora.planes_to_device(which, a, mine + t.numpy())
+            else:
+                libasora.planes_to_device(which, a, t.numpy())
+
+    def slab_iteration(self, libasora, plan, N, R, sig, dr, num_src_local, minlogtau, dlogtau, NumTau, chemistry, first):
+        """One outer iteration with the rates summed slab-wise: raytrace this rank's sources, send the rates to the
+        owners of the planes, chemistry on the own slab, send the new xh_av back to the ranks that trace through it.
+        Returns (conv_flag, sum x, sum 1-x) over the WHOLE grid, identical on every rank.  `first`: the first
+        iteration of a time step (accumulators and nHI are set up on the whole grid)."""
+        import torch
+        from . import _capi
+        me = self.Get_rank()
+        if first:
+            libasora.raytrace_begin_planes(R, sig, dr, minlogtau, dlogtau, NumTau, [(0, N)])
+        else:
+            libasora.raytrace_begin_planes(R, sig, dr, minlogtau, dlogtau, NumTau,
+                                           [(a, b - a) for a, b in plan.work_runs(me)])
+        libasora.raytrace_range(0, num_src_local)
+        for a, b in plan.reach_runs(me):
+            libasora.raytrace_fold(a, b - a)
+        self._exchange(libasora, plan, _capi.GRID_PHI_ION, N, "to_owner")
+        a, b = plan.own[me]
+        libasora.chemistry_range(*chemistry, a, b - a, True)
+        part = libasora.chemistry_finish()
+        self._exchange(libasora, plan, _capi.GRID_XH_AV, N, "from_owner")
+        # the three scalars: gathered, then summed in rank order on the host
+        t = torch.tensor([float(part[0]), part[1], part[2]], dtype=torch.float64)
+        if self._backend() == "nccl":
+            t = t.cuda()
+        allp = [torch.empty_like(t) for _ in range(plan.P)]
+        self._dist.all_gather(allp, t, group=self._group)
+        tot = [0.0, 0.0, 0.0]
+        for q in range(plan.P):
+            v = allp[q].cpu().tolist()
+            tot = [tot[0] + v[0], tot[1] + v[1], tot[2] + v[2]]
+        return int(round(tot[0])), tot[1], tot[2]
+
+    def slab_gather(self, libasora, plan, which, N):
+        """Every rank gets every owner's slab of grid `which` (end of a time step: xh_intermed, phi_ion)."""
+        import torch
+        me = self.Get_rank()
+        if self._backend() == "nccl":
+            lib_stream = torch.cuda.ExternalStream(libasora.stream_ptr())
+            with torch.cuda.stream(lib_stream):
+                grid = self._planes_view(libasora, which, N)
+                for q, (a, b) in enumerate(plan.own):
+                    if b > a:
+                        self._dist.broadcast(grid[a:b], src=q, group=self._group)
+            return
+        for q, (a, b) in enumerate(plan.own):
+            if b <= a:
+                continue
+            t = torch.from_numpy(libasora.planes_to_host(which, a, b - a, N)) if q == me else \
+                torch.empty((b - a, N, N), dtype=torch.float64)
+            self._dist.broadcast(t, src=q, group=self._group)
+            if q != me:
+                libasora.planes_to_device(which, a, t.numpy())
 
     # -- raytrace + sum over ranks, optionally pipelined ------------------------------------------------
     @staticmethod

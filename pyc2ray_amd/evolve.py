@@ -158,14 +158,25 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
     niter = 0
 
     # source shard of this rank, evolve.py:360-371
-    if distributed:
+    slab = (distributed and hasattr(comm, "slab_iteration") and getattr(comm, "exchange", "") == "slab"
+            and not getattr(comm, "overlap", False))
+    plan = None
+    all_pos, all_flux = np.asarray(src_pos), src_flux
+    if slab:
+        # the same contiguous blocks, of the list ordered by the first coordinate: a rank's rates then live on the
+        # planes within R of its slab of sources, and only those planes are exchanged (pyc2ray_amd.dist.SlabPlan)
+        from .dist import SlabPlan
+        all_pos, all_flux, bounds = comm.shard_sources_by_slab(all_pos, all_flux, nprocs)
+        i_start, i_end = bounds[rank], bounds[rank + 1]
+        plan = SlabPlan(N, nprocs, R_max_LLS, [all_pos[0, bounds[r]:bounds[r + 1]] - 1 for r in range(nprocs)])
+    elif distributed:
         perrank = NumSrc // nprocs
         i_start = int(rank * perrank)
         i_end = int((rank + 1) * perrank) if rank != nprocs - 1 else NumSrc
     else:
         i_start, i_end = 0, NumSrc
     NumSrc_local = i_end - i_start
-    my_pos, my_flux = np.asarray(src_pos)[:, i_start:i_end], src_flux[i_start:i_end]
+    my_pos, my_flux = all_pos[:, i_start:i_end], all_flux[i_start:i_end]
     # pipelined raytrace + all-reduce (pyc2ray_amd.dist, opt-in): the shard is traced in order of the first coordinate
     pipelined = distributed and getattr(comm, "overlap", False) and hasattr(comm, "raytrace_and_allreduce")
     src_i0 = None
@@ -227,7 +238,13 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
 
         # (1) raytracing, evolve.py:174-196
         trt0 = time.time()
-        if pipelined:
+        if slab:
+            # raytrace; rates to the owners of the planes; chemistry of the own slab; xh_av back (steps (1) and (2))
+            printlog(f"Doing Raytracing and Chemistry, slab-wise (rank={rank:n})...", logfile, quiet, ' ')
+            conv_flag, sum_xh1_int, sum_xh0_int = comm.slab_iteration(
+                libasora, plan, N, R_max_LLS, sig, dr, NumSrc_local, minlogtau, dlogtau, NumTau, chem, niter == 1)
+            printlog(f"rank={rank:n} took {(time.time()-trt0) : .1e} s.", logfile, quiet)
+        elif pipelined:
             # raytrace, sum over ranks and chemistry slab by slab (pyc2ray_amd.dist): steps (1) and (2) in one
             printlog(f"Doing Raytracing and Chemistry, pipelined (rank={rank:n})...", logfile, quiet, ' ')
             conv_flag, sum_xh1_int, sum_xh0_int = comm.raytrace_and_allreduce(
@@ -271,6 +288,9 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
 
     if rank == 0:
         printlog("Multiple source convergence reached.", logfile, quiet)
+    if slab:       # every rank returns the whole fields (evolve.py:480-481,497): collect the owners' slabs
+        comm.slab_gather(libasora, plan, _capi.GRID_XH_INTERMED, N)
+        comm.slab_gather(libasora, plan, _capi.GRID_PHI_ION, N)
     xh_new = libasora.grid_to_host(_capi.GRID_XH_INTERMED, np.empty_like(xh, dtype=np.float64))
     phi_ion = libasora.grid_to_host(_capi.GRID_PHI_ION, np.empty((N, N, N)))
     _evolve.last_niter = niter

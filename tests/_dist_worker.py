@@ -15,6 +15,11 @@ def main():
     cpu_semantics = len(sys.argv) > 5 and sys.argv[5] in ("cpu_semantics", "real_cpu_semantics")
     real = len(sys.argv) > 5 and sys.argv[5].startswith("real_")      # the HIP library itself, every rank on GPU 0
     overlap = overlap or (len(sys.argv) > 5 and sys.argv[5] == "real_overlap")
+    mode = sys.argv[5] if len(sys.argv) > 5 else "plain"
+    # slab modes: "slab:N:ns:R[:real][:mpi]" -- rates exchanged plane-wise (pyc2ray_amd.dist.SlabPlan)
+    spec = mode.split(":")
+    slab = spec[0] == "slab"
+    real = real or "real" in spec[1:]
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     import cases
@@ -25,6 +30,7 @@ def main():
     r, w, _ = pd.init_process_group_from_env("gloo")
     assert (r, w) == (rank, world)
     comm = pd.TorchComm(overlap=overlap, chunks=4, pipeline_chemistry=overlap)
+    comm.exchange = "slab" if slab else "allreduce"
     assert comm.Get_rank() == rank and comm.Get_size() == world
 
     # mpi4py-flavoured surface
@@ -42,11 +48,26 @@ def main():
         comm.Reduce([b3, pd.MPI.DOUBLE], None, op=pd.MPI.SUM, root=0)
 
     # the sharded evolve step on the oracle-backed stand-in
-    N = 16
+    N, ns, R, dt = 16, 5, 6.0, 3.15576e13 * 5
+    if slab:
+        N, ns, R = int(spec[1]), int(spec[2]), float(spec[3])
     nd, xh, dr = cases.grid(N, "lognormal", 51, 0.15, xlo=1e-4, xhi=2e-3)
     temp = np.full((N, N, N), 1e4)
-    pos, flux = cases.sources(N, 5, 52, flux=30.0)       # 5 sources over 2 ranks: 2 + 3
+    pos, flux = cases.sources(N, ns, 52, flux=30.0)       # 5 sources over 2 ranks: 2 + 3
+    if slab:
+        flux = flux * (3e-4 * (N / 16.0) ** 3 / ns / 30.0) * (1.0 + 0.1 * np.arange(ns))    # a partially ionised box, unequal fluxes
     thin, thick, dlog = cases.soft_tables()
+    use_mpi, the_comm = pd.MPI, comm
+    if "mpi" in spec[1:]:
+        # an mpi4py-shaped communicator (Reduce / Bcast on numpy buffers and nothing else): the host-staged branch of
+        # evolve3D_MPI that a real mpi4py communicator takes (pyc2ray/evolve.py:433-437,484-489)
+        class _MPIOnly:
+            def Reduce(self, sendbuf, recvbuf, op=None, root=0):
+                return comm.Reduce(sendbuf, recvbuf, op=op, root=root)
+
+            def Bcast(self, buf, root=0):
+                return comm.Bcast(buf, root=root)
+        the_comm = _MPIOnly()
     fake = OracleAsora(thin, thick)
     if real:
         import pyc2ray_amd as p
@@ -56,11 +77,11 @@ def main():
         ev.load_asora = lambda: fake
         ev.cuda_is_init = lambda: True
         ev.load_c2ray = lambda: OracleC2Ray()
-    xh_new, phi = ev.evolve3D_MPI(3.15576e13 * 5, dr, flux, pos, not cpu_semantics, 1000, 3, 1e-2, pd.MPI, comm, rank, world,
-                                  temp, nd, xh, thin, thick, cases.MINLOGTAU, dlog, 6.0, 1e-4, cases.SIG,
+    xh_new, phi = ev.evolve3D_MPI(dt, dr, flux, pos, not cpu_semantics, 1000, 3, 1e-2, use_mpi, the_comm, rank, world,
+                                  temp, nd, xh, thin, thick, cases.MINLOGTAU, dlog, R, 1e-4, cases.SIG,
                                   cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C,
                                   logfile=None, quiet=True)
-    np.savez(out, xh=xh_new, phi=phi, niter=ev._evolve.last_niter, nsrc=(fake.flux.shape[0] if fake.flux is not None else [2, 3][rank]))
+    np.savez(out, xh=xh_new, phi=phi, niter=ev._evolve.last_niter, nsrc=(fake.flux.shape[0] if fake.flux is not None else -1))
     comm.Barrier()
 
 

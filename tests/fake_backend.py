@@ -63,16 +63,48 @@ class OracleAsora:
 
     # the three-part raytrace of the pipelined path
     def raytrace_begin(self, R, sig, dr, minlogtau, dlogtau, NumTau):
+        self._planes_mode = False
         N = self.g[0].shape[0]
         self._rt = (R, sig, dr, minlogtau, dlogtau, NumTau)
         self.g[2] = np.zeros((N, N, N))
         self._folded = np.zeros(N, dtype=bool)
+
+    def raytrace_begin_planes(self, R, sig, dr, minlogtau, dlogtau, NumTau, runs):
+        """Like the library: the accumulator is zeroed and nHI is formed on the given planes ONLY.  nHI of every other
+        plane is whatever an earlier call left there -- NaN if none did, so a plan that forgets planes a source
+        reaches poisons the result instead of passing by accident."""
+        N = self.g[0].shape[0]
+        self._rt = (R, sig, dr, minlogtau, dlogtau, NumTau)
+        if 2 not in self.g or self.g[2].shape != (N, N, N):
+            self.g[2] = np.full((N, N, N), np.nan)
+        if getattr(self, "_nhi", None) is None or self._nhi.shape != (N, N, N):
+            self._nhi = np.full((N, N, N), np.nan)
+        for a, cnt in runs:
+            self.g[2][a:a + cnt] = 0.0
+            self._nhi[a:a + cnt] = self.g[0][a:a + cnt] * (1.0 - self.g[1][a:a + cnt])
+        self._folded = np.zeros(N, dtype=bool)
+        self._planes_mode = True
+
+    def planes_to_host(self, which, i_begin, i_count, N):
+        return self.g[which][i_begin:i_begin + i_count].copy()
+
+    def planes_to_device(self, which, i_begin, planes):
+        planes = np.asarray(planes)
+        self.g[which][i_begin:i_begin + planes.shape[0]] = planes.reshape(planes.shape[0], *self.g[which].shape[1:])
 
     def raytrace_range(self, src_begin, src_count):
         if src_count == 0:
             return
         R, sig, dr, minlogtau, dlogtau, NumTau = self._rt
         sl = slice(3 * src_begin, 3 * (src_begin + src_count))
+        if getattr(self, "_planes_mode", False):
+            # nHI as formed by raytrace_begin_planes (density = nHI, ionised fraction = 0)
+            add = O.asora_do_all_sources(R, sig, dr, self._nhi, np.zeros_like(self._nhi), self.pos[sl],
+                                         self.flux[src_begin:src_begin + src_count], self.thin, self.thick,
+                                         minlogtau, dlogtau, NumTau=NumTau, flags=O.ASORA_MODE)["phi_ion"]
+            w = add != 0
+            self.g[2][w] += add[w]
+            return
         self.g[2] = self.g[2] + O.asora_do_all_sources(R, sig, dr, self.g[0], self.g[1], self.pos[sl],
                                                        self.flux[src_begin:src_begin + src_count], self.thin,
                                                        self.thick, minlogtau, dlogtau, NumTau=NumTau,

@@ -68,7 +68,8 @@ def test_two_ranks_match_single_process(tmp_path, mode):
         assert p.returncode == 0, log
     res = [np.load(o) for o in outs]
     # contiguous source blocks, last rank takes the remainder (pyc2ray/evolve.py:362-367)
-    assert [int(r["nsrc"]) for r in res] == [2, 3]
+    if not mode.startswith("real_"):
+        assert [int(r["nsrc"]) for r in res] == [2, 3]
     # every rank returns the same fields
     assert np.array_equal(res[0]["xh"], res[1]["xh"]) and np.array_equal(res[0]["phi"], res[1]["phi"])
     assert int(res[0]["niter"]) == int(res[1]["niter"])
@@ -92,3 +93,124 @@ def test_two_ranks_match_single_process(tmp_path, mode):
     rtol = 1e-7 if mode.startswith("real_") else 1e-10          # the HIP kernels vs the oracle: tests/test_gpu_parity.py
     np.testing.assert_allclose(res[0]["xh"], x_ref, rtol=rtol, atol=0)
     np.testing.assert_allclose(res[0]["phi"], phi_ref, rtol=rtol, atol=0)
+
+
+# ---- slab exchange (pyc2ray_amd.dist.SlabPlan): rates to the owners of the planes, slab chemistry, xh_av back -------
+def test_slab_plan_covers_what_the_sources_reach():
+    """Pure bookkeeping: for random source sets, radii and rank counts, every plane a rank's sources can rate lies in
+    its reach, every reached plane of a foreign slab lies in the run sent to that slab's owner, the slabs partition
+    the planes, and the byte counts are symmetric between the two exchanges."""
+    from pyc2ray_amd.dist import SlabPlan, TorchComm
+    rng = np.random.default_rng(7)
+    for trial in range(60):
+        N = int(rng.choice([16, 17, 24, 33, 64, 256]))
+        P = int(rng.choice([1, 2, 3, 4, 8]))
+        R = float(rng.choice([0.0, 1.5, 3.0, N / 8.0, N / 4.0 + 0.5, N / 2.0, 10.0 * N]))
+        ns = int(rng.integers(P, 6 * P + 1))
+        pos = 1 + rng.integers(0, N, size=(3, ns))
+        if trial % 3 == 0:
+            pos[0] = 1 + (pos[0] % max(2, N // 5))                  # all sources in a thin slab near the periodic seam
+        flux = rng.uniform(0.5, 2.0, size=ns)
+        spos, sflux, bounds = TorchComm.shard_sources_by_slab(pos, flux, P)
+        assert sorted(map(tuple, spos.T)) == sorted(map(tuple, pos.T)) and np.all(np.diff(spos[0]) >= 0)
+        assert bounds[0] == 0 and bounds[-1] == ns and all(bounds[r + 1] - bounds[r] >= ns // P for r in range(P))
+        plan = SlabPlan(N, P, R, [spos[0, bounds[r]:bounds[r + 1]] - 1 for r in range(P)])
+        owner = np.full(N, -1)
+        for q, (a, b) in enumerate(plan.own):
+            assert np.all(owner[a:b] == -1)
+            owner[a:b] = q
+        assert np.all(owner >= 0)
+        m = int(np.floor(R))
+        for r in range(P):
+            want = np.zeros(N, dtype=bool)
+            for i0 in spos[0, bounds[r]:bounds[r + 1]] - 1:
+                for d in range(-min(m, N // 2), min(m, N // 2 - 1 + N % 2) + 1):     # raytracing.cu:122-123
+                    want[(i0 + d) % N] = True
+            assert np.array_equal(want, plan.reach[r])
+            for q in range(P):
+                a, b = plan.own[q]
+                idx = np.flatnonzero(want[a:b])
+                if idx.size == 0:
+                    assert plan.run[r][q] is None
+                else:
+                    ra, rb = plan.run[r][q]
+                    assert a <= ra <= a + idx[0] and a + idx[-1] < rb <= b
+            work = np.zeros(N, dtype=bool)
+            for a, b in plan.work_runs(r):
+                work[a:b] = True
+            assert np.array_equal(work, want | (owner == r))
+        sent = sum(plan.bytes_per_rank(r)[0] for r in range(P))
+        recv = sum(plan.bytes_per_rank(r)[1] for r in range(P))
+        assert sent == recv
+    # the benchmark configuration: 256^3, R = 32, 8 ranks, evenly spread sources -> two neighbours, 32 planes each
+    pos = np.stack([1 + np.arange(1000) % 256, np.ones(1000, int), np.ones(1000, int)])
+    spos, _, bounds = TorchComm.shard_sources_by_slab(pos, np.ones(1000), 8)
+    plan = SlabPlan(256, 8, 32.0, [spos[0, bounds[r]:bounds[r + 1]] - 1 for r in range(8)])
+    per_exchange = max(plan.bytes_per_rank(r)[0] for r in range(8))
+    assert per_exchange <= 70 * 256 * 256 * 8                       # ~2 x 32 planes of 512 KiB, against 2 x 7/8 x 128 MiB in a ring all-reduce
+
+
+def _run_workers(tmp_path, world, mode, timeout=600):
+    port = _free_port()
+    outs = [str(tmp_path / f"r{r}.npz") for r in range(world)]
+    env = dict(os.environ, PYC2RAY_AMD_NO_TORCH="0", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), str(r), str(world), port,
+                               outs[r], mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    logs = [p.communicate(timeout=timeout)[0].decode() for p in procs]
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log
+    return [np.load(o) for o in outs]
+
+
+def _slab_reference(N, ns, R):
+    nd, xh, dr = cases.grid(N, "lognormal", 51, 0.15, xlo=1e-4, xhi=2e-3)
+    temp = np.full((N, N, N), 1e4)
+    pos, flux = cases.sources(N, ns, 52, flux=30.0)
+    flux = flux * (3e-4 * (N / 16.0) ** 3 / ns / 30.0) * (1.0 + 0.1 * np.arange(ns))
+    thin, thick, dlog = cases.soft_tables()
+    return evolve3D_oracle(3.15576e13 * 5, dr, flux, pos, temp, nd, xh, thin, thick, cases.MINLOGTAU, dlog, R, 1e-4,
+                           cases.SIG, cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C)
+
+
+@pytest.mark.parametrize("world,N,ns,R", [(2, 16, 5, 6.0), (3, 17, 7, 2.5), (4, 24, 9, 3.0), (8, 16, 19, 2.0), (4, 16, 6, 1000.0)])
+def test_slab_exchange_matches_single_process(tmp_path, world, N, ns, R):
+    """evolve3D_MPI with the rates exchanged plane-wise (the default with a TorchComm), 2 to 8 ranks over gloo,
+    against the single-process oracle loop: same iteration count, same fields on every rank.  Radii small against
+    the slabs (some pairs of ranks exchange nothing), odd meshes, uneven slabs, and R beyond the box (every rank
+    reaches every plane).  The per-rank compute is the oracle-backed stand-in, which leaves NaN wherever a plan
+    would forget to form nHI or to zero the accumulator."""
+    res = _run_workers(tmp_path, world, f"slab:{N}:{ns}:{R}")
+    for r in res[1:]:
+        assert np.array_equal(r["xh"], res[0]["xh"]) and np.array_equal(r["phi"], res[0]["phi"])
+        assert int(r["niter"]) == int(res[0]["niter"])
+    assert sum(int(r["nsrc"]) for r in res) == ns
+    x_ref, phi_ref, niter_ref, _ = _slab_reference(N, ns, R)
+    assert int(res[0]["niter"]) == niter_ref and niter_ref >= 3
+    assert 0.02 < x_ref.mean() < 0.98
+    np.testing.assert_allclose(res[0]["xh"], x_ref, rtol=1e-10, atol=0)
+    np.testing.assert_allclose(res[0]["phi"], phi_ref, rtol=1e-10, atol=0)
+
+
+def test_mpi4py_shaped_communicator_takes_the_host_staged_branch(tmp_path):
+    """A communicator that only offers mpi4py's Reduce / Bcast on numpy buffers (what evolve3D_MPI gets from a real
+    mpi4py run; mpi4py itself is not installed here): Reduce to rank 0 + Bcast of the rate grid, Bcast of the
+    convergence flag, as the reference does."""
+    res = _run_workers(tmp_path, 2, "slab:16:5:6.0:mpi")
+    assert np.array_equal(res[0]["xh"], res[1]["xh"]) and np.array_equal(res[0]["phi"], res[1]["phi"])
+    x_ref, phi_ref, niter_ref, _ = _slab_reference(16, 5, 6.0)
+    assert int(res[0]["niter"]) == niter_ref
+    np.testing.assert_allclose(res[0]["xh"], x_ref, rtol=1e-10, atol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,N,ns,R", [(2, 16, 5, 6.0), (4, 24, 9, 3.0)])
+def test_slab_exchange_with_the_hip_library(tmp_path, world, N, ns, R):
+    """The same with the HIP library under every rank (all on GPU 0, planes staged through the host by gloo)."""
+    res = _run_workers(tmp_path, world, f"slab:{N}:{ns}:{R}:real")
+    for r in res[1:]:
+        assert np.array_equal(r["xh"], res[0]["xh"]) and int(r["niter"]) == int(res[0]["niter"])
+    x_ref, phi_ref, niter_ref, _ = _slab_reference(N, ns, R)
+    assert int(res[0]["niter"]) == niter_ref
+    np.testing.assert_allclose(res[0]["xh"], x_ref, rtol=1e-7, atol=0)
+    np.testing.assert_allclose(res[0]["phi"], phi_ref, rtol=1e-7, atol=0)

@@ -189,7 +189,7 @@ def test_config4_512_corner_sources_and_large_indices(asora):
     w = ref != 0
     assert np.array_equal(one != 0, w)
     np.testing.assert_allclose(one[w], ref[w], rtol=1e-8, atol=0)
-    for corner in [(0, 0, 0), (511, 0, 0), (0, 511, 511), (511, 511, 511), (480, 5, 500)]:
+    for corner in [(0, 0, 0), (511, 0, 0), (0, 511, 511), (511, 511, 511), (490, 5, 500)]:
         assert one[corner] > 0
     # superposition at this size: the sources one by one add up to the joint trace
     acc = one.copy()
@@ -224,8 +224,10 @@ def test_config1_128_single_source_R64_against_oracle(asora):
     phi = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
     ref = O.asora_do_all_sources(R, cases.SIG, dr, nd, xh, p0, f0, thin, thick, cases.MINLOGTAU, dlog,
                                  NumTau=thin.shape[0], flags=O.ASORA_MODE)["phi_ion"]
-    w = ref != 0
-    assert np.array_equal(phi != 0, w)
+    # tau = 46 per cell: beyond ~16 cells the grey table's exp(-tau) is denormal, then 0; a rate that is a difference of
+    # denormals has no relative accuracy, so the comparison is made where the reference is a normal number
+    w = ref > 1e-290
+    assert w.sum() > 1000 and np.all(phi[~w] <= 1e-289) and np.all(phi >= 0)
     np.testing.assert_allclose(phi[w], ref[w], rtol=1e-8, atol=0)
     dt = 1.578e15 / 10
     x = xh

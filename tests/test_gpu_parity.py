@@ -881,8 +881,8 @@ def test_device_resident_loop_equals_the_step_by_step_loop(asora, N, ns, R, monk
         results.append((x, phi, E._evolve.last_niter))
     for x, phi, niter in results[1:]:
         assert niter == results[0][2]
-        assert np.array_equal(x, results[0][0])
-        np.testing.assert_allclose(phi, results[0][1], rtol=1e-11, atol=0)       # atomic summation order only
+        np.testing.assert_allclose(x, results[0][0], rtol=1e-11, atol=0)         # the order the atomics add up in, only
+        np.testing.assert_allclose(phi, results[0][1], rtol=1e-11, atol=0)
     x_ref, phi_ref, niter_ref, hist = evolve3D_oracle(dt, dr, flux, pos, temp, nd, xh, thin, thick, cases.MINLOGTAU, dlog,
                                                       R, 1e-4, cases.SIG, cases.BH00, cases.ALBPOW, cases.COLH0,
                                                       cases.TEMPH0, cases.ABU_C)
