@@ -264,11 +264,11 @@ int launch_chemistry(State &st, ChemParams &p, hipStream_t stream)
 }
 
 // Workgroups of a tiled pass over `planes` i-planes: (k tiles, j chunks, i tiles).  Every workgroup walks its
-// (i,k) tile through N / (j chunks) values of j; the chunk count gives ~8 workgroups per CU.
+// (i,k) tile through N / (j chunks) values of j; the chunk count gives ~16 workgroups per CU (8 measured 10 % slower).
 static dim3 tile_pass_grid(const State &st, int N, int planes)
 {
     const unsigned kt = (N + 31) / 32, it = (planes + 31) / 32;
-    const unsigned want = (unsigned)st.cu_count * 8u;
+    const unsigned want = (unsigned)st.cu_count * 16u;
     unsigned jc = std::max(1u, std::min((unsigned)N, (want + kt * it - 1) / (kt * it)));
     return dim3(kt, jc, it);
 }

@@ -42,6 +42,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace asora {
@@ -148,6 +149,13 @@ __device__ __forceinline__ double photo_rate_per_atom(double flux, double cd_in,
 // only waits for the atomic of the step before.  Costs 3 VGPRs.
 #ifndef ASORA_LATE_ATOMIC
 #define ASORA_LATE_ATOMIC 1
+#endif
+
+// 1: the table lookups of a step are CONSUMED in the next step (their rate is formed there, right before that step's
+// own lookups are issued, and added behind them): a whole step of arithmetic hides their latency.  Pays where the
+// kernel is latency-bound (small radii: few waves per SIMD, short shells); costs ~19 VGPRs.
+#ifndef ASORA_LATE_LOOKUP
+#define ASORA_LATE_LOOKUP 0
 #endif
 
 // waves per SIMD the register allocation must leave room for (2nd argument of __launch_bounds__)
@@ -266,6 +274,13 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
     bool late_ok = false;              // a rate computed in the previous step, not yet added (ASORA_LATE_ATOMIC)
     double late_v = 0.0, late_h = 0.0;
     double *late_dst = p.phi;
+#if ASORA_LATE_LOOKUP
+    Lookup pend_A, pend_B;             // lookups issued in the previous step, consumed in this one
+    pend_A.t = pend_B.t = pend_A.h = pend_B.h = double2{0.0, 0.0};
+    pend_A.residual = pend_B.residual = 0.0;
+    bool pend_thick = false;
+    double pend_pref = 0.0, pend_dtau = 0.0;
+#endif
 
     auto step = [&](unsigned e_pf, const uint4 &cur_A, const uint4 &cur_B, const double cur_nhi, const unsigned cur_idx,
                     const uint4 &nxt_A, double &nxt_nhi, unsigned &nxt_idx, uint4 &pf_A, uint4 &pf_B) {
@@ -356,9 +371,29 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
             const double tau_thin = p.fortran_consts ? tau_in : tau_out;                 // photorates.f90:121 / rates.cu:37
             // one code path for both kinds of cell: per-lane table offset and arguments
             const double2 *tab = p.tables + (thick ? 0 : p.table_len);
+#if ASORA_LATE_LOOKUP
+            {   // the previous step's lookups have had a whole step to arrive: form its rate now, issue this step's
+                // lookups, then add the rate behind them
+                const double ta = lookup_value(pend_A), tb = lookup_value(pend_B);
+                const double v_prev = pend_thick ? pend_pref * (ta - tb) : pend_pref * pend_dtau * ta;
+                double h_prev = 0.0;
+                if (HEAT) {
+                    const double ha = lookup_heat(pend_A), hb = lookup_heat(pend_B);
+                    h_prev = pend_thick ? pend_pref * (ha - hb) : pend_pref * pend_dtau * ha;
+                }
+                const Lookup A2 = lookup_issue<HEAT>(tab, thick ? tau_in : tau_thin, p, logtab);
+                const Lookup B2 = lookup_issue<HEAT>(tab, thick ? tau_out : tau_thin, p, logtab);
+                if (late_ok) {
+                    ASORA_RATE_ATOMIC(late_dst, v_prev);
+                    if (HEAT) unsafeAtomicAdd(p.heat + (late_dst - p.phi), h_prev);
+                }
+                pend_A = A2; pend_B = B2; pend_thick = thick; pend_pref = pref; pend_dtau = dtau;
+                late_dst = dst;
+                late_ok = rated;
+            }
+#elif ASORA_LATE_ATOMIC
             const Lookup A = lookup_issue<HEAT>(tab, thick ? tau_in : tau_thin, p, logtab);
             const Lookup B = lookup_issue<HEAT>(tab, thick ? tau_out : tau_thin, p, logtab);
-#if ASORA_LATE_ATOMIC
             if (late_ok) {       // the previous step's rate, behind this step's lookups in the memory pipeline
                 ASORA_RATE_ATOMIC(late_dst, late_v);
                 if (HEAT) unsafeAtomicAdd(p.heat + (late_dst - p.phi), late_h);
@@ -374,6 +409,8 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
                 late_ok = rated;
             }
 #else
+            const Lookup A = lookup_issue<HEAT>(tab, thick ? tau_in : tau_thin, p, logtab);
+            const Lookup B = lookup_issue<HEAT>(tab, thick ? tau_out : tau_thin, p, logtab);
             if (rated) {
                 const double ta = lookup_value(A), tb = lookup_value(B);
                 ASORA_RATE_ATOMIC(dst, thick ? pref * (ta - tb) : pref * dtau * ta);
@@ -400,10 +437,21 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
         step(e + 3 * RT_THREADS, A1, B1, nhi1, idx1, A2, nhi2, idx2, A0, B0);
         step(e + 4 * RT_THREADS, A2, B2, nhi2, idx2, A0, nhi0, idx0, A1, B1);
     }
+#if ASORA_LATE_LOOKUP
+    if (late_ok) {
+        const double ta = lookup_value(pend_A), tb = lookup_value(pend_B);
+        ASORA_RATE_ATOMIC(late_dst, pend_thick ? pend_pref * (ta - tb) : pend_pref * pend_dtau * ta);
+        if (HEAT) {
+            const double ha = lookup_heat(pend_A), hb = lookup_heat(pend_B);
+            unsafeAtomicAdd(p.heat + (late_dst - p.phi), pend_thick ? pend_pref * (ha - hb) : pend_pref * pend_dtau * ha);
+        }
+    }
+#else
     if (late_ok) {
         ASORA_RATE_ATOMIC(late_dst, late_v);
         if (HEAT) unsafeAtomicAdd(p.heat + (late_dst - p.phi), late_h);
     }
+#endif
 
     // work accounting: one atomic per wave
     for (int o = 32; o > 0; o >>= 1) {
@@ -699,9 +747,20 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
     uint32_t max_cells = 1;
     const uint32_t MARK = 0xffffffffu;
     bool dr_matters = false;
+    {   // the tables of the distinct units are independent: one host thread each (a whole-box trace tabulates N^3
+        // cells per unit set -- ~1 s on one core at 320^3)
+        std::vector<std::thread> workers;
+        const double R_all = p.R, dr_all = p.dr;
+        for (int u = 0; u < units; ++u) {
+            if (owner[u] != u) continue;
+            workers.emplace_back([&hg, &spec, u, R_all, dr_all, q_max, threads]() {
+                build_unit_geometry(hg[u], spec[u], R_all, dr_all, q_max, MARK, threads);
+            });
+        }
+        for (auto &w : workers) w.join();
+    }
     for (int u = 0; u < units; ++u) {
         if (owner[u] != u) continue;
-        build_unit_geometry(hg[u], spec[u], p.R, p.dr, q_max, MARK, threads);
         if (hg[u].inconsistent)
             return fail(11, "raytrace geometry: a cell of a unit reads a corner outside the unit (internal error)");
         Smax = std::max(Smax, hg[u].S);
