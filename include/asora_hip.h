@@ -249,7 +249,10 @@ enum {
     /* c2ray_do_all_sources only.  0 (default): every source's rates use the flux of the LAST source, as the
      *    reference does (src/c2ray/raytracing.f90:500,503 pass normflux(NumSrc));  1: each source its own flux. */
     ASORA_OPT_C2RAY_OWN_FLUX = 7,
-    ASORA_OPT_COUNT = 8
+    /* 1: never take the uniform-temperature form of the tiled chemistry pass (diagnostics / tests: both forms give
+     *    bit-identical results).  0 (default): a temperature grid found uniform when uploaded is not read again. */
+    ASORA_OPT_NO_UNIFORM_T = 8,
+    ASORA_OPT_COUNT = 9
 };
 int asora_set_option(int option, int value);
 int asora_get_option(int option);

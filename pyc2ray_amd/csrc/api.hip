@@ -90,6 +90,29 @@ static int ensure_runtime()
     return 0;
 }
 
+// One temperature for the whole grid?  Probed once per upload of TEMP and set of chemistry constants (one pass over the
+// grid + a 40-byte read-back); the tiled chemistry pass then needs neither the temperature loads nor pow/sqrt/exp.
+static int ensure_temp_probe(double bh00, double albpow, double colh0, double temph0)
+{
+    State &st = g_state;
+    const double c[4] = {bh00, albpow, colh0, temph0};
+    if (st.temp_probe_valid && std::memcmp(c, st.temp_consts, sizeof c) == 0) return 0;
+    if (!st.temp_probe_dev) ASORA_HIP_TRY(hipMalloc(&st.temp_probe_dev, sizeof(double) * 5));
+    if (int rc = launch_temp_probe(st, st.grid[ASORA_GRID_TEMP], st.ncell, bh00, albpow, colh0, temph0, st.temp_probe_dev)) return rc;
+    ASORA_HIP_TRY(hipMemcpyAsync(st.temp_probe, st.temp_probe_dev, sizeof(double) * 5, hipMemcpyDeviceToHost, st.stream));
+    ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    std::memcpy(st.temp_consts, c, sizeof c);
+    st.temp_probe_valid = true;
+    return 0;
+}
+static void set_uniform_temperature(ChemTileParams &p)
+{
+    State &st = g_state;
+    p.uniform = (st.temp_probe_valid && st.temp_probe[0] != 0.0 && !st.opt[ASORA_OPT_NO_UNIFORM_T]) ? 1 : 0;
+    p.uniform_T = st.temp_probe[1]; p.uniform_brech0 = st.temp_probe[2]; p.uniform_acolh0 = st.temp_probe[3];
+    p.uniform_t_ok = st.temp_probe[4] != 0.0 ? 1 : 0;
+}
+
 // per-workgroup partial sums of the chemistry passes: room for `entries` doubles
 static int ensure_red_capacity(size_t entries)
 {
@@ -109,6 +132,7 @@ static int release_all()
     for (int g = 0; g < ASORA_GRID_COUNT; ++g) { drop(st.grid[g]); st.grid_valid[g] = false; }
     drop(st.nhi); drop(st.staging); drop(st.acc);
     st.ev_open = false;
+    st.temp_probe_valid = false;
     st.nhi_t = st.phi_t = st.heat_t = nullptr;    // second halves of nhi / phi_ion / phi_heat
     st.have_heat_tables = false;
     drop(st.tables); st.table_len = 0;
@@ -483,6 +507,7 @@ int asora_grid_to_device(int which, const double *host, int N, char order)
         return fail(3, "grid_to_device: order must be 'C' or 'F'");
     ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
     st.grid_valid[which] = true;
+    if (which == ASORA_GRID_TEMP) st.temp_probe_valid = false;
     return 0;
 }
 
@@ -518,6 +543,7 @@ int asora_grid_copy(int dst, int src)
     ASORA_HIP_TRY(hipMemcpyAsync(st.grid[dst], st.grid[src], st.ncell * sizeof(double), hipMemcpyDeviceToDevice,
                                  st.stream));
     st.grid_valid[dst] = true;
+    if (dst == ASORA_GRID_TEMP) st.temp_probe_valid = false;
     return 0;
 }
 
@@ -735,6 +761,8 @@ int asora_chemistry_range(double dt, double bh00, double albpow, double colh0, d
     p.xh_av = st.grid[ASORA_GRID_XH_AV]; p.xh_intermed = st.grid[ASORA_GRID_XH_INTERMED];
     p.red_partial = st.red_partial; p.red_final = st.red_final;
     p.accumulate = first ? 0 : 1;
+    if (int rc = ensure_temp_probe(bh00, albpow, colh0, temph0)) return rc;
+    set_uniform_temperature(p);
     return launch_chemistry_tiles(st, p, st.stream);
 }
 
@@ -943,6 +971,7 @@ int asora_evolve_begin(double dt, double bh00, double albpow, double colh0, doub
         return fail(4, "evolve_begin: source range outside the " + std::to_string(st.num_src) + " uploaded sources");
     if (st.opt[ASORA_OPT_HEATING]) return fail(4, "evolve_begin: the fused loop carries no heating rates (use raytrace_device)");
 
+    if (int rc = ensure_temp_probe(bh00, albpow, colh0, temph0)) return rc;
     const size_t bytes = st.ncell * sizeof(double);
     if (!st.acc) ASORA_HIP_TRY(hipMalloc(&st.acc, 2 * bytes));
     if (!st.ev_status) {
@@ -999,6 +1028,7 @@ int asora_evolve_enqueue(int iterations)
         c.red_partial = st.red_partial; c.red_final = st.red_final;
         c.status = st.ev_status;
         c.fold = true; c.emit = true;
+        set_uniform_temperature(c);
         if (int rc = launch_chemistry_tiles(st, c, st.stream)) return rc;
         st.ev_first = false;
     }

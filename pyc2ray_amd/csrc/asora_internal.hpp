@@ -138,6 +138,11 @@ struct State {
     EvolveStatus *ev_status = nullptr;      // device
     EvolveStatus *ev_host = nullptr;        // pinned
     bool ev_open = false, ev_first = true;
+    // temperature probe of the TEMP grid: valid for the upload `temp_generation` and the constants in temp_consts
+    double *temp_probe_dev = nullptr;       // [5] device
+    double temp_probe[5] = {0, 0, 0, 0, 0}; // host copy: uniform?, T, brech0, acolh0, t_ok
+    bool temp_probe_valid = false;
+    double temp_consts[4] = {0, 0, 0, 0};
     int ev_reported = 0;                    // iterations already handed to the caller by asora_evolve_poll
     double ev_chem[6] = {0, 0, 0, 0, 0, 0}; // dt, bh00, albpow, colh0, temph0, abu_c
     int ev_src_begin = 0, ev_src_count = 0;
@@ -147,7 +152,7 @@ struct State {
     struct PendingTimer { int which; hipEvent_t e0, e1; };
     std::vector<PendingTimer> pending_timers;     // recorded, not yet resolved
     std::vector<hipEvent_t> free_events;
-    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 0};
+    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 0, 0};
     double k_ms[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
     long k_n[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
 };
@@ -252,7 +257,12 @@ struct ChemTileParams {
     int accumulate = 0;
     EvolveStatus *status = nullptr;
     bool fold = false, emit = false;
+    // the grid has one temperature (launch_temp_probe): its factors, evaluated on the device, travel with the parameters
+    int uniform = 0, uniform_t_ok = 0;
+    double uniform_T = 0, uniform_brech0 = 0, uniform_acolh0 = 0;
 };
+int launch_temp_probe(State &st, const double *temp, size_t n, double bh00, double albpow, double colh0, double temph0,
+                      double *out_dev);
 int launch_chemistry_tiles(State &st, ChemTileParams &p, hipStream_t stream);
 size_t chemistry_tile_blocks(const State &st, int N, int planes);
 int launch_prepare_nhi_from(State &st, const double *xh_av, bool need_transposed);

@@ -18,9 +18,28 @@ namespace asora {
 
 constexpr int CH_THREADS = 256;
 
+// doric's temperature-only factors (chemistry.f90:257-262) and the temperature term of do_chemistry's exit test
+// (chemistry.f90:185-186).  The path is isothermal (the temperature never changes inside do_chemistry) and most
+// grids are uniform in T, so a lane keeps the factors of the last temperature it saw: pow, sqrt and exp -- half of the
+// pass's instructions -- are then evaluated once per lane instead of once per cell, with bit-identical results.
+struct TempFactors {
+    double T = -1.0;           // temperature the factors below belong to (no cell has T = -1: first use always computes)
+    double brech0 = 0.0, acolh0 = 0.0;
+    bool t_ok = false;
+};
+__device__ __forceinline__ void temperature_factors(const ChemParams &p, double T, TempFactors &f)
+{
+    if (T == f.T) return;
+    f.T = T;
+    f.brech0 = 1.0 * p.bh00 * pow(T / 1e4, p.albpow);
+    f.acolh0 = p.colh0 * sqrt(T) * exp(-p.temph0 / T);
+    // |(T - T)/T| < min_frac_change: 0 unless T is 0, infinite or NaN (then NaN: the test fails, as in the reference)
+    f.t_ok = fabs((T - T) / T) < (double)1.0e-3f;
+}
+
 // One cell: do_chemistry + the convergence test of evolve0D_global.
-__device__ __forceinline__ void chemistry_cell(const ChemParams &p, double n, double T, double x0, double gamma,
-                                               double &xav, double &xint, unsigned int &nconv)
+__device__ __forceinline__ void chemistry_cell(const ChemParams &p, double n, double x0, double gamma,
+                                               double &xav, double &xint, unsigned int &nconv, const TempFactors &tf)
 {
     // single-precision parameters promoted to double, chemistry.f90:9-10
     const double min_frac_change = (double)1.0e-3f;
@@ -30,11 +49,8 @@ __device__ __forceinline__ void chemistry_cell(const ChemParams &p, double n, do
     const double xav_start = xav;                                    // chemistry.f90:91,99
     const double yh_av = 1.0 - xav;                                  // chemistry.f90:93
 
-    // doric's temperature-only factors, chemistry.f90:257-262 (isothermal: same every iteration)
-    const double brech0 = 1.0 * p.bh00 * pow(T / 1e4, p.albpow);
-    const double acolh0 = p.colh0 * sqrt(T) * exp(-p.temph0 / T);
-    // temperature convergence term of do_chemistry, chemistry.f90:185-186 (0 unless T is 0/NaN)
-    const bool t_ok = fabs((T - T) / T) < min_frac_change;
+    const double brech0 = tf.brech0, acolh0 = tf.acolh0;
+    const bool t_ok = tf.t_ok;
 
     int nit = 0;
     for (;;) {                                                       // do_chemistry, chemistry.f90:146-203
@@ -66,6 +82,7 @@ __global__ void __launch_bounds__(CH_THREADS) chemistry_kernel(const ChemParams 
 {
     double sum1 = 0.0, sum0 = 0.0;
     unsigned int nconv = 0;
+    TempFactors tf;
 
     const size_t npair = p.ncell / 2;
     const size_t stride = (size_t)gridDim.x * CH_THREADS;
@@ -78,8 +95,10 @@ __global__ void __launch_bounds__(CH_THREADS) chemistry_kernel(const ChemParams 
     for (size_t q = (size_t)blockIdx.x * CH_THREADS + threadIdx.x; q < npair; q += stride) {
         const double2 n = nd2[q], T = tp2[q], x0 = x02[q], g = ph2[q];
         double2 xav = xa2[q], xint;
-        chemistry_cell(p, n.x, T.x, x0.x, g.x, xav.x, xint.x, nconv);
-        chemistry_cell(p, n.y, T.y, x0.y, g.y, xav.y, xint.y, nconv);
+        temperature_factors(p, T.x, tf);
+        chemistry_cell(p, n.x, x0.x, g.x, xav.x, xint.x, nconv, tf);
+        temperature_factors(p, T.y, tf);
+        chemistry_cell(p, n.y, x0.y, g.y, xav.y, xint.y, nconv, tf);
         xi2[q] = xint;                                               // chemistry.f90:107-108
         xa2[q] = xav;
         sum1 += xint.x; sum0 += 1.0 - xint.x;                        // evolve.py:216-217
@@ -88,7 +107,8 @@ __global__ void __launch_bounds__(CH_THREADS) chemistry_kernel(const ChemParams 
     if ((p.ncell & 1) && blockIdx.x == 0 && threadIdx.x == 0) {      // odd cell count: the last cell
         const size_t idx = p.ncell - 1;
         double xav = p.xh_av[idx], xint;
-        chemistry_cell(p, p.ndens[idx], p.temp[idx], p.xh[idx], p.phi[idx], xav, xint, nconv);
+        temperature_factors(p, p.temp[idx], tf);
+        chemistry_cell(p, p.ndens[idx], p.xh[idx], p.phi[idx], xav, xint, nconv, tf);
         p.xh_intermed[idx] = xint;
         p.xh_av[idx] = xav;
         sum1 += xint; sum0 += 1.0 - xint;
@@ -168,8 +188,13 @@ __global__ void __launch_bounds__(RED_THREADS) chemistry_reduce_kernel(const dou
 // the grids: per cell 6 loads (ndens, temp, xh, xh_av, two accumulators) and 7 stores (xh_av, xh_intermed,
 // phi_ion, nHI twice, two zeros) = 104 B, against 56 + 32 + 24 + 16 B of the four separate passes.
 // The [k][j][i] twins are read and written through LDS tiles so that their rows are contiguous as well.
-template <bool FOLD, bool EMIT>
-__global__ void __launch_bounds__(CH_THREADS) chemistry_tile_kernel(const ChemTileParams p)
+// waves per SIMD the register allocation of the tiled pass must leave room for (a streaming pass: more waves, more
+// bytes in flight)
+#ifndef ASORA_CHEM_MIN_WAVES
+#define ASORA_CHEM_MIN_WAVES 1
+#endif
+template <bool FOLD, bool EMIT, bool UNIFORM_T>
+__global__ void __launch_bounds__(CH_THREADS, ASORA_CHEM_MIN_WAVES) chemistry_tile_kernel(const ChemTileParams p)
 {
     if (p.status && p.status->done) return;
     __shared__ double tile_g[32][33], tile_n[32][33];
@@ -184,6 +209,11 @@ __global__ void __launch_bounds__(CH_THREADS) chemistry_tile_kernel(const ChemTi
 
     double sum1 = 0.0, sum0 = 0.0;
     unsigned int nconv = 0;
+    // UNIFORM_T: the whole grid has ONE temperature (probed when the grid was uploaded, temp_probe_kernel): its factors
+    // come with the parameters -- no temperature load (96 B per cell instead of 104), no pow / sqrt / exp code in the
+    // kernel (fewer registers: more waves in flight)
+    TempFactors tf;
+    if (UNIFORM_T) { tf.T = p.uniform_T; tf.brech0 = p.uniform_brech0; tf.acolh0 = p.uniform_acolh0; tf.t_ok = p.uniform_t_ok != 0; }
     for (int j = blockIdx.y; j < N; j += gridDim.y) {
         if (FOLD) {
             if (j != (int)blockIdx.y) __syncthreads();             // the tiles of the previous j have been consumed
@@ -206,7 +236,8 @@ __global__ void __launch_bounds__(CH_THREADS) chemistry_tile_kernel(const ChemTi
                 if (EMIT) p.gamma[idx] = 0.0;
                 const double n = p.ndens[idx];
                 double xav = p.xh_av_in[idx], xint;
-                chemistry_cell(cp, n, p.temp[idx], p.xh[idx], g, xav, xint, nconv);
+                if (!UNIFORM_T) temperature_factors(cp, p.temp[idx], tf);
+                chemistry_cell(cp, n, p.xh[idx], g, xav, xint, nconv, tf);
                 p.xh_intermed[idx] = xint;                           // chemistry.f90:107-108
                 p.xh_av[idx] = xav;
                 sum1 += xint; sum0 += 1.0 - xint;                    // evolve.py:216-217
@@ -242,6 +273,66 @@ __global__ void __launch_bounds__(CH_THREADS) chemistry_tile_kernel(const ChemTi
         p.red_partial[(size_t)p.red_stride + b] = r0[0];
         p.red_partial[2 * (size_t)p.red_stride + b] = (double)rc[0];
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Is the temperature grid uniform?  (once per upload of the grid and set of chemistry constants)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(CH_THREADS) temp_minmax_kernel(const double *__restrict__ temp, size_t n, double *partial)
+{
+    double lo = INFINITY, hi = -INFINITY;
+    bool nan = false;
+    for (size_t q = (size_t)blockIdx.x * CH_THREADS + threadIdx.x; q < n; q += (size_t)gridDim.x * CH_THREADS) {
+        const double t = temp[q];
+        nan = nan || (t != t);
+        lo = fmin(lo, t); hi = fmax(hi, t);
+    }
+    __shared__ double slo[CH_THREADS], shi[CH_THREADS];
+    __shared__ int snan[CH_THREADS];
+    slo[threadIdx.x] = lo; shi[threadIdx.x] = hi; snan[threadIdx.x] = nan ? 1 : 0;
+    __syncthreads();
+    for (int off = CH_THREADS / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            slo[threadIdx.x] = fmin(slo[threadIdx.x], slo[threadIdx.x + off]);
+            shi[threadIdx.x] = fmax(shi[threadIdx.x], shi[threadIdx.x + off]);
+            snan[threadIdx.x] |= snan[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = slo[0];
+        partial[gridDim.x + blockIdx.x] = shi[0];
+        partial[2 * gridDim.x + blockIdx.x] = (double)snan[0];
+    }
+}
+
+// out[0] = 1 if every cell holds the same (non-NaN) temperature, out[1..4] = that temperature and its factors, evaluated
+// by the same device code the general path runs per cell (bit-identical results on both paths)
+__global__ void temp_probe_final_kernel(const double *partial, int nblocks, double bh00, double albpow, double colh0,
+                                        double temph0, double *out)
+{
+    double lo = INFINITY, hi = -INFINITY, nan = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        lo = fmin(lo, partial[b]); hi = fmax(hi, partial[nblocks + b]); nan += partial[2 * nblocks + b];
+    }
+    ChemParams p;
+    p.bh00 = bh00; p.albpow = albpow; p.colh0 = colh0; p.temph0 = temph0;
+    TempFactors tf;
+    temperature_factors(p, lo, tf);
+    out[0] = (lo == hi && nan == 0.0) ? 1.0 : 0.0;
+    out[1] = lo; out[2] = tf.brech0; out[3] = tf.acolh0; out[4] = tf.t_ok ? 1.0 : 0.0;
+}
+
+int launch_temp_probe(State &st, const double *temp, size_t n, double bh00, double albpow, double colh0, double temph0,
+                      double *out_dev)
+{
+    const int blocks = (int)std::min<size_t>(std::max<size_t>(1, (n + CH_THREADS - 1) / CH_THREADS), (size_t)st.red_blocks);
+    hipLaunchKernelGGL(temp_minmax_kernel, dim3(blocks), dim3(CH_THREADS), 0, st.stream, temp, n, st.red_partial);
+    ASORA_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(temp_probe_final_kernel, dim3(1), dim3(1), 0, st.stream, (const double *)st.red_partial, blocks, bh00,
+                       albpow, colh0, temph0, out_dev);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int chemistry_reduction_blocks(const State &st) { return st.cu_count * 8; }
@@ -290,9 +381,14 @@ int launch_chemistry_tiles(State &st, ChemTileParams &p, hipStream_t stream)
     q.red_stride = (int)blocks;
     {
         KernelTimer kt(ASORA_KERNEL_CHEMISTRY, stream);
-        if (p.fold && p.emit)        hipLaunchKernelGGL((chemistry_tile_kernel<true, true>), grid, dim3(CH_THREADS), 0, stream, q);
-        else if (!p.fold && !p.emit) hipLaunchKernelGGL((chemistry_tile_kernel<false, false>), grid, dim3(CH_THREADS), 0, stream, q);
-        else return fail(11, "chemistry: unsupported fold/emit combination (internal error)");
+        const bool u = p.uniform != 0;
+        if (p.fold && p.emit) {
+            if (u) hipLaunchKernelGGL((chemistry_tile_kernel<true, true, true>), grid, dim3(CH_THREADS), 0, stream, q);
+            else   hipLaunchKernelGGL((chemistry_tile_kernel<true, true, false>), grid, dim3(CH_THREADS), 0, stream, q);
+        } else if (!p.fold && !p.emit) {
+            if (u) hipLaunchKernelGGL((chemistry_tile_kernel<false, false, true>), grid, dim3(CH_THREADS), 0, stream, q);
+            else   hipLaunchKernelGGL((chemistry_tile_kernel<false, false, false>), grid, dim3(CH_THREADS), 0, stream, q);
+        } else return fail(11, "chemistry: unsupported fold/emit combination (internal error)");
         ASORA_HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(chemistry_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, stream,

@@ -273,7 +273,9 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
     // loaded into.  The loop below is unrolled three times with the three register sets rotating,
     // so the pipeline needs no register-to-register copies.
     bool late_ok = false;              // a rate computed in the previous step, not yet added (ASORA_LATE_ATOMIC)
+#if !ASORA_LATE_LOOKUP
     double late_v = 0.0, late_h = 0.0;
+#endif
     double *late_dst = p.phi;
 #if ASORA_LATE_LOOKUP
     Lookup pend_A, pend_B;             // lookups issued in the previous step, consumed in this one

@@ -892,3 +892,43 @@ def test_device_resident_loop_equals_the_step_by_step_loop(asora, N, ns, R, monk
     assert 0.02 < results[0][0].mean() < 0.98                                     # a partially ionised box
     # the log has one convergence line per iteration
     assert open(tmp_path / "log8").read().count("Number of non-converged points") == niter_ref
+
+
+def test_uniform_temperature_form_of_the_chemistry_pass_is_bit_identical(asora):
+    """A temperature grid found uniform at upload is not read again and its pow/sqrt/exp factors are evaluated once on
+    the device; the general form (forced by ASORA_OPT_NO_UNIFORM_T) must give the same bits.  And a grid that is uniform
+    except for ONE cell must take the general form by itself."""
+    p, lib, capi = asora
+    N = 24
+    c = cases.chem_case(N, 77)
+    chem = (c["dt"], c["bh00"], c["albpow"], c["colh0"], c["temph0"], c["abu_c"])
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 8)
+
+    def run(temp, force_general):
+        for which, key in ((capi.GRID_NDENS, "ndens"), (capi.GRID_XH, "xh"), (capi.GRID_XH_AV, "xh_av"),
+                           (capi.GRID_XH_INTERMED, "xh_intermed"), (capi.GRID_PHI_ION, "phi_ion")):
+            lib.grid_to_device(which, c[key])
+        lib.grid_to_device(capi.GRID_TEMP, temp)
+        lib.set_option(capi.OPT_NO_UNIFORM_T, 1 if force_general else 0)
+        try:
+            lib.chemistry_range(*chem, 0, N, True)
+            red = lib.chemistry_finish()
+        finally:
+            lib.set_option(capi.OPT_NO_UNIFORM_T, 0)
+        return (lib.grid_to_host(capi.GRID_XH_AV, np.empty((N, N, N))), lib.grid_to_host(capi.GRID_XH_INTERMED, np.empty((N, N, N))), red)
+
+    uniform = np.full((N, N, N), 8.7e3)
+    a, b = run(uniform, False), run(uniform, True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    ref = O.global_pass(c["dt"], c["ndens"], uniform, c["xh"], c["xh_av"], c["xh_intermed"], c["phi_ion"], c["bh00"],
+                        c["albpow"], c["colh0"], c["temph0"], c["abu_c"])
+    np.testing.assert_allclose(a[1], ref[1], rtol=1e-9, atol=0)
+    spoiled = uniform.copy()
+    spoiled[N - 1, 3, 5] = 2.0e4
+    s = run(spoiled, False)
+    ref2 = O.global_pass(c["dt"], c["ndens"], spoiled, c["xh"], c["xh_av"], c["xh_intermed"], c["phi_ion"], c["bh00"],
+                         c["albpow"], c["colh0"], c["temph0"], c["abu_c"])
+    np.testing.assert_allclose(s[1], ref2[1], rtol=1e-9, atol=0)
+    assert s[1][N - 1, 3, 5] != a[1][N - 1, 3, 5]
