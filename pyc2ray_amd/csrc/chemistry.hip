@@ -308,13 +308,26 @@ __global__ void __launch_bounds__(CH_THREADS) temp_minmax_kernel(const double *_
 
 // out[0] = 1 if every cell holds the same (non-NaN) temperature, out[1..4] = that temperature and its factors, evaluated
 // by the same device code the general path runs per cell (bit-identical results on both paths)
-__global__ void temp_probe_final_kernel(const double *partial, int nblocks, double bh00, double albpow, double colh0,
-                                        double temph0, double *out)
+__global__ void __launch_bounds__(CH_THREADS) temp_probe_final_kernel(const double *partial, int nblocks, double bh00, double albpow,
+                                                                      double colh0, double temph0, double *out)
 {
     double lo = INFINITY, hi = -INFINITY, nan = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
+    for (int b = threadIdx.x; b < nblocks; b += CH_THREADS) {
         lo = fmin(lo, partial[b]); hi = fmax(hi, partial[nblocks + b]); nan += partial[2 * nblocks + b];
     }
+    __shared__ double slo[CH_THREADS], shi[CH_THREADS], snan[CH_THREADS];
+    slo[threadIdx.x] = lo; shi[threadIdx.x] = hi; snan[threadIdx.x] = nan;
+    __syncthreads();
+    for (int off = CH_THREADS / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            slo[threadIdx.x] = fmin(slo[threadIdx.x], slo[threadIdx.x + off]);
+            shi[threadIdx.x] = fmax(shi[threadIdx.x], shi[threadIdx.x + off]);
+            snan[threadIdx.x] += snan[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    lo = slo[0]; hi = shi[0]; nan = snan[0];
     ChemParams p;
     p.bh00 = bh00; p.albpow = albpow; p.colh0 = colh0; p.temph0 = temph0;
     TempFactors tf;
@@ -329,7 +342,7 @@ int launch_temp_probe(State &st, const double *temp, size_t n, double bh00, doub
     const int blocks = (int)std::min<size_t>(std::max<size_t>(1, (n + CH_THREADS - 1) / CH_THREADS), (size_t)st.red_blocks);
     hipLaunchKernelGGL(temp_minmax_kernel, dim3(blocks), dim3(CH_THREADS), 0, st.stream, temp, n, st.red_partial);
     ASORA_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(temp_probe_final_kernel, dim3(1), dim3(1), 0, st.stream, (const double *)st.red_partial, blocks, bh00,
+    hipLaunchKernelGGL(temp_probe_final_kernel, dim3(1), dim3(CH_THREADS), 0, st.stream, (const double *)st.red_partial, blocks, bh00,
                        albpow, colh0, temph0, out_dev);
     ASORA_HIP_TRY(hipGetLastError());
     return 0;

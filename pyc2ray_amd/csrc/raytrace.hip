@@ -159,6 +159,11 @@ __device__ __forceinline__ double photo_rate_per_atom(double flux, double cd_in,
 #define ASORA_LATE_LOOKUP 1
 #endif
 
+// 1: within a group of 8 sources the units are dispatched largest first (the z-sector units hold the most cells)
+#ifndef ASORA_UNITS_LARGEST_FIRST
+#define ASORA_UNITS_LARGEST_FIRST 0
+#endif
+
 // waves per SIMD the register allocation must leave room for (2nd argument of __launch_bounds__)
 #ifndef ASORA_MIN_WAVES
 #define ASORA_MIN_WAVES 1
@@ -178,7 +183,11 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
     // on one XCD so that they share its L2 lines of nHI.  Speed only, never correctness.
     // p.units workgroups per source (8, 24 or 12: see ensure_geometry)
     const int src_local = (blk & 7) + 8 * (blk / (8 * p.units));
+#if ASORA_UNITS_LARGEST_FIRST
+    const int unit = p.units - 1 - (blk >> 3) % p.units;   // sector units: z (most cells) first, x (fewest) last in dispatch order
+#else
     const int unit = (blk >> 3) % p.units;
+#endif
     if (src_local >= p.src_count) return;
     const int ns = p.src_begin + src_local;
 
