@@ -252,7 +252,9 @@ enum {
     /* 1: never take the uniform-temperature form of the tiled chemistry pass (diagnostics / tests: both forms give
      *    bit-identical results).  0 (default): a temperature grid found uniform when uploaded is not read again. */
     ASORA_OPT_NO_UNIFORM_T = 8,
-    ASORA_OPT_COUNT = 9
+    /* 1: the sub-box raytracer keeps its shell buffers in global memory even when they would fit LDS (tests). */
+    ASORA_OPT_SUBBOX_GLOBAL_SHELLS = 9,
+    ASORA_OPT_COUNT = 10
 };
 int asora_set_option(int option, int value);
 int asora_get_option(int option);

@@ -159,9 +159,11 @@ __device__ __forceinline__ double photo_rate_per_atom(double flux, double cd_in,
 #define ASORA_LATE_LOOKUP 1
 #endif
 
-// 1: within a group of 8 sources the units are dispatched largest first (the z-sector units hold the most cells)
+// 1: within a group of 8 sources the units are dispatched largest first (the z-sector units hold the most cells), so
+// that the workgroups still running when the grid drains are the short ones.  Measured (tools/ab_macro.sh, 1000 sources,
+// 256^3): R = 24 -2.6 %, 32 -1.8 %, 48 -1.7 %, 64 -0.5 %.
 #ifndef ASORA_UNITS_LARGEST_FIRST
-#define ASORA_UNITS_LARGEST_FIRST 0
+#define ASORA_UNITS_LARGEST_FIRST 1
 #endif
 
 // waves per SIMD the register allocation must leave room for (2nd argument of __launch_bounds__)

@@ -40,11 +40,15 @@ __device__ __forceinline__ double dist2_reference(int a, int b, int c, double dr
 
 // SB_THREADS = 256, or 1024 when there are fewer workgroups than CUs (a handful of sources: the launch then lasts
 // as long as one workgroup, so wider workgroups shorten it)
-template <int SB_THREADS>
+// HEAT: heating tables are looked up and heating rates deposited.  LDS_SHELLS: the two shell buffers (3 W^2 doubles each)
+// live in LDS for the launch (they fit up to W ~ 55) and only the trailing shell goes through the global buffer that
+// hands it to the next sub-box's launch; otherwise both stay in the global, L2-resident buffer.
+template <int SB_THREADS, bool HEAT, bool LDS_SHELLS>
 __global__ void __launch_bounds__(SB_THREADS) subbox_sweep_kernel(const SubboxParams p)
 {
     __shared__ double2 logtab[LOG_TABLE_SIZE];
     __shared__ double red[SB_THREADS / 64];
+    extern __shared__ double lds_shells[];
 
     const int blk = blockIdx.x;
     const int src_local = (blk & 7) + 8 * (blk >> 6);       // the 8 octants of a source share an XCD
@@ -71,8 +75,14 @@ __global__ void __launch_bounds__(SB_THREADS) subbox_sweep_kernel(const SubboxPa
 
     double *buf0 = p.scratch + (size_t)blk * p.unit_stride;
     double *buf1 = buf0 + 3 * (size_t)WW;
-    double *prev = (p.s_begin & 1) ? buf1 : buf0;           // after k shells the trailing one sits in buffer k & 1
+    double *gprev = (p.s_begin & 1) ? buf1 : buf0;          // after k shells the trailing one sits in buffer k & 1
+    double *prev = gprev;
     double *cur = (p.s_begin & 1) ? buf0 : buf1;
+    if (LDS_SHELLS) {
+        prev = lds_shells; cur = lds_shells + 3 * WW;
+        if (p.s_begin > 0)                                  // the trailing shell of the previous sub-box
+            for (int t = threadIdx.x; t < 3 * WW; t += SB_THREADS) prev[t] = gprev[t];
+    }
     __syncthreads();
 
     double loss = 0.0;
@@ -100,9 +110,9 @@ __global__ void __launch_bounds__(SB_THREADS) subbox_sweep_kernel(const SubboxPa
                 else       { phi = pref * dtau * exp(-tau_in); phi_out = phi_in - phi; }
             } else {                                                                  // photorates.f90:62-125
                 const double pref = flux / vol;
-                const Lookup A = lookup_issue<true>(p.tables, tau_in, p, logtab);     // thick table at tau_in
-                const Lookup B = thick ? lookup_issue<true>(p.tables, tau_out, p, logtab)
-                                       : lookup_issue<true>(p.tables + p.table_len, tau_in, p, logtab);   // thin, tau_in
+                const Lookup A = lookup_issue<HEAT>(p.tables, tau_in, p, logtab);     // thick table at tau_in
+                const Lookup B = thick ? lookup_issue<HEAT>(p.tables, tau_out, p, logtab)
+                                       : lookup_issue<HEAT>(p.tables + p.table_len, tau_in, p, logtab);   // thin, tau_in
                 const double phi_in = pref * lookup_value(A);
                 if (thick) {
                     // (pref*(T_in - T_out): phi_in - phi_out would be fused into fma(pref, T_in, -phi_out) and leave the
@@ -110,15 +120,15 @@ __global__ void __launch_bounds__(SB_THREADS) subbox_sweep_kernel(const SubboxPa
                     const double tb = lookup_value(B);
                     phi_out = pref * tb;
                     phi = pref * (lookup_value(A) - tb);
-                    heat = pref * (lookup_heat(A) - lookup_heat(B));
+                    if (HEAT) heat = pref * (lookup_heat(A) - lookup_heat(B));
                 } else {
                     phi = pref * dtau * lookup_value(B);
                     phi_out = phi_in - phi;
-                    heat = pref * dtau * lookup_heat(B);
+                    if (HEAT) heat = pref * dtau * lookup_heat(B);
                 }
             }
             unsafeAtomicAdd(p.phi + idx, phi / nHI);                                  // f90:531-535
-            if (p.heat) unsafeAtomicAdd(p.heat_grid + idx, heat / nHI);
+            if (HEAT) unsafeAtomicAdd(p.heat_grid + idx, heat / nHI);
         }
         if (on_edge) loss += phi_out;                                                 // f90:541-543
         return cd_out;
@@ -144,19 +154,22 @@ __global__ void __launch_bounds__(SB_THREADS) subbox_sweep_kernel(const SubboxPa
         const int nx = s <= Ea ? (Bx + 1) * (Cx + 1) : 0;
         const int ntot = nz + ny + nx;
         const int sm = s - 1;
+        // row = t / rowlength without an integer division: (t + 1/2) * (1/rowlength) in single precision is off by
+        // < 2e-5 for t < 2^17 and rows < 2^8 cells, while the quotient stays >= 1/(2 rowlength) away from an integer
+        const float inv_z = 1.0f / (float)(Az + 1), inv_y = 1.0f / (float)(Cy + 1), inv_x = 1.0f / (float)(Cx + 1);
 
         for (int t = threadIdx.x; t < ntot; t += SB_THREADS) {
             int a, b, c, U, V, face;
             if (t < nz) {            // dk = s: rows along a (contiguous in the [k][j][i] copies)
-                const int row = t / (Az + 1);
+                const int row = (int)(((float)t + 0.5f) * inv_z);
                 a = t - row * (Az + 1); b = row; c = s;
                 U = a; V = b; face = 2;
             } else if (t < nz + ny) { // dj = s: rows along c
-                const int r = t - nz, row = r / (Cy + 1);
+                const int r = t - nz, row = (int)(((float)r + 0.5f) * inv_y);
                 c = r - row * (Cy + 1); a = row; b = s;
                 U = a; V = c; face = 1;
             } else {                  // di = s
-                const int r = t - nz - ny, row = r / (Cx + 1);
+                const int r = t - nz - ny, row = (int)(((float)r + 0.5f) * inv_x);
                 c = r - row * (Cx + 1); b = row; a = s;
                 U = b; V = c; face = 0;
             }
@@ -195,10 +208,11 @@ __global__ void __launch_bounds__(SB_THREADS) subbox_sweep_kernel(const SubboxPa
             const double c2 = (e0 && fm) ? prev[o2] : 0.0;
             const double c3 = (em && f0) ? prev[o3] : 0.0;
             const double c4 = (e0 && f0) ? prev[o4] : 0.0;
-            w1 *= 1.0 / fmax(0.6, c1 * sig);                  // weightf, f90:823-835
-            w2 *= 1.0 / fmax(0.6, c2 * sig);
-            w3 *= 1.0 / fmax(0.6, c3 * sig);
-            w4 *= 1.0 / fmax(0.6, c4 * sig);
+            // w_n = s_n / max(0.6, c_n sig) (weightf, f90:823-835) and cdensi = sum(c_n w_n) / sum(w_n) (f90:641), with
+            // numerator and denominator multiplied through by the four max() terms: one division instead of five
+            const double m1 = fmax(0.6, c1 * sig), m2 = fmax(0.6, c2 * sig), m3 = fmax(0.6, c3 * sig), m4 = fmax(0.6, c4 * sig);
+            const double m12 = m1 * m2, m34 = m3 * m4;
+            w1 *= m2 * m34; w2 *= m1 * m34; w3 *= m12 * m4; w4 *= m12 * m3;
             double cd_in = (c1 * w1 + c2 * w2 + c3 * w3 + c4 * w4) / (w1 + w2 + w3 + w4);
             if (s == 1 && (U == 1 || V == 1)) cd_in = ((U == 1 && V == 1) ? r3 : r2) * cd_in;   // f90:648-658
             const double path = sqrt((u * u + v * v) / (sd * sd) + 1.0) * dr;                   // f90:661 * dr
@@ -218,6 +232,11 @@ __global__ void __launch_bounds__(SB_THREADS) subbox_sweep_kernel(const SubboxPa
         }
         __syncthreads();
         double *tmp = prev; prev = cur; cur = tmp;
+    }
+
+    if (LDS_SHELLS) {       // hand the trailing shell to the next sub-box's launch: after k shells it sits in buffer k & 1
+        double *gnext = (p.s_end & 1) ? buf1 : buf0;
+        for (int t = threadIdx.x; t < 3 * WW; t += SB_THREADS) gnext[t] = prev[t];
     }
 
     // ---- photon loss of this octant through the faces of the sub-box ------------------------------
@@ -249,16 +268,31 @@ __global__ void subbox_decide_kernel(int mode, int count, const double *src_flux
     }
 }
 
+template <int T>
+static int launch_subbox_variant(State &st, const SubboxParams &p, unsigned grid, bool lds, size_t lds_bytes)
+{
+#define ASORA_SB_LAUNCH(HT, LD)                                                                                          \
+    do {                                                                                                                 \
+        if (LD) ASORA_HIP_TRY(hipFuncSetAttribute((const void *)subbox_sweep_kernel<T, HT, LD>,                          \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));          \
+        hipLaunchKernelGGL((subbox_sweep_kernel<T, HT, LD>), dim3(grid), dim3(T), LD ? lds_bytes : 0, st.stream, p);     \
+    } while (0)
+    if (p.heat) { if (lds) ASORA_SB_LAUNCH(true, true); else ASORA_SB_LAUNCH(true, false); }
+    else        { if (lds) ASORA_SB_LAUNCH(false, true); else ASORA_SB_LAUNCH(false, false); }
+#undef ASORA_SB_LAUNCH
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_subbox_sweep(State &st, const SubboxParams &p)
 {
     const unsigned grid = 64u * (unsigned)((p.src_count + 7) / 8);
     KernelTimer kt(ASORA_KERNEL_RAYTRACE);
-    if ((long)p.src_count * 8 < (long)st.cu_count)
-        hipLaunchKernelGGL(subbox_sweep_kernel<1024>, dim3(grid), dim3(1024), 0, st.stream, p);
-    else
-        hipLaunchKernelGGL(subbox_sweep_kernel<256>, dim3(grid), dim3(256), 0, st.stream, p);
-    ASORA_HIP_TRY(hipGetLastError());
-    return 0;
+    // both shell buffers in LDS up to 56 KB per workgroup (W <= 34: a +-32 box, the benchmark's)
+    const size_t lds_bytes = (size_t)6 * p.W * p.W * sizeof(double);
+    const bool lds = lds_bytes <= 56 * 1024 && !st.opt[ASORA_OPT_SUBBOX_GLOBAL_SHELLS];
+    if ((long)p.src_count * 8 < (long)st.cu_count) return launch_subbox_variant<1024>(st, p, grid, lds, lds_bytes);
+    return launch_subbox_variant<256>(st, p, grid, lds, lds_bytes);
 }
 
 int launch_subbox_decide(State &st, int mode, int count, const double *src_flux, int src_begin, double loss_fraction,

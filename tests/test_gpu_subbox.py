@@ -308,3 +308,33 @@ def test_randomised_subbox_parameters_against_oracle(libs):
         seen_early_stop += nbox < full
         seen_full += nbox == full
     assert seen_early_stop >= 3 and seen_full >= 3            # the sweep exercises both outcomes
+
+
+@pytest.mark.parametrize("name", ["sb32_b5", "sb32_mid", "sb17_b2"])
+@pytest.mark.parametrize("heat", [True, False])
+def test_shell_buffers_in_lds_and_in_global_memory_give_the_same(libs, name, heat):
+    """The sweep keeps its two shell buffers in LDS when they fit and hands the trailing shell to the next sub-box's
+    launch through global memory; with ASORA_OPT_SUBBOX_GLOBAL_SHELLS both stay in global memory (what large meshes
+    use).  Same box counts and loss, rates and column densities equal up to the order of the atomic sums -- with and
+    without heating tables (two kernel variants each)."""
+    p, c2ray, asora, capi = libs
+    c = cases.subbox_case(name)
+    _fresh(p, c["N"])
+    out = []
+    for global_shells in (0, 1):
+        asora.set_option(capi.OPT_SUBBOX_GLOBAL_SHELLS, global_shells)
+        try:
+            out.append(_call(c2ray, c, c["max_subbox"], c["subboxsize"], c["loss_fraction"], c["R"], heat=heat))
+        finally:
+            asora.set_option(capi.OPT_SUBBOX_GLOBAL_SHELLS, 0)
+    (phi0, heat0, cd0, nbox0, loss0), (phi1, heat1, cd1, nbox1, loss1) = out
+    assert nbox0 == nbox1
+    np.testing.assert_allclose(loss0, loss1, rtol=1e-12)
+    assert np.array_equal(cd0, cd1)
+    _close(phi0, phi1, 1e-12)
+    _close(heat0, heat1, 1e-12)
+    assert heat or not heat0.any()
+    g = np.load(os.path.join(G, "subbox.npz"))
+    if heat:
+        _close(phi1, g[name + "__phi"], RATE_RTOL)
+        assert nbox1 == int(g[name + "__stats"][0])

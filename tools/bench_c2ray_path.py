@@ -24,6 +24,7 @@ ap.add_argument("--cpu-sources", type=int, default=1000)
 ap.add_argument("--workload", default="uniform")
 ap.add_argument("--loss-fraction", type=float, default=1e-2)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--global-shells", type=int, default=0, help="1: ASORA_OPT_SUBBOX_GLOBAL_SHELLS (shell buffers in global memory)")
 a = ap.parse_args()
 
 N, ns = a.N, a.nsrc
@@ -34,6 +35,7 @@ ndens, xh, temp, dr, pos, flux = bench.make_workload(a.workload, N, ns)
 nd_f, xh_f = np.asfortranarray(ndens), np.asfortranarray(xh)
 zeros = np.zeros(thin.shape[0])
 
+asora.set_option(9, a.global_shells)      # ASORA_OPT_SUBBOX_GLOBAL_SHELLS
 for R in a.R:
     sub = int(R)
     phi = np.zeros((N, N, N), order="F")
@@ -50,7 +52,7 @@ for R in a.R:
     t_gpu = (time.perf_counter() - t0) / a.reps
     k_ms, k_n = asora.kernel_time_ms(0)
     asora.set_option(2, 0)
-    out = {"call": "libc2ray.raytracing.do_all_sources on the GPU (host grids in/out, Fortran order)", "N": N,
+    out = {"call": "libc2ray.raytracing.do_all_sources on the GPU (host grids in/out, Fortran order)", "N": N, "shell_buffers": "global memory" if a.global_shells else "LDS when they fit",
            "sources": ns, "R": R, "subboxsize": sub, "loss_fraction": a.loss_fraction, "s_per_call": t_gpu,
            "sweep_kernels_ms_per_call": k_ms / a.reps, "sweep_launches_per_call": k_n / a.reps,
            "nsubbox": nbox, "photon_loss": loss}
