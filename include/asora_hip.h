@@ -254,7 +254,10 @@ enum {
     ASORA_OPT_NO_UNIFORM_T = 8,
     /* 1: the sub-box raytracer keeps its shell buffers in global memory even when they would fit LDS (tests). */
     ASORA_OPT_SUBBOX_GLOBAL_SHELLS = 9,
-    ASORA_OPT_COUNT = 10
+    /* 1 (default): asora_do_all_sources overlaps the upload of xh_av, the trace and the download of phi_ion slab by slab
+     *    (when all uploaded sources are traced and R is small against the mesh); 0: upload, trace, download in turn. */
+    ASORA_OPT_PIPELINED_COPIES = 10,
+    ASORA_OPT_COUNT = 11
 };
 int asora_set_option(int option, int value);
 int asora_get_option(int option);

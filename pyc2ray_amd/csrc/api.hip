@@ -136,7 +136,7 @@ static int release_all()
     st.nhi_t = st.phi_t = st.heat_t = nullptr;    // second halves of nhi / phi_ion / phi_heat
     st.have_heat_tables = false;
     drop(st.tables); st.table_len = 0;
-    drop(st.src_pos); drop(st.src_flux); st.num_src = 0;
+    drop(st.src_pos); drop(st.src_flux); drop(st.src_pos_sorted); drop(st.src_flux_sorted); st.src_i0_sorted.clear(); st.num_src = 0;
     drop(st.shell_scratch); st.shell_scratch_bytes = 0;
     drop(st.sb_active); drop(st.sb_nbox); drop(st.sb_loss); drop(st.sb_loss_final); st.subbox_cap = 0;
     release_geometry(st);
@@ -418,6 +418,136 @@ static int subbox_core(const SubboxCall &c, long long &total_nbox, double &total
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The drop-in asora_do_all_sources with its two PCIe copies hidden behind the trace
+// ---------------------------------------------------------------------------------------------
+// The reference's call uploads xh_av (N^3 doubles), traces, downloads phi_ion (raytracing.cu:117-146): at 256^3 the two
+// copies take 2 x 2.4 ms at the link's ~56 GB/s against 1.4 ms of tracing 1000 sources.  A source at plane i0 only needs
+// nHI on, and only rates, the planes within R of it.  So the grid is cut into K slabs of planes; the slabs of xh_av are
+// uploaded one after the other on a copy stream, nHI of a slab is formed as soon as it has arrived, the sources of a
+// slab (a second copy of the source list, ordered by first coordinate) are traced as soon as the slabs they reach are
+// there, and a slab of phi_ion is folded and sent to the host on a second copy stream as soon as the last source that
+// reaches it has been traced -- upload, trace and download overlap (PCIe is full duplex).  The host buffers are
+// registered (pinned) for the duration of the call so that the copies are asynchronous; re-registering a buffer the
+// driver has seen before costs microseconds (tools/micro/pcie.hip).  done = false: conditions not met, nothing was
+// started, the caller takes the plain path.
+static int do_all_sources_pipelined(double R, double sig, double dr, const double *xh_av, double *phi_ion, int NumSrc,
+                                    double minlogtau, double dlogtau, int NumTau, bool &done)
+{
+    State &st = g_state;
+    done = false;
+    const int N = st.N;
+    const int K = 8;
+    if (!st.opt[ASORA_OPT_PIPELINED_COPIES] || !st.opt[ASORA_OPT_Z_TRANSPOSED] || st.opt[ASORA_OPT_HEATING]) return 0;
+    if (NumSrc != st.num_src || NumSrc < 1 || !st.src_pos_sorted || N < 8 * K) return 0;
+    if (!std::isfinite(R) || !(R >= 0.0)) return 0;
+    const int m = (int)std::floor(R) + 1;
+    if (2 * m + N / K >= N) return 0;                       // every slab of sources reaches (nearly) every plane
+    if (!st.grid_valid[ASORA_GRID_NDENS]) return fail(4, "raytrace: density not on device (density_to_device)");
+    if (!st.opt[ASORA_OPT_GREY_NOTABLES] && !st.tables)
+        return fail(4, "raytrace: radiation tables not on device (photo_table_to_device)");
+    if (NumTau < 1 && !st.opt[ASORA_OPT_GREY_NOTABLES]) return fail(4, "raytrace: NumTau must be >= 1");
+
+    const size_t bytes = st.ncell * sizeof(double);
+    if (hipHostRegister((void *)xh_av, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipHostRegister((void *)phi_ion, bytes, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipHostUnregister((void *)xh_av); return 0;
+    }
+    struct Unpin { const void *a, *b; ~Unpin() { (void)hipHostUnregister((void *)a); (void)hipHostUnregister((void *)b); } } unpin{xh_av, phi_ion};
+
+    while ((int)st.pipe_events.size() < 2 * K) {
+        hipEvent_t e = nullptr;
+        ASORA_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        st.pipe_events.push_back(e);
+    }
+    hipStream_t up = st.side[0], down = st.side[1];
+    const size_t plane = (size_t)N * N;
+    int lo[K + 1];
+    for (int c = 0; c <= K; ++c) lo[c] = c * N / K;
+    // sources of slab c: [sb[c], sb[c+1]) of the sorted list
+    int sb[K + 1];
+    for (int c = 0; c <= K; ++c)
+        sb[c] = (int)(std::lower_bound(st.src_i0_sorted.begin(), st.src_i0_sorted.end(), lo[c]) - st.src_i0_sorted.begin());
+    // reach[c][d]: do sources of slab c touch planes of slab d (within m planes, periodically)
+    bool reach[K][K];
+    for (int c = 0; c < K; ++c)
+        for (int d = 0; d < K; ++d) {
+            bool hit = false;
+            if (sb[c + 1] > sb[c])
+                for (int q = lo[d]; q < lo[d + 1] && !hit; ++q) {
+                    // distance from plane q to the interval [lo[c], lo[c+1]) on the ring
+                    int dist = 0;
+                    if (q < lo[c]) dist = std::min(lo[c] - q, q + N - (lo[c + 1] - 1));
+                    else if (q >= lo[c + 1]) dist = std::min(q - (lo[c + 1] - 1), lo[c] + N - q);
+                    hit = dist <= m;
+                }
+            reach[c][d] = hit;
+        }
+
+    ASORA_HIP_TRY(hipMemsetAsync(st.grid[ASORA_GRID_PHI_ION], 0, 2 * bytes, st.stream));      // raytracing.cu:113 (+ twin)
+    ASORA_HIP_TRY(hipMemsetAsync(st.counters, 0, sizeof(unsigned long long) * 2, st.stream));
+    RtParams base;
+    fill_rt_params(base, R, sig, dr, minlogtau, dlogtau, NumTau);
+    base.src_pos = st.src_pos_sorted; base.src_flux = st.src_flux_sorted;
+    base.shape_src_count = NumSrc;
+    st.rt_open = false;
+    // the copy streams start behind whatever the main stream has done so far (earlier calls may still own the grids)
+    ASORA_HIP_TRY(hipEventRecord(st.main_ready, st.stream));
+    ASORA_HIP_TRY(hipStreamWaitEvent(up, st.main_ready, 0));
+    ASORA_HIP_TRY(hipStreamWaitEvent(down, st.main_ready, 0));
+
+    bool prepped[K] = {}, traced[K] = {}, sent[K] = {};
+    auto try_traces = [&]() -> int {
+        for (int c = 0; c < K; ++c) {
+            if (traced[c]) continue;
+            bool ready = true;
+            for (int d = 0; d < K; ++d) if (reach[c][d] && !prepped[d]) ready = false;
+            if (!ready) continue;
+            if (sb[c + 1] > sb[c]) {
+                RtParams p = base;
+                p.src_begin = sb[c]; p.src_count = sb[c + 1] - sb[c];
+                if (int rc = launch_raytrace(st, p, false, false)) return rc;
+            }
+            traced[c] = true;
+        }
+        return 0;
+    };
+    auto try_downloads = [&]() -> int {
+        for (int d = 0; d < K; ++d) {
+            if (sent[d]) continue;
+            bool final_ = true;
+            for (int c = 0; c < K; ++c) if (reach[c][d] && !traced[c]) final_ = false;
+            if (!final_) continue;
+            if (int rc = launch_fold_range(st, st.phi_t, st.grid[ASORA_GRID_PHI_ION], lo[d], lo[d + 1] - lo[d])) return rc;
+            ASORA_HIP_TRY(hipEventRecord(st.pipe_events[K + d], st.stream));
+            ASORA_HIP_TRY(hipStreamWaitEvent(down, st.pipe_events[K + d], 0));
+            ASORA_HIP_TRY(hipMemcpyAsync(phi_ion + (size_t)lo[d] * plane, st.grid[ASORA_GRID_PHI_ION] + (size_t)lo[d] * plane,
+                                         (size_t)(lo[d + 1] - lo[d]) * plane * sizeof(double), hipMemcpyDeviceToHost, down));
+            sent[d] = true;
+        }
+        return 0;
+    };
+    // upload order: the last slab first (the sources of slab 0 reach back into it), then 0, 1, ...
+    for (int q = 0; q < K; ++q) {
+        const int c = (q + K - 1) % K;
+        ASORA_HIP_TRY(hipMemcpyAsync(st.grid[ASORA_GRID_XH_AV] + (size_t)lo[c] * plane, xh_av + (size_t)lo[c] * plane,
+                                     (size_t)(lo[c + 1] - lo[c]) * plane * sizeof(double), hipMemcpyHostToDevice, up));   // cu:117
+        ASORA_HIP_TRY(hipEventRecord(st.pipe_events[c], up));
+        ASORA_HIP_TRY(hipStreamWaitEvent(st.stream, st.pipe_events[c], 0));
+        if (int rc = launch_prepare_range(st, lo[c], lo[c + 1] - lo[c], false, nullptr)) return rc;
+        prepped[c] = true;
+        if (int rc = try_traces()) return rc;
+        if (int rc = try_downloads()) return rc;
+    }
+    for (int c = 0; c < K; ++c) if (!traced[c] || !sent[c]) return fail(11, "do_all_sources: pipeline schedule incomplete (internal error)");
+    ASORA_HIP_TRY(hipStreamSynchronize(down));
+    ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    st.grid_valid[ASORA_GRID_XH_AV] = true;
+    st.grid_valid[ASORA_GRID_PHI_ION] = true;
+    done = true;
+    return 0;
+}
+
 } // namespace asora
 
 namespace {
@@ -619,12 +749,34 @@ int asora_source_data_to_device(const int32_t *pos, const double *flux, int NumS
                                    std::to_string(pos[3 * s + ax]) + " on axis " + std::to_string(ax) + ")");
     if (st.src_pos) { (void)hipFree(st.src_pos); st.src_pos = nullptr; }          // memory.cu:102-103
     if (st.src_flux) { (void)hipFree(st.src_flux); st.src_flux = nullptr; }
+    if (st.src_pos_sorted) { (void)hipFree(st.src_pos_sorted); st.src_pos_sorted = nullptr; }
+    if (st.src_flux_sorted) { (void)hipFree(st.src_flux_sorted); st.src_flux_sorted = nullptr; }
+    st.src_i0_sorted.clear();
     st.num_src = 0;
     if (NumSrc == 0) return 0;
     ASORA_HIP_TRY(hipMalloc(&st.src_pos, sizeof(int32_t) * 3 * (size_t)NumSrc));
     ASORA_HIP_TRY(hipMalloc(&st.src_flux, sizeof(double) * (size_t)NumSrc));
     ASORA_HIP_TRY(hipMemcpy(st.src_pos, pos, sizeof(int32_t) * 3 * (size_t)NumSrc, hipMemcpyHostToDevice));
     ASORA_HIP_TRY(hipMemcpy(st.src_flux, flux, sizeof(double) * (size_t)NumSrc, hipMemcpyHostToDevice));
+    {   // a second copy ordered by the first coordinate, for the pipelined asora_do_all_sources (the sum over sources
+        // does not depend on their order)
+        std::vector<int> order((size_t)NumSrc);
+        for (int s = 0; s < NumSrc; ++s) order[s] = s;
+        std::stable_sort(order.begin(), order.end(), [pos](int a, int b) { return pos[3 * a] < pos[3 * b]; });
+        std::vector<int32_t> ps(3 * (size_t)NumSrc);
+        std::vector<double> fs((size_t)NumSrc);
+        st.src_i0_sorted.resize((size_t)NumSrc);
+        for (int s = 0; s < NumSrc; ++s) {
+            const int o = order[s];
+            ps[3 * s] = pos[3 * o]; ps[3 * s + 1] = pos[3 * o + 1]; ps[3 * s + 2] = pos[3 * o + 2];
+            fs[s] = flux[o];
+            st.src_i0_sorted[s] = pos[3 * o];
+        }
+        ASORA_HIP_TRY(hipMalloc(&st.src_pos_sorted, sizeof(int32_t) * 3 * (size_t)NumSrc));
+        ASORA_HIP_TRY(hipMalloc(&st.src_flux_sorted, sizeof(double) * (size_t)NumSrc));
+        ASORA_HIP_TRY(hipMemcpy(st.src_pos_sorted, ps.data(), sizeof(int32_t) * 3 * (size_t)NumSrc, hipMemcpyHostToDevice));
+        ASORA_HIP_TRY(hipMemcpy(st.src_flux_sorted, fs.data(), sizeof(double) * (size_t)NumSrc, hipMemcpyHostToDevice));
+    }
     st.num_src = NumSrc;
     return 0;
 }
@@ -702,6 +854,11 @@ int asora_do_all_sources(double R, double *coldensh_out, double sig, double dr, 
         return fail(3, "do_all_sources: NumSrc=" + std::to_string(NumSrc) + " exceeds the " +
                            std::to_string(st.num_src) + " sources on the device");
     const size_t bytes = st.ncell * sizeof(double);
+    {
+        bool done = false;
+        if (int rc = do_all_sources_pipelined(R, sig, dr, xh_av, phi_ion, NumSrc, minlogtau, dlogtau, NumTau, done)) return rc;
+        if (done) return 0;
+    }
     ASORA_HIP_TRY(hipMemcpyAsync(st.grid[ASORA_GRID_XH_AV], xh_av, bytes, hipMemcpyHostToDevice, st.stream)); // cu:117
     st.grid_valid[ASORA_GRID_XH_AV] = true;
     if (int rc = do_raytrace(R, sig, dr, 0, NumSrc, minlogtau, dlogtau, NumTau, nullptr)) return rc;

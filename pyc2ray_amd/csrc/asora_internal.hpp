@@ -91,6 +91,11 @@ struct State {
     int32_t *src_pos = nullptr;
     double *src_flux = nullptr;
     int num_src = 0;
+    // the same sources ordered by their first coordinate (pipelined asora_do_all_sources)
+    int32_t *src_pos_sorted = nullptr;
+    double *src_flux_sorted = nullptr;
+    std::vector<int> src_i0_sorted;
+    std::vector<hipEvent_t> pipe_events;
 
     // raytracing geometry tables (built once per (N, R, dr), see raytrace.hip)
     std::vector<void *> geom_owned;
@@ -152,7 +157,7 @@ struct State {
     struct PendingTimer { int which; hipEvent_t e0, e1; };
     std::vector<PendingTimer> pending_timers;     // recorded, not yet resolved
     std::vector<hipEvent_t> free_events;
-    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
+    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1};
     double k_ms[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
     long k_n[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
 };

@@ -932,3 +932,38 @@ def test_uniform_temperature_form_of_the_chemistry_pass_is_bit_identical(asora):
                          c["albpow"], c["colh0"], c["temph0"], c["abu_c"])
     np.testing.assert_allclose(s[1], ref2[1], rtol=1e-9, atol=0)
     assert s[1][N - 1, 3, 5] != a[1][N - 1, 3, 5]
+
+
+@pytest.mark.parametrize("N,R,ns", [(64, 5.5, 40), (72, 12.0, 25), (64, 3.0, 3)])
+def test_pipelined_copies_of_the_drop_in_call_change_nothing(asora, N, R, ns):
+    """libasora.do_all_sources overlaps its upload of xh_av, the trace and the download of phi_ion slab by slab (sources
+    taken in order of their first coordinate).  Same rates as the plain upload-trace-download sequence (up to the order
+    of the atomic sums) and as the oracle; sources near the periodic seam, empty slabs of sources, a second call on
+    the same buffers."""
+    p, lib, capi = asora
+    nd, xh, dr = cases.grid(N, "lognormal", 90 + N, 0.1)
+    pos, flux = cases.sources(N, ns, 91 + N, flux=2.0)
+    pos[0, :3] = [1, N, N - 1]                                   # sources on the first and last planes: reach wraps
+    flux = flux * (1.0 + 0.1 * np.arange(ns))
+    thin, thick, dlog = cases.soft_tables()
+    c = dict(N=N, ndens=nd, xh=xh, dr=dr, pos=pos, flux=flux, R=R, thin=thin, thick=thick, dlogtau=dlog,
+             minlogtau=cases.MINLOGTAU, sig=cases.SIG)
+    p0, f0 = _setup(p, lib, c, N)
+    numtau = thin.shape[0] - 1
+    assert lib.get_option(capi.OPT_PIPELINED_COPIES) == 1
+    piped = _asora_call(lib, c, N, numtau)
+    gam = lib.last_raytrace_counts()[0]
+    piped2 = _asora_call(lib, c, N, numtau)
+    lib.set_option(capi.OPT_PIPELINED_COPIES, 0)
+    try:
+        plain = _asora_call(lib, c, N, numtau)
+    finally:
+        lib.set_option(capi.OPT_PIPELINED_COPIES, 1)
+    assert lib.last_raytrace_counts()[0] == gam
+    np.testing.assert_allclose(piped, plain, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(piped2, plain, rtol=1e-12, atol=0)
+    ref = O.asora_do_all_sources(R, cases.SIG, dr, nd, xh, p0, f0, thin, thick, cases.MINLOGTAU, dlog, NumTau=numtau,
+                                 flags=O.ASORA_MODE)["phi_ion"]
+    np.testing.assert_allclose(piped, ref, rtol=GAMMA_RTOL, atol=0)
+    # the device-resident xh_av the call leaves behind is the uploaded one
+    assert np.array_equal(lib.grid_to_host(capi.GRID_XH_AV, np.empty((N, N, N))), xh)

@@ -27,15 +27,19 @@ lib.density_to_device(nd_flat, N)
 xh_flat = np.ravel(xh).astype("float64", copy=True)
 phi_flat = np.zeros(N ** 3)
 cd_flat = np.zeros(N ** 3)
-for _ in range(2):
-    lib.do_all_sources(R, cd_flat, bench.SIG, dr, nd_flat, xh_flat, phi_flat, ns, N, bench.MINLOGTAU, dlog, thin.shape[0] - 1)
-reps = 10
-t0 = time.perf_counter()
-for _ in range(reps):
-    lib.do_all_sources(R, cd_flat, bench.SIG, dr, nd_flat, xh_flat, phi_flat, ns, N, bench.MINLOGTAU, dlog, thin.shape[0] - 1)
-t = (time.perf_counter() - t0) / reps
-gam, ev = lib.last_raytrace_counts()
-print(json.dumps({"call": "libasora.do_all_sources (H2D xh_av + raytrace + D2H phi_ion)", "N": N, "sources": ns, "R": R,
-                  "s_per_call": t, "raytrace_cell_updates_per_s": gam / t,
-                  "ns_per_source_per_insphere_cell": t * 1e9 / (ns * 4 * np.pi * R ** 3 / 3)}))
+out = {"call": "libasora.do_all_sources (H2D xh_av + raytrace + D2H phi_ion)", "N": N, "sources": ns, "R": R}
+for label, opt in (("pipelined_copies", 1), ("copies_in_turn", 0)):
+    lib.set_option(10, opt)               # ASORA_OPT_PIPELINED_COPIES
+    for _ in range(2):
+        lib.do_all_sources(R, cd_flat, bench.SIG, dr, nd_flat, xh_flat, phi_flat, ns, N, bench.MINLOGTAU, dlog, thin.shape[0] - 1)
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        lib.do_all_sources(R, cd_flat, bench.SIG, dr, nd_flat, xh_flat, phi_flat, ns, N, bench.MINLOGTAU, dlog, thin.shape[0] - 1)
+    t = (time.perf_counter() - t0) / reps
+    gam, ev = lib.last_raytrace_counts()
+    out[label] = {"s_per_call": t, "raytrace_cell_updates_per_s": gam / t,
+                  "ns_per_source_per_insphere_cell": t * 1e9 / (ns * 4 * np.pi * R ** 3 / 3), "checksum": float(phi_flat.sum())}
+lib.set_option(10, 1)
+print(json.dumps(out))
 p.device_close()
