@@ -28,6 +28,7 @@ struct RtParams {
     double sig, dr;
     double minlogtau, dlogtau, numtau_f;
     double lut_k1, lut_k0; // table index = 1 + (log10 tau - minlogtau)/dlogtau = lut_k1*log2(tau) + lut_k0
+    double tau_zero;       // thick cells with tau_in >= tau_zero get exactly +0 (both lookups clamp): not added; +inf = add everything
     int NumTau, table_len;
     int fortran_consts, grey, z_transposed;
     int src_begin, src_count;
@@ -157,7 +158,7 @@ struct State {
     struct PendingTimer { int which; hipEvent_t e0, e1; };
     std::vector<PendingTimer> pending_timers;     // recorded, not yet resolved
     std::vector<hipEvent_t> free_events;
-    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1};
+    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0};
     double k_ms[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
     long k_n[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
 };
@@ -208,7 +209,7 @@ struct SubboxParams {
     double sig, dr, R;          // R = R_max_LLS in cells
     double numtau_f, lut_k1, lut_k0;
     int table_len, ablate;
-    int grey, heat;
+    int grey, heat, add_zero;   // add_zero: ASORA_OPT_ADD_ZERO_RATES
     int src_begin, src_count;   // batch of sources
     int flux_src;               // >= 0: every source shines with the flux of this one (f90:500,503); -1: its own
     int dump_src;               // source whose column densities are returned (the last one), or -1

@@ -379,13 +379,20 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
             const double tau_in = mul_unfused(cd_in, sig), tau_out = mul_unfused(cd_out, sig);   // un-fused, see rate_issue
             // TAU_PHOTO_LIMIT: rates.cu:7 (double 1e-7) or photorates.f90:69 (single 1e-7 promoted)
             const double limit = p.fortran_consts ? (double)1.0e-7f : 1.0e-7;
-            const double pref = flux / vol_nhi;
             const double dtau = tau_out - tau_in;
             const bool thick = fabs(dtau) > limit;
             const double tau_thin = p.fortran_consts ? tau_in : tau_out;                 // photorates.f90:121 / rates.cu:37
             // one code path for both kinds of cell: per-lane table offset and arguments
             const double2 *tab = p.tables + (thick ? 0 : p.table_len);
 #if ASORA_LATE_LOOKUP
+            // A thick cell whose tau_in lies beyond the last table entry gets pref * (T_last - T_last) = exactly +0
+            // (every cell further than a few mean free paths from its source in a neutral medium): adding it changes
+            // nothing, so the atomic is not issued -- and when no lane of the wave has anything to add, neither are the
+            // division, the logarithms and the lookups.  p.tau_zero is +inf with ASORA_OPT_ADD_ZERO_RATES.  (pref must be
+            // finite for the product to be 0 and not NaN: vol_nhi is checked instead of forming pref first.)
+            const bool zero_rate = thick && tau_in >= p.tau_zero && fabs(vol_nhi) > 1e-250 && (vol_nhi - vol_nhi == 0.0);
+            const bool add = rated && !zero_rate;
+            const bool wave_adds = __builtin_amdgcn_readfirstlane((int)__any(add)) != 0;
             {   // the previous step's lookups have had a whole step to arrive: form its rate now, issue this step's
                 // lookups, then add the rate behind them
                 const double ta = lookup_value(pend_A), tb = lookup_value(pend_B);
@@ -395,17 +402,23 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
                     const double ha = lookup_heat(pend_A), hb = lookup_heat(pend_B);
                     h_prev = pend_thick ? pend_pref * (ha - hb) : pend_pref * pend_dtau * ha;
                 }
-                const Lookup A2 = lookup_issue<HEAT>(tab, thick ? tau_in : tau_thin, p, logtab);
-                const Lookup B2 = lookup_issue<HEAT>(tab, thick ? tau_out : tau_thin, p, logtab);
+                Lookup A2 = pend_A, B2 = pend_B;
+                double pref = 0.0;
+                if (wave_adds) {
+                    pref = flux / vol_nhi;
+                    A2 = lookup_issue<HEAT>(tab, thick ? tau_in : tau_thin, p, logtab);
+                    B2 = lookup_issue<HEAT>(tab, thick ? tau_out : tau_thin, p, logtab);
+                }
                 if (late_ok) {
                     ASORA_RATE_ATOMIC(late_dst, v_prev);
                     if (HEAT) unsafeAtomicAdd(p.heat + (late_dst - p.phi), h_prev);
                 }
                 pend_A = A2; pend_B = B2; pend_thick = thick; pend_pref = pref; pend_dtau = dtau;
                 late_dst = dst;
-                late_ok = rated;
+                late_ok = add;
             }
 #elif ASORA_LATE_ATOMIC
+            const double pref = flux / vol_nhi;
             const Lookup A = lookup_issue<HEAT>(tab, thick ? tau_in : tau_thin, p, logtab);
             const Lookup B = lookup_issue<HEAT>(tab, thick ? tau_out : tau_thin, p, logtab);
             if (late_ok) {       // the previous step's rate, behind this step's lookups in the memory pipeline
@@ -423,6 +436,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
                 late_ok = rated;
             }
 #else
+            const double pref = flux / vol_nhi;
             const Lookup A = lookup_issue<HEAT>(tab, thick ? tau_in : tau_thin, p, logtab);
             const Lookup B = lookup_issue<HEAT>(tab, thick ? tau_out : tau_thin, p, logtab);
             if (rated) {
@@ -1038,6 +1052,14 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
     if (int rc = ensure_geometry(st, p, threads, units)) return rc;
     p.lut_k1 = 0.30102999566398119521 / p.dlogtau;      // log10(2)/dlogtau
     p.lut_k0 = 1.0 - p.minlogtau / p.dlogtau;
+    // optical depth from which BOTH lookups of a thick cell return the same table value (index clamped to NumTau, or on
+    // the last pair of the device table, whose slope is 0): 0.01 index units beyond the exact point, far more than the
+    // 1e-12 the device's log2 can be off by
+    p.tau_zero = INFINITY;
+    if (!st.opt[ASORA_OPT_ADD_ZERO_RATES] && !p.grey && p.lut_k1 > 0.0) {
+        const double last = std::min(p.numtau_f, (double)(p.table_len - 1));
+        p.tau_zero = std::exp2((last + 0.01 - p.lut_k0) / p.lut_k1);
+    }
 
     const size_t slots = ((size_t)p.max_cells + 2) & ~(size_t)1;   // max_cells + zero slot, rounded to even (16-B alignment)
     // small tables (log table, 1/s, three wrapped-coordinate tables) at fixed capacity, then the shell buffers
