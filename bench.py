@@ -343,10 +343,6 @@ def main():
     lib.grid_to_device(_capi.GRID_NDENS, ndens)
     lib.grid_to_device(_capi.GRID_TEMP, temp)
     lib.grid_to_device(_capi.GRID_XH, xh)
-    # Every rated (source, cell) pair is looked up and added, as the reference does -- also where the rate is exactly +0
-    # (in this optically thick medium: wherever tau exceeds the last table entry, i.e. most pairs).  The library's
-    # default leaves those no-op additions out; that is timed separately below and reported as `without_zero_additions`.
-    lib.set_option(_capi.OPT_ADD_ZERO_RATES, 1)
     lib.set_option(_capi.OPT_Z_TRANSPOSED, args.z_transposed)
     lib.set_option(_capi.OPT_BLOCK_THREADS, args.block_threads)
     lib.set_option(_capi.OPT_SECTORS, args.sectors)
@@ -413,29 +409,6 @@ def main():
     ch_ms, ch_n = lib.kernel_time_ms(_capi.KERNEL_CHEMISTRY)
     pr_ms, pr_n = lib.kernel_time_ms(_capi.KERNEL_PREP)
     fi_ms, fi_n = lib.kernel_time_ms(_capi.KERNEL_FINISH)
-
-    without_zero = None
-    if comm is None:
-        # the same K steps with the library's default (exactly-zero rates are not added, waves with nothing to add skip
-        # the lookups): same results, less work on this medium -- NOT the headline
-        lib.set_option(_capi.OPT_ADD_ZERO_RATES, 0)
-        for _ in range(max(W, 2)):
-            step()
-        lib.set_option(_capi.OPT_TIMING, 1)
-        lib.kernel_time_reset()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(K):
-            step()
-        fence()
-        dt_z = time.perf_counter() - t0
-        lib.set_option(_capi.OPT_TIMING, 0)
-        z_rt, z_n = lib.kernel_time_ms(_capi.KERNEL_RAYTRACE)
-        without_zero = {"ms_per_step": dt_z / K * 1e3, "raytrace_ms": z_rt / max(z_n, 1),
-                        "value": (gamma_cells + N ** 3) * K / dt_z,
-                        "note": "library default: a rate of exactly +0 (optical depth beyond the last table entry) is not added; "
-                                "bit-identical rates, fewer atomics and lookups; depends on the medium, so not the headline"}
-        lib.set_option(_capi.OPT_ADD_ZERO_RATES, 1)
 
     tot_gamma = gamma_cells
     if comm is not None:
@@ -557,7 +530,6 @@ def main():
             "chemistry_achieved_GBs": ch_achieved,
         },
         "raytrace_ns_per_source_per_insphere_cell": (rt_ms / max(rt_n, 1)) * 1e6 / (max(n_local, 1) * insphere),
-        "without_zero_additions": without_zero,
     }
 
     if world == 1 and args.cpu_sources > 0:

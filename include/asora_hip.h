@@ -257,11 +257,12 @@ enum {
     /* 1 (default): asora_do_all_sources overlaps the upload of xh_av, the trace and the download of phi_ion slab by slab
      *    (when all uploaded sources are traced and R is small against the mesh); 0: upload, trace, download in turn. */
     ASORA_OPT_PIPELINED_COPIES = 10,
-    /* 0 (default): a rate that is exactly +0 -- a thick cell whose optical depth lies beyond the last table entry, where
-     *    both lookups return the same value -- is not added (bit-identical result, no atomic; waves without anything to add
-     *    skip the lookups too).  1: every rated cell is looked up and added, as the reference does (rates.cu:16-41,
-     *    raytracing.cu:328); bench.py times this. */
-    ASORA_OPT_ADD_ZERO_RATES = 11,
+    /* 1: a rate that is exactly +0 -- a thick cell whose optical depth lies beyond the last table entry, where both
+     *    lookups return the same value -- is not added (bit-identical result, no atomic; waves with nothing to add skip
+     *    the division, logarithms and lookups too).  Pays where r_RT x (optical depth of a cell) exceeds the table's
+     *    last entry (the benchmark medium at r_RT = 64: -25 %); costs 4.5 % where nothing can be left out, hence
+     *    0 (default): every rated cell is looked up and added, as the reference does (rates.cu:16-41, raytracing.cu:328). */
+    ASORA_OPT_SKIP_ZERO_RATES = 11,
     ASORA_OPT_COUNT = 12
 };
 int asora_set_option(int option, int value);

@@ -28,7 +28,7 @@ struct RtParams {
     double sig, dr;
     double minlogtau, dlogtau, numtau_f;
     double lut_k1, lut_k0; // table index = 1 + (log10 tau - minlogtau)/dlogtau = lut_k1*log2(tau) + lut_k0
-    double tau_zero;       // thick cells with tau_in >= tau_zero get exactly +0 (both lookups clamp): not added; +inf = add everything
+    double tau_zero;       // ASORA_OPT_SKIP_ZERO_RATES: thick cells with tau_in >= tau_zero get exactly +0 (both lookups clamp) and are not added; +inf = add everything
     int NumTau, table_len;
     int fortran_consts, grey, z_transposed;
     int src_begin, src_count;
@@ -209,7 +209,7 @@ struct SubboxParams {
     double sig, dr, R;          // R = R_max_LLS in cells
     double numtau_f, lut_k1, lut_k0;
     int table_len, ablate;
-    int grey, heat, add_zero;   // add_zero: ASORA_OPT_ADD_ZERO_RATES
+    int grey, heat, add_zero;   // add_zero = 0: ASORA_OPT_SKIP_ZERO_RATES
     int src_begin, src_count;   // batch of sources
     int flux_src;               // >= 0: every source shines with the flux of this one (f90:500,503); -1: its own
     int dump_src;               // source whose column densities are returned (the last one), or -1

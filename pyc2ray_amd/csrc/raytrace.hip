@@ -174,7 +174,7 @@ __device__ __forceinline__ double photo_rate_per_atom(double flux, double cd_in,
 constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_RATE = 1u << 29, CELL_NEG = 1u << 28,
                    CELL_SLOT_MASK = (1u << 28) - 1;   // NEG: the cell lies on the mirrored side of the unit's merge axis
 
-template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP, bool HEAT, int TABCAP>
+template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP, bool HEAT, int TABCAP, bool SKIP_ZERO = false>
 __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_kernel(const RtParams p)
 {
     extern __shared__ double lds_raw[];
@@ -385,14 +385,18 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
             // one code path for both kinds of cell: per-lane table offset and arguments
             const double2 *tab = p.tables + (thick ? 0 : p.table_len);
 #if ASORA_LATE_LOOKUP
-            // A thick cell whose tau_in lies beyond the last table entry gets pref * (T_last - T_last) = exactly +0
-            // (every cell further than a few mean free paths from its source in a neutral medium): adding it changes
-            // nothing, so the atomic is not issued -- and when no lane of the wave has anything to add, neither are the
-            // division, the logarithms and the lookups.  p.tau_zero is +inf with ASORA_OPT_ADD_ZERO_RATES.  (pref must be
-            // finite for the product to be 0 and not NaN: vol_nhi is checked instead of forming pref first.)
-            const bool zero_rate = thick && tau_in >= p.tau_zero && fabs(vol_nhi) > 1e-250 && (vol_nhi - vol_nhi == 0.0);
-            const bool add = rated && !zero_rate;
-            const bool wave_adds = __builtin_amdgcn_readfirstlane((int)__any(add)) != 0;
+            // SKIP_ZERO (ASORA_OPT_SKIP_ZERO_RATES): a thick cell whose tau_in lies beyond the last table entry gets
+            // pref * (T_last - T_last) = exactly +0; adding it changes nothing, so the atomic is not issued -- and when no
+            // lane of the wave has anything to add, neither are the division, the logarithms and the lookups.  (pref must
+            // be finite for the product to be 0 and not NaN: vol_nhi is checked instead of forming pref first.)  A kernel
+            // variant of its own: the test and the branch cost 4.5 % where nothing can be left out.
+            bool add = rated;
+            bool wave_adds = true;
+            if (SKIP_ZERO) {
+                const bool zero_rate = thick && tau_in >= p.tau_zero && fabs(vol_nhi) > 1e-250 && (vol_nhi - vol_nhi == 0.0);
+                add = rated && !zero_rate;
+                wave_adds = __builtin_amdgcn_readfirstlane((int)__any(add)) != 0;
+            }
             {   // the previous step's lookups have had a whole step to arrive: form its rate now, issue this step's
                 // lookups, then add the rate behind them
                 const double ta = lookup_value(pend_A), tb = lookup_value(pend_B);
@@ -1033,6 +1037,11 @@ static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t ld
     } while (0)
     if (T == 256 && dump) { if (use_lds) ASORA_LAUNCH(false, true, false); else ASORA_LAUNCH(true, true, false); }
     else if (heat)        { if (use_lds) ASORA_LAUNCH(false, false, true); else ASORA_LAUNCH(true, false, true); }
+    else if (use_lds && std::isfinite(q.tau_zero)) {       // ASORA_OPT_SKIP_ZERO_RATES: the variant that leaves exact zeros out
+        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, false, TABCAP, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, false, TABCAP, true>), dim3(grid), dim3(T), lds_bytes, stream, q);
+    }
     else                  { if (use_lds) ASORA_LAUNCH(false, false, false); else ASORA_LAUNCH(true, false, false); }
 #undef ASORA_LAUNCH
     ASORA_HIP_TRY(hipGetLastError());
@@ -1056,7 +1065,7 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
     // the last pair of the device table, whose slope is 0): 0.01 index units beyond the exact point, far more than the
     // 1e-12 the device's log2 can be off by
     p.tau_zero = INFINITY;
-    if (!st.opt[ASORA_OPT_ADD_ZERO_RATES] && !p.grey && p.lut_k1 > 0.0) {
+    if (st.opt[ASORA_OPT_SKIP_ZERO_RATES] && !p.grey && p.lut_k1 > 0.0) {
         const double last = std::min(p.numtau_f, (double)(p.table_len - 1));
         p.tau_zero = std::exp2((last + 0.01 - p.lut_k0) / p.lut_k1);
     }

@@ -127,8 +127,8 @@ __global__ void __launch_bounds__(SB_THREADS) subbox_sweep_kernel(const SubboxPa
                     if (HEAT) heat = pref * dtau * lookup_heat(B);
                 }
             }
-            // (a rate of exactly +0 -- both lookups beyond the last table entry -- changes nothing: not added, unless
-            //  ASORA_OPT_ADD_ZERO_RATES; NaN != 0, so the reference's NaN for nHI = 0 is still deposited)
+            // (a rate of exactly +0 -- both lookups beyond the last table entry -- changes nothing: it is not added
+            //  with ASORA_OPT_SKIP_ZERO_RATES; NaN != 0, so the reference's NaN for nHI = 0 is still deposited)
             const double dphi = phi / nHI;                                            // f90:531-535
             if (p.add_zero || dphi != 0.0) unsafeAtomicAdd(p.phi + idx, dphi);
             if (HEAT) { const double dheat = heat / nHI; if (p.add_zero || dheat != 0.0) unsafeAtomicAdd(p.heat_grid + idx, dheat); }

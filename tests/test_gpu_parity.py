@@ -970,9 +970,9 @@ def test_pipelined_copies_of_the_drop_in_call_change_nothing(asora, N, R, ns):
 
 
 def test_leaving_out_exactly_zero_rates_changes_nothing(asora):
-    """Default: a thick cell whose optical depth lies beyond the last table entry gets pref * (T_last - T_last) = +0 and
-    is not added (no atomic; waves with nothing to add skip the lookups).  With ASORA_OPT_ADD_ZERO_RATES every rated cell
-    is looked up and added.  One source (no summation-order freedom): the two grids must be IDENTICAL, zeros included,
+    """With ASORA_OPT_SKIP_ZERO_RATES a thick cell whose optical depth lies beyond the last table entry, which gets
+    pref * (T_last - T_last) = +0, is not added (no atomic; waves with nothing to add skip the lookups); by default every
+    rated cell is looked up and added.  One source (no summation-order freedom): the two grids must be IDENTICAL, zeros included,
     in an optically thick medium where most cells are beyond the table, in a thin one where none is, and with NumTau
     given as the table length and as length - 1."""
     p, lib, capi = asora
@@ -980,7 +980,7 @@ def test_leaving_out_exactly_zero_rates_changes_nothing(asora):
     thin, thick, dlog = cases.soft_tables(400)
     pos = np.array([[20], [31], [7]])
     flux = np.array([2.5])
-    for tau_cell in (60.0, 3.0, 1e-3):
+    for tau_cell in (3000.0, 3.0, 1e-3):
         nd, xh, dr = cases.grid(N, "lognormal", 5, tau_cell, xlo=1e-4, xhi=1e-3)
         if p.cuda_is_init():
             p.device_close()
@@ -992,12 +992,12 @@ def test_leaving_out_exactly_zero_rates_changes_nothing(asora):
         lib.grid_to_device(capi.GRID_XH_AV, xh)
         for numtau in (thin.shape[0], thin.shape[0] - 1):
             out = []
-            for add_zero in (0, 1):
-                lib.set_option(capi.OPT_ADD_ZERO_RATES, add_zero)
+            for skip in (1, 0):
+                lib.set_option(capi.OPT_SKIP_ZERO_RATES, skip)
                 try:
                     lib.raytrace_device(1000.0, cases.SIG, dr, 0, 1, cases.MINLOGTAU, dlog, numtau)
                 finally:
-                    lib.set_option(capi.OPT_ADD_ZERO_RATES, 0)
+                    lib.set_option(capi.OPT_SKIP_ZERO_RATES, 0)
                 out.append(lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N))))
             assert np.array_equal(out[0], out[1])
             ref = O.asora_do_all_sources(1000.0, cases.SIG, dr, nd, xh, p0, f0, thin, thick, cases.MINLOGTAU, dlog,
@@ -1006,4 +1006,4 @@ def test_leaving_out_exactly_zero_rates_changes_nothing(asora):
             w = ref != 0
             np.testing.assert_allclose(out[0][w], ref[w], rtol=GAMMA_RTOL, atol=0)
         zeros = float((out[0] == 0).mean())
-        assert (zeros > 0.5) if tau_cell == 60.0 else (zeros < 0.05 or tau_cell == 3.0)
+        assert (zeros > 0.5) if tau_cell == 3000.0 else (zeros < 0.5)
