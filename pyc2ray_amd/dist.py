@@ -172,6 +172,14 @@ class TorchComm:
         #: how the per-rank rate grids are summed: "slab" (SlabPlan: planes to their owners, slab chemistry, xh_av
         #: back) or "allreduce" (full-grid all-reduce, chemistry replicated on every rank)
         self.exchange = os.environ.get("PYC2RAY_AMD_EXCHANGE", "slab")
+        # Bring the communicator up with a collective EVERY rank takes part in.  The slab exchange is point-to-point
+        # and a rank with nothing to send or receive skips it; if that were the first operation on the process group,
+        # the ranks that do take part would wait for the others in the communicator's set-up.
+        import torch
+        t = torch.zeros(1, dtype=torch.float64)
+        if self._backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, group=self._group)
 
     # -- mpi4py-flavoured surface ---------------------------------------------------------------
     def Get_rank(self):
