@@ -901,10 +901,10 @@ int asora_chemistry_device(double dt, double bh00, double albpow, double colh0, 
     clear_error();
     if (int rc = require_init("chemistry_device")) return rc;
     State &st = g_state;
-    static const int need[] = {ASORA_GRID_NDENS, ASORA_GRID_TEMP, ASORA_GRID_XH, ASORA_GRID_XH_AV,
-                               ASORA_GRID_XH_INTERMED, ASORA_GRID_PHI_ION};
+    static const int need[] = {ASORA_GRID_NDENS, ASORA_GRID_TEMP, ASORA_GRID_XH, ASORA_GRID_XH_AV, ASORA_GRID_PHI_ION};
     for (int g : need)
         if (!st.grid_valid[g]) return fail(4, "chemistry_device: grid " + std::to_string(g) + " holds no data");
+    st.grid_valid[ASORA_GRID_XH_INTERMED] = true;
     ChemParams p;
     p.ncell = st.ncell;
     p.dt = dt; p.bh00 = bh00; p.albpow = albpow; p.colh0 = colh0; p.temph0 = temph0; p.abu_c = abu_c;
@@ -927,10 +927,11 @@ int asora_chemistry_range(double dt, double bh00, double albpow, double colh0, d
     clear_error();
     if (int rc = require_init("chemistry_range")) return rc;
     State &st = g_state;
-    static const int need[] = {ASORA_GRID_NDENS, ASORA_GRID_TEMP, ASORA_GRID_XH, ASORA_GRID_XH_AV,
-                               ASORA_GRID_XH_INTERMED, ASORA_GRID_PHI_ION};
+    // (xh_intermed is only ever written by the pass: chemistry.f90:107)
+    static const int need[] = {ASORA_GRID_NDENS, ASORA_GRID_TEMP, ASORA_GRID_XH, ASORA_GRID_XH_AV, ASORA_GRID_PHI_ION};
     for (int g : need)
         if (!st.grid_valid[g]) return fail(4, "chemistry_range: grid " + std::to_string(g) + " holds no data");
+    st.grid_valid[ASORA_GRID_XH_INTERMED] = true;
     if (i_begin < 0 || i_count < 0 || i_begin + i_count > st.N) return fail(4, "chemistry_range: bad plane range");
     if (i_count == 0 && !first) return 0;
     if (i_count == 0) {       // an empty first slab still resets the reductions
