@@ -519,7 +519,11 @@ struct HostGeom {
 
 inline bool inside_radius_reference(int a, int b, int c, double dr, double R2)
 {
-    // raytracing.cu:302-305,315 as the reference evaluates it (un-fused on the host)
+    // raytracing.cu:302-305,315 evaluated with every operation rounded on its own, i.e. as the Fortran path
+    // (raytracing.f90:452-456,474) and the oracle evaluate it.  The CUDA library itself is built with nvcc's default
+    // -fmad=true, which may contract xs*xs + ys*ys + zs*zs into fused multiply-adds: for a lattice point EXACTLY on the
+    // sphere (integer R with integer solutions, e.g. (6,8,0) at R = 10) a CUDA build can classify a handful of surface
+    // cells differently.  Parity on such cells is claimed against the un-fused evaluation only.
     volatile double xs = dr * (double)a, ys = dr * (double)b, zs = dr * (double)c;
     volatile double xx = xs * xs, yy = ys * ys, zz = zs * zs;
     volatile double d2 = xx + yy;

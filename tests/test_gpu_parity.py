@@ -1007,3 +1007,41 @@ def test_leaving_out_exactly_zero_rates_changes_nothing(asora):
             np.testing.assert_allclose(out[0][w], ref[w], rtol=GAMMA_RTOL, atol=0)
         zeros = float((out[0] == 0).mean())
         assert (zeros > 0.5) if tau_cell == 3000.0 else (zeros < 0.5)
+
+
+def test_randomised_time_steps_of_the_device_resident_loop_against_the_oracle_loop(asora, tmp_path):
+    """Seeded sweep of whole time steps through evolve3D (device-resident loop): odd and even meshes (tiles of the fused
+    pass cut by the mesh edge), radii from one cell to beyond the box, 1 to 6 sources (criterion (NumSrc-1)/3 = 0 for one
+    source: only the relative-change test can end the loop), uniform and non-uniform temperature grids (both forms of the
+    fused pass), two consecutive steps (the second starts from a grid with fronts).  Iteration counts, fields and the
+    returned rates against the oracle's restatement of the reference loop."""
+    from evolve_oracle import evolve3D_oracle
+    p, lib, capi = asora
+    rng = np.random.default_rng(777)
+    thin, thick, dlog = cases.soft_tables(600)
+    for trial in range(10):
+        N = int(rng.choice([9, 12, 17, 20, 33]))
+        ns = int(rng.integers(1, 7))
+        R = float(rng.choice([1.0, 2.5, 4.0, N / 3.0, N * 0.8, 1000.0]))
+        nd, xh, dr = cases.grid(N, "lognormal", 500 + trial, float(10 ** rng.uniform(-1.5, 0.3)), xlo=1e-4, xhi=2e-3)
+        temp = np.full((N, N, N), 1e4) if trial % 2 else 10 ** rng.uniform(3.7, 4.3, size=(N, N, N))
+        pos = 1 + rng.integers(0, N, size=(3, ns))
+        flux = rng.uniform(0.5, 2.0, size=ns) * 3e-4 * (N / 16.0) ** 3 / ns
+        dt = 3.15576e13 * float(rng.choice([0.5, 2.0, 5.0]))
+        if p.cuda_is_init():
+            p.device_close()
+        p.device_init(N, 8)
+        p.photo_table_to_device(thin, thick)
+        x, x_ref = xh, xh
+        for step in range(2):
+            x, phi = p.evolve3D(dt, dr, flux, pos, True, 1000, N, 1e-2, temp, nd, x, thin, thick, cases.MINLOGTAU, dlog, R,
+                                1e-4, cases.SIG, cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C,
+                                logfile=str(tmp_path / "log"), quiet=True)
+            x_ref, phi_ref, niter_ref, _ = evolve3D_oracle(dt, dr, flux, pos, temp, nd, x_ref, thin, thick, cases.MINLOGTAU,
+                                                           dlog, R, 1e-4, cases.SIG, cases.BH00, cases.ALBPOW, cases.COLH0,
+                                                           cases.TEMPH0, cases.ABU_C)
+            tag = f"trial {trial} step {step}: N={N} ns={ns} R={R:g} dt={dt:.3g} uniform_T={bool(trial % 2)}"
+            assert p.evolve._evolve.last_niter == niter_ref, tag
+            np.testing.assert_allclose(x, x_ref, rtol=1e-8, atol=0, err_msg=tag)
+            scale = phi_ref.max()
+            np.testing.assert_allclose(phi, phi_ref, rtol=1e-7, atol=1e-13 * scale, err_msg=tag)
