@@ -52,7 +52,15 @@ for R in a.R:
     t_gpu = (time.perf_counter() - t0) / a.reps
     k_ms, k_n = asora.kernel_time_ms(0)
     asora.set_option(2, 0)
-    out = {"call": "libc2ray.raytracing.do_all_sources on the GPU (host grids in/out, Fortran order)", "N": N, "shell_buffers": "global memory" if a.global_shells else "LDS when they fit",
+    m = int(R)
+    rr = np.arange(-m, m + 1)
+    rated = int(((rr[:, None, None] ** 2 + rr[None, :, None] ** 2 + rr[None, None, :] ** 2) <= R * R).sum()) * ns
+    swept = (2 * sub + 1) ** 3 * (nbox // max(ns, 1)) ** 0 * ns if nbox == ns else None      # one box of +-subboxsize per source
+    algo_bytes = 32 * rated + 8 * ((swept - rated) if swept else 0)                          # 32 B per rated cell, 8 B (nHI) per carried-on cell
+    out = {"call": "libc2ray.raytracing.do_all_sources on the GPU (host grids in/out, Fortran order)", "N": N,
+           "roofline_sweep_kernel": {"bound": "hbm", "algorithmic_bytes_per_call": algo_bytes, "rated_cells": rated, "swept_cells": swept,
+                                     "achieved_GBs": algo_bytes / (k_ms / a.reps * 1e-3) / 1e9, "peak_GBs": 8000.0,
+                                     "frac": algo_bytes / (k_ms / a.reps * 1e-3) / 1e9 / 8000.0}, "shell_buffers": "global memory" if a.global_shells else "LDS when they fit",
            "sources": ns, "R": R, "subboxsize": sub, "loss_fraction": a.loss_fraction, "s_per_call": t_gpu,
            "sweep_kernels_ms_per_call": k_ms / a.reps, "sweep_launches_per_call": k_n / a.reps,
            "nsubbox": nbox, "photon_loss": loss}
