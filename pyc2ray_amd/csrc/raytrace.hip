@@ -1012,6 +1012,9 @@ static void pick_launch_shape(const State &st, double R, int N, int src_count, b
     else { units = 12; threads = 512; }
     // Few sources (fewer workgroups than CUs): the time of the call is the time of ONE workgroup, so cut a source
     // into more (24 sectors) and wider pieces.  One source, 128^3, R = 64: 0.235 -> 0.146 ms (tools/sweep_single_source.sh)
+    // A few dozen sources (workgroups for half the CUs' slots at most): still one round, wider workgroups finish it sooner
+    // (64 sources, R = 32: pairs x 256 threads 0.183 ms against 0.202 with 128; tools/sweep_mid_counts.sh)
+    if ((long)src_count * 12 <= (long)st.cu_count * 4 && units == 12 && threads == 128) threads = 256;
     if ((long)src_count * 12 < (long)st.cu_count) {
         units = 24;
         if (est_cells > 900.0) threads = std::max(threads, 512);
