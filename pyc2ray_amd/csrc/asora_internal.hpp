@@ -19,6 +19,8 @@ struct OctGeomDev {
     int info;                    // sign bits of the unit | (merge axis + 1) << 3 | rates-the-source-cell << 5
 };
 
+constexpr int MAX_UNITS = 96;   // workgroups per source: 8 octants, 12 mirrored sector pairs, 24 sectors or 96 sector wedges
+
 // Parameters of one raytrace launch (raytrace.hip)
 struct RtParams {
     int N;
@@ -34,8 +36,9 @@ struct RtParams {
     int src_begin, src_count;
     int shape_src_count;   // source count the launch shape is chosen for (the whole call's, not a pipelined range's)
     int ablate;            // diagnostics only (env ASORA_ABLATE): 1 = no rate atomics, 2 = no rates
-    OctGeomDev geom[24];        // by value: pointers read from the kernarg segment are known-global to the compiler
-    int units;                  // workgroups per source: 8 octants, 24 octant-sectors, or 12 mirrored sector pairs
+    OctGeomDev geom[MAX_UNITS]; // by value: pointers read from the kernarg segment are known-global to the compiler
+    int units;                  // workgroups per source: 8 octants, 24 octant-sectors, 12 mirrored sector pairs, 96 sector wedges
+    int spread;                 // 1: block b = (source b / units, unit b % units) -- a source's units on different XCDs
     const double2 *logtab;      // 128 x {1/c, log2 c}
     unsigned ncell;             // N^3: the [k][j][i] copy of a grid starts ncell elements after its [i][j][k] form
     const double *nhi;          // nHI, [i][j][k] then [k][j][i]
@@ -100,7 +103,7 @@ struct State {
 
     // raytracing geometry tables (built once per (N, R, dr), see raytrace.hip)
     std::vector<void *> geom_owned;
-    OctGeomDev geom_host[24];               // device pointers of the unit tables
+    OctGeomDev geom_host[MAX_UNITS];        // device pointers of the unit tables
     int geom_units = 0;
     double2 *logtab_dev = nullptr;          // log2 table (ensure_logtab), lives until the runtime is torn down
     bool geom_valid = false;

@@ -183,12 +183,19 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
     const int blk = blockIdx.x;
     // blocks b and b+8 share an XCD (round-robin dispatch): keep the 8 octants of one source
     // on one XCD so that they share its L2 lines of nHI.  Speed only, never correctness.
-    // p.units workgroups per source (8, 24 or 12: see ensure_geometry)
-    const int src_local = (blk & 7) + 8 * (blk / (8 * p.units));
+    // p.units workgroups per source (8, 24, 12 or 96: see ensure_geometry).
+    // p.spread (a handful of sources): consecutive blocks are the units of ONE source, i.e. they go to different XCDs --
+    // with the grouping above a single source would keep all its workgroups on one XCD's 32 CUs.
+    int src_local, unit;
+    if (p.spread) {
+        src_local = blk / p.units;
+        unit = blk % p.units;
+    } else {
+        src_local = (blk & 7) + 8 * (blk / (8 * p.units));
+        unit = (blk >> 3) % p.units;
+    }
 #if ASORA_UNITS_LARGEST_FIRST
-    const int unit = p.units - 1 - (blk >> 3) % p.units;   // sector units: z (most cells) first, x (fewest) last in dispatch order
-#else
-    const int unit = (blk >> 3) % p.units;
+    unit = p.units - 1 - unit;   // sector units: z (most cells) first, x (fewest) last in dispatch order
 #endif
     if (src_local >= p.src_count) return;
     const int ns = p.src_begin + src_local;
@@ -550,6 +557,7 @@ struct UnitSpec {
     int merge_axis = -1;
     int ext[3] = {0, 0, 0};   // periodic-window extent of each axis on the side this unit looks at
     int ext_neg = 0;          // extent on the mirrored side of merge_axis
+    int wedge = -1;           // 0..3: a quarter of the sector (restrict_to_wedge), -1: the whole unit
 };
 
 void build_unit_geometry(HostGeom &h, const UnitSpec &us, double R, double dr, int q_max, uint32_t zero_slot_marker,
@@ -678,6 +686,82 @@ void build_unit_geometry(HostGeom &h, const UnitSpec &us, double R, double dr, i
     for (int q = 0; q < 4 * RT_THREADS; ++q) { h.cellA.push_back(pad_a); h.cellB.push_back(pad_b); }
 }
 
+// A quarter of a sector, as a unit of its own: for a handful of sources the call lasts as long as ONE workgroup, so a
+// source is cut into more of them.  The own-face cells of a sector are split by their transverse offsets (U, V) of
+// shell s into four wedges, 2U > s and 2V > s or not (every shell is partitioned exactly).  A wedge is not closed under
+// the interpolation's dependencies -- a cell reads (U-1, V-1) ... (U, V) of shell s-1, so the cone that feeds a wedge
+// widens towards the source -- hence the unit is the wedge's RATED cells plus everything they (transitively) read:
+// found by marking backwards from the outermost shell through the corner links of the full sector's tables, then
+// renumbering the shell-buffer slots of what is kept.  Evaluations double (each wedge re-derives the inner part of the
+// sector), workgroups quadruple: the single-source trace gets about twice as fast.
+HostGeom restrict_to_wedge(const HostGeom &full, int wedge, int RT_THREADS, uint32_t zero_slot_marker)
+{
+    struct Entry { uint4 a, b; };
+    std::vector<std::vector<Entry>> shells;
+    {
+        std::vector<Entry> cur;
+        const size_t nent = (size_t)full.nsteps * RT_THREADS;
+        for (size_t st0 = 0; st0 < nent; st0 += RT_THREADS) {
+            for (int q = 0; q < RT_THREADS; ++q)
+                if (full.cellA[st0 + q].y & CELL_VALID) cur.push_back({full.cellA[st0 + q], full.cellB[st0 + q]});
+            if (full.cellA[st0].y & CELL_LAST) { shells.push_back(cur); cur.clear(); }
+        }
+    }
+    auto in_wedge = [wedge](const uint4 &a) -> bool {
+        if (!(a.y & CELL_RATE)) return false;
+        const int ca = a.x & 1023, cb = (a.x >> 10) & 1023, cc = (a.x >> 20) & 1023, face = a.x >> 30;
+        const int s = std::max(ca, std::max(cb, cc));
+        const int U = face == 0 ? cb : ca, V = face == 2 ? cb : cc;
+        return ((2 * U > s ? 1 : 0) | (2 * V > s ? 2 : 0)) == wedge;
+    };
+    // backward marking: what the wedge's rated cells read, transitively
+    std::vector<std::vector<char>> keep(shells.size());
+    for (size_t si = 0; si < shells.size(); ++si) {
+        keep[si].assign(shells[si].size(), 0);
+        for (size_t q = 0; q < shells[si].size(); ++q) keep[si][q] = in_wedge(shells[si][q].a) ? 1 : 0;
+    }
+    for (size_t si = shells.size(); si-- > 1;)
+        for (size_t q = 0; q < shells[si].size(); ++q) {
+            if (!keep[si][q]) continue;
+            const uint32_t c[4] = {shells[si][q].b.x, shells[si][q].b.y, shells[si][q].b.z, shells[si][q].b.w};
+            for (uint32_t slot : c) if (slot != zero_slot_marker) keep[si - 1][slot] = 1;     // slot == rank in its shell
+        }
+    HostGeom h;
+    h.S = full.S; h.inconsistent = full.inconsistent; h.on_sphere = full.on_sphere;
+    const uint4 pad_a = {0u, 0u, 0u, 0u};
+    const uint4 pad_b = {zero_slot_marker, zero_slot_marker, zero_slot_marker, zero_slot_marker};
+    std::vector<uint32_t> prev_map, cur_map;
+    for (size_t si = 0; si < shells.size(); ++si) {
+        cur_map.assign(shells[si].size(), zero_slot_marker);
+        uint32_t count = 0;
+        for (size_t q = 0; q < shells[si].size(); ++q) {
+            if (!keep[si][q]) continue;
+            Entry e = shells[si][q];
+            const uint32_t flags = e.a.y & (CELL_NEG);
+            e.a.y = count | CELL_VALID | flags | (in_wedge(e.a) ? CELL_RATE : 0u);
+            if (si > 0) {       // corners of shell 1 point into shell 0 (the source cell, slot 0): unchanged
+                auto remap = [&](uint32_t slot) -> uint32_t {
+                    if (slot == zero_slot_marker) return slot;
+                    if (prev_map[slot] == zero_slot_marker) h.inconsistent = true;            // a read corner was not kept
+                    return prev_map[slot];
+                };
+                e.b.x = remap(e.b.x); e.b.y = remap(e.b.y); e.b.z = remap(e.b.z); e.b.w = remap(e.b.w);
+            }
+            h.cellA.push_back(e.a); h.cellB.push_back(e.b);
+            cur_map[q] = count++;
+        }
+        if (count == 0) break;                        // the wedge holds nothing from here on (tiny radii)
+        while (h.cellA.size() % RT_THREADS) { h.cellA.push_back(pad_a); h.cellB.push_back(pad_b); }
+        for (size_t q = h.cellA.size() - RT_THREADS; q < h.cellA.size(); ++q) h.cellA[q].y |= CELL_LAST;
+        h.max_cells = std::max(h.max_cells, count);
+        prev_map.swap(cur_map);
+    }
+    while ((h.cellA.size() / (size_t)RT_THREADS) % 3) for (int q = 0; q < RT_THREADS; ++q) { h.cellA.push_back(pad_a); h.cellB.push_back(pad_b); }
+    h.nsteps = (int)(h.cellA.size() / (size_t)RT_THREADS);
+    for (int q = 0; q < 4 * RT_THREADS; ++q) { h.cellA.push_back(pad_a); h.cellB.push_back(pad_b); }
+    return h;
+}
+
 template <typename T>
 int upload(const std::vector<T> &v, const T *&dev_out, std::vector<void *> &owned)
 {
@@ -743,12 +827,18 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
     // the window on any axis all of a sector's units are identical.
     const double R2hi_all = p.R * p.R * (1.0 + 1e-9) + 1e-9;
     const bool unclipped = std::isfinite(R2hi_all) && std::floor(std::sqrt(R2hi_all)) <= (double)std::min(ext_pos, ext_neg);
-    UnitSpec spec[24];
-    int info[24];
+    //   96: unit = wedge*24 + sector*8 + octant       (a quarter of a sector and what it reads: restrict_to_wedge)
+    UnitSpec spec[MAX_UNITS];
+    int info[MAX_UNITS];
     for (int u = 0; u < units; ++u) {
         int neg[3] = {0, 0, 0};
         UnitSpec &us = spec[u];
-        if (units == 12) {
+        if (units == 96) {
+            us.wedge = u / 24;
+            us.face = (u % 24) >> 3;
+            us.merge_axis = -1;
+            for (int ax = 0; ax < 3; ++ax) neg[ax] = ((u & 7) >> ax) & 1;
+        } else if (units == 12) {
             us.face = u >> 2;
             us.merge_axis = us.face == 2 ? 0 : 2;
             const int q = u & 3;
@@ -762,14 +852,14 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
         for (int ax = 0; ax < 3; ++ax) us.ext[ax] = neg[ax] ? ext_neg : ext_pos;
         us.ext_neg = ext_neg;
         // exactly one unit rates the source cell: the all-positive one (of the z-sector when there are sectors)
-        const bool rates_source = !neg[0] && !neg[1] && !neg[2] && (us.face == -1 || us.face == 2);
+        const bool rates_source = !neg[0] && !neg[1] && !neg[2] && (us.face == -1 || us.face == 2) && us.wedge <= 0;
         info[u] = neg[0] | (neg[1] << 1) | (neg[2] << 2) | ((us.merge_axis + 1) << 3) | (rates_source ? 32 : 0);
     }
-    int owner[24];
+    int owner[MAX_UNITS];
     for (int u = 0; u < units; ++u) {
         owner[u] = u;
         for (int u2 = 0; u2 < u; ++u2) {
-            if (spec[u2].face != spec[u].face || spec[u2].merge_axis != spec[u].merge_axis) continue;
+            if (spec[u2].face != spec[u].face || spec[u2].merge_axis != spec[u].merge_axis || spec[u2].wedge != spec[u].wedge) continue;
             if (unclipped || (spec[u].ext[0] == spec[u2].ext[0] && spec[u].ext[1] == spec[u2].ext[1] &&
                               spec[u].ext[2] == spec[u2].ext[2])) {
                 owner[u] = owner[u2];
@@ -778,7 +868,7 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
         }
     }
     std::vector<HostGeom> hg(units);
-    OctGeomDev od[24];
+    OctGeomDev od[MAX_UNITS];
     int Smax = 0;
     uint32_t max_cells = 1;
     const uint32_t MARK = 0xffffffffu;
@@ -790,7 +880,12 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
         for (int u = 0; u < units; ++u) {
             if (owner[u] != u) continue;
             workers.emplace_back([&hg, &spec, u, R_all, dr_all, q_max, threads]() {
-                build_unit_geometry(hg[u], spec[u], R_all, dr_all, q_max, MARK, threads);
+                if (spec[u].wedge < 0) { build_unit_geometry(hg[u], spec[u], R_all, dr_all, q_max, MARK, threads); return; }
+                HostGeom sector;                     // the whole sector first, then the wedge and what it reads
+                UnitSpec whole = spec[u];
+                whole.wedge = -1;
+                build_unit_geometry(sector, whole, R_all, dr_all, q_max, MARK, threads);
+                hg[u] = restrict_to_wedge(sector, spec[u].wedge, threads, MARK);
             });
         }
         for (auto &w : workers) w.join();
@@ -1020,10 +1115,19 @@ static void pick_launch_shape(const State &st, double R, int N, int src_count, b
         if (est_cells > 900.0) threads = std::max(threads, 512);
         if (est_cells > 2500.0) threads = 1024;
     }
+    // A handful of sources: 24 workgroups each still leave most CUs idle -- quarter the sectors (96 per source; each wedge
+    // re-derives the inner part of its sector, so evaluations double, time about halves)
+    // (measured, one source: 128^3 whole box 0.205 -> 0.157 ms, R = 32 0.051 -> 0.043 ms; the floor is the chain of shells,
+    //  ~2 us each, not the work: tools/sweep_single_source.sh)
+    if ((long)src_count * 48 <= (long)st.cu_count) {
+        units = 96;
+        threads = est_cells > 6000.0 ? 1024 : est_cells > 2500.0 ? 512 : 256;
+    }
     const int want_sectors = st.opt[ASORA_OPT_SECTORS];
     if (want_sectors == 1) units = 8;
     if (want_sectors == 2) units = 24;
     if (want_sectors == 3) units = 12;
+    if (want_sectors == 4) units = 96;
     const int forced = st.opt[ASORA_OPT_BLOCK_THREADS];
     if (forced == 64 || forced == 128 || forced == 256 || forced == 512 || forced == 1024) threads = forced;
     if (dump) threads = 256;                                // the column-density dump variant is built for 256 only
@@ -1116,7 +1220,8 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
         q.src_begin = p.src_begin + done;
         q.src_count = batch;
         q.shell_scratch = use_lds ? nullptr : st.shell_scratch;
-        const unsigned grid = 8u * (unsigned)units * (unsigned)((batch + 7) / 8);
+        q.spread = (long)batch * units <= 2L * st.cu_count ? 1 : 0;      // few workgroups: spread a source's units over the XCDs
+        const unsigned grid = q.spread ? (unsigned)units * (unsigned)batch : 8u * (unsigned)units * (unsigned)((batch + 7) / 8);
         {
             KernelTimer kt(ASORA_KERNEL_RAYTRACE, stream);
             int rc = 0;

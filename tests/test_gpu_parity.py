@@ -143,8 +143,9 @@ def test_z_transposed_layout_is_only_a_layout(asora):
 @pytest.mark.parametrize("name", ["u16_1src_R8", "l16_7src_R5.5", "l17_3src_Rbox", "l32_5src_R10", "l16_thick"])
 @pytest.mark.parametrize("threads", [64, 128, 256, 512, 1024])
 def test_decomposition_and_workgroup_size_do_not_change_results(asora, name, threads):
-    """One workgroup per octant vs one per (octant, sector), at every workgroup size: same Gamma and the
-    same count of rated pairs; the sector form evaluates a few more column densities (re-derived planes)."""
+    """One workgroup per octant vs one per (octant, sector), per mirrored sector pair and per quarter sector, at every
+    workgroup size: same Gamma and the same count of rated pairs; the sector forms evaluate more column densities
+    (re-derived planes; the quarter sectors re-derive what feeds them)."""
     p, lib, capi = asora
     c = cases.rt_case(name, "soft")
     N = c["N"]
@@ -155,7 +156,7 @@ def test_decomposition_and_workgroup_size_do_not_change_results(asora, name, thr
     out = {}
     try:
         lib.set_option(capi.OPT_BLOCK_THREADS, threads)
-        for mode in (1, 2, 3):
+        for mode in (1, 2, 3, 4):
             lib.set_option(capi.OPT_SECTORS, mode)
             phi = _asora_call(lib, c, N, numtau)
             np.testing.assert_allclose(phi, ref, rtol=GAMMA_RTOL, atol=0)
@@ -165,8 +166,10 @@ def test_decomposition_and_workgroup_size_do_not_change_results(asora, name, thr
         lib.set_option(capi.OPT_BLOCK_THREADS, 0)
     np.testing.assert_allclose(out[1][0], out[2][0], rtol=1e-12, atol=0)
     np.testing.assert_allclose(out[1][0], out[3][0], rtol=1e-12, atol=0)
-    assert out[1][1][0] == out[2][1][0] == out[3][1][0]    # rated pairs
+    np.testing.assert_allclose(out[1][0], out[4][0], rtol=1e-12, atol=0)
+    assert out[1][1][0] == out[2][1][0] == out[3][1][0] == out[4][1][0]    # rated pairs
     assert out[2][1][1] >= out[1][1][1]               # evaluations (re-derived planes)
+    assert out[4][1][1] >= out[2][1][1]               # quarter sectors re-derive the inner part of their sector
 
 
 def test_grey_notables_option(asora):
@@ -202,7 +205,7 @@ def test_large_radius_and_window_clipping(asora, N, R):
     np.testing.assert_allclose(phi, ref, rtol=GAMMA_RTOL, atol=0)
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 0])
 def test_large_shells_global_scratch_and_large_lds(asora, mode):
     """N=168 full box.  One workgroup per octant (mode 1): shell buffers 2*21.8k*8 B = 349 KB > 160 KB of LDS
     -> the global-scratch variant.  One per (octant, sector) (mode 2, what the library picks at this size):

@@ -1,10 +1,9 @@
-# BASELINE configs[1]: one source, 128^3, r_RT = 64: raytrace time per launch for every decomposition / workgroup size
-for M in 0 1 2 3; do for T in 0 256 512 1024; do
-  if [ $M = 0 ] && [ $T != 0 ]; then continue; fi
-  if [ $M != 0 ] && [ $T = 0 ]; then continue; fi
-  timeout -k 10 300 python bench.py --N 128 --nsrc 1 --R 64 --steps 20 --warmup 3 --cpu-sources 0 --sectors $M --block-threads $T 2>/dev/null > gpurun_out/ss_${M}_$T.json
-  python - <<PY
-import json
-d=json.load(open("gpurun_out/ss_${M}_$T.json")); print("mode=$M threads=$T raytrace_ms=%.4f step_ms=%.4f" % (d["kernels_ms_per_step"]["raytrace"], d["ms_per_step"]))
-PY
+# One source, whole-box trace (BASELINE configs[1]-like): raytrace time per launch over decompositions and workgroup sizes
+# usage: bash tools/sweep_single_source.sh [N] [R]
+N=${1:-128}; RR=${2:-1000}
+for S in 2 4; do for T in 256 512 1024; do
+  timeout -k 10 120 python bench.py --steps 20 --warmup 3 --cpu-sources 0 --N $N --nsrc 1 --R $RR --sectors $S --block-threads $T > /tmp/ss.json 2>/dev/null && python -c "
+import json;d=json.load(open('/tmp/ss.json'));print('N $N R $RR sectors $S threads $T raytrace ms', round(d['kernels_ms_per_step']['raytrace'],4))"
 done; done
+timeout -k 10 120 python bench.py --steps 20 --warmup 3 --cpu-sources 0 --N $N --nsrc 1 --R $RR > /tmp/ss.json 2>/dev/null && python -c "
+import json;d=json.load(open('/tmp/ss.json'));print('N $N R $RR auto raytrace ms', round(d['kernels_ms_per_step']['raytrace'],4))"
