@@ -1026,7 +1026,15 @@ int c2ray_do_all_sources(const double *normflux, const int32_t *srcpos, int max_
     const bool grey = st.opt[ASORA_OPT_GREY_NOTABLES] != 0;
     if (!grey && (NumTau < 1 || !photo_thin_table || !photo_thick_table))
         return fail(3, std::string(who) + ": empty photo-ionisation tables");
-    const bool heat = !grey && phi_heat && heat_thin_table && heat_thick_table;
+    // Heating tables that are identically zero (what the reference's evolve3D passes, pyc2ray/evolve.py:193: "eventually
+    // we'll add heating tables here") add exactly 0 to phi_heat: the grid is then neither uploaded, nor rated, nor
+    // downloaded -- two 128 MiB transfers at 256^3 and the slower kernel variant for nothing.
+    bool heat = !grey && phi_heat && heat_thin_table && heat_thick_table;
+    if (heat) {
+        bool any = false;
+        for (int i = 0; i < NumTau && !any; ++i) any = heat_thin_table[i] != 0.0 || heat_thick_table[i] != 0.0;
+        heat = any;
+    }
     if (int rc = asora_device_init_auto(m1)) return rc;
     const int N = st.N;
     for (int s = 0; s < NumSrc; ++s)
