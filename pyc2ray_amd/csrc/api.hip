@@ -130,7 +130,7 @@ static int release_all()
     State &st = g_state;
     auto drop = [](auto *&ptr) { if (ptr) { (void)hipFree(ptr); ptr = nullptr; } };
     for (int g = 0; g < ASORA_GRID_COUNT; ++g) { drop(st.grid[g]); st.grid_valid[g] = false; }
-    drop(st.nhi); drop(st.staging); drop(st.acc);
+    drop(st.nhi); drop(st.staging); drop(st.acc); st.ev_acc_clean = false;
     st.ev_open = false;
     st.temp_probe_valid = false;
     st.nhi_t = st.phi_t = st.heat_t = nullptr;    // second halves of nhi / phi_ion / phi_heat
@@ -1167,6 +1167,9 @@ int asora_evolve_begin(double dt, double bh00, double albpow, double colh0, doub
 
     if (int rc = ensure_temp_probe(bh00, albpow, colh0, temph0)) return rc;
     const size_t bytes = st.ncell * sizeof(double);
+    // the accumulators are zeroed once: every fused pass leaves them zero behind it, iterations beyond convergence do
+    // not touch them, so they are zero again whenever a new time step begins
+    bool acc_is_zero = st.acc != nullptr;
     if (!st.acc) ASORA_HIP_TRY(hipMalloc(&st.acc, 2 * bytes));
     if (!st.ev_status) {
         ASORA_HIP_TRY(hipMalloc(&st.ev_status, sizeof(EvolveStatus)));
@@ -1179,7 +1182,8 @@ int asora_evolve_begin(double dt, double bh00, double albpow, double colh0, doub
     st.ev_host->conv_criterion = conv_criterion;
     st.ev_host->conv_fraction = convergence_fraction;
     ASORA_HIP_TRY(hipMemcpyAsync(st.ev_status, st.ev_host, sizeof(EvolveStatus), hipMemcpyHostToDevice, st.stream));
-    ASORA_HIP_TRY(hipMemsetAsync(st.acc, 0, 2 * bytes, st.stream));                       // raytracing.cu:113
+    if (!acc_is_zero || !st.ev_acc_clean) ASORA_HIP_TRY(hipMemsetAsync(st.acc, 0, 2 * bytes, st.stream));   // raytracing.cu:113
+    st.ev_acc_clean = true;
     ASORA_HIP_TRY(hipMemsetAsync(st.counters, 0, sizeof(unsigned long long) * 2, st.stream));
     // xh_av = copy(xh) (evolve.py:136) is not materialised: nHI of the first trace is formed from xh and the first
     // chemistry pass takes xh as its starting xh_av; xh_intermed (evolve.py:137) is only ever written
@@ -1208,6 +1212,7 @@ int asora_evolve_enqueue(int iterations)
     for (int it = 0; it < iterations; ++it) {
         if (st.ev_src_count > 0) {
             RtParams p = st.ev_rt;
+            st.ev_acc_clean = false;                 // until the fused pass behind this trace has been enqueued
             if (int rc = launch_raytrace(st, p, false, false)) return rc;
         }
         ChemTileParams c;
@@ -1224,6 +1229,7 @@ int asora_evolve_enqueue(int iterations)
         c.fold = true; c.emit = true;
         set_uniform_temperature(c);
         if (int rc = launch_chemistry_tiles(st, c, st.stream)) return rc;
+        st.ev_acc_clean = true;
         st.ev_first = false;
     }
     st.grid_valid[ASORA_GRID_XH_AV] = st.grid_valid[ASORA_GRID_XH_INTERMED] = st.grid_valid[ASORA_GRID_PHI_ION] = true;

@@ -147,6 +147,7 @@ struct State {
     EvolveStatus *ev_status = nullptr;      // device
     EvolveStatus *ev_host = nullptr;        // pinned
     bool ev_open = false, ev_first = true;
+    bool ev_acc_clean = false;              // both accumulators are known to be zero
     // temperature probe of the TEMP grid: valid for the upload `temp_generation` and the constants in temp_consts
     double *temp_probe_dev = nullptr;       // [5] device
     double temp_probe[5] = {0, 0, 0, 0, 0}; // host copy: uniform?, T, brech0, acolh0, t_ok
