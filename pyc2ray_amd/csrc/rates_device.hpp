@@ -17,11 +17,14 @@ constexpr int LOG_TABLE_SIZE = 1 << LOG_TABLE_BITS;
 // log2 c at the interval centres, staged in LDS) + degree-6 series in r = m/c - 1, |r| < 2^-8
 // (truncation 3e-18).  Absolute error ~1 ulp of the result, like libm's log10; it replaces
 // log10 in the table lookup because two of them per cell dominated the instruction count.
-__device__ __forceinline__ double log2_pos(double x, const double2 *__restrict__ logtab)
+__device__ __forceinline__ double log2_pos(double x, const double2 *__restrict__ logtab, int diag_linear_index = 0)
 {
     const long long bits = __double_as_longlong(x);
     const int e = (int)(bits >> 52) - 1023;
-    const int idx = (int)(bits >> (52 - LOG_TABLE_BITS)) & (LOG_TABLE_SIZE - 1);
+    int idx = (int)(bits >> (52 - LOG_TABLE_BITS)) & (LOG_TABLE_SIZE - 1);
+#ifdef ASORA_ENABLE_ABLATION
+    if (diag_linear_index) idx = threadIdx.x & (LOG_TABLE_SIZE - 1);   // diagnostic: conflict-free table reads (wrong values)
+#endif
     const double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);
     const double2 t = logtab[idx];                 // {1/c, log2 c}
     const double r = fma(m, t.x, -1.0);
@@ -43,7 +46,11 @@ template <bool HEAT = false, typename Params = RtParams>
 __device__ __forceinline__ Lookup lookup_issue(const double2 *__restrict__ table, double tau, const Params &p,
                                                const double2 *__restrict__ logtab)
 {
+#ifdef ASORA_ENABLE_ABLATION
+    const double l2 = log2_pos(fmax(1.0e-20, tau), logtab, p.ablate & 16);
+#else
     const double l2 = log2_pos(fmax(1.0e-20, tau), logtab);
+#endif
     const double real_i = fmin(p.numtau_f, fmax(0.0, fma(l2, p.lut_k1, p.lut_k0)));
     const int i0 = (int)real_i;
     Lookup L;
