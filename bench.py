@@ -348,7 +348,7 @@ def main():
     lib.set_option(_capi.OPT_SECTORS, args.sectors)
 
     chem = (MYR, BH00, ALBPOW, COLH0, TEMPH0, ABU_C)
-    state = {"first": True}
+    state = {"first": True, "slab": slab}
 
     def begin_time_step():
         # conv_criterion = -1 and convergence_fraction = 0 can never be met: every enqueued iteration does its work
@@ -360,7 +360,7 @@ def main():
             state["first"] = True
 
     def step():
-        if slab:                       # what evolve3D_MPI does per outer iteration with a TorchComm
+        if state["slab"]:              # what evolve3D_MPI does per outer iteration with a TorchComm
             r = comm.slab_iteration(lib, plan, N, args.R, SIG, dr, n_local, MINLOGTAU, dlog, numtau, chem, state["first"])
             state["first"] = False
             return r
@@ -378,6 +378,24 @@ def main():
             comm.Barrier()
             torch.cuda.synchronize()
 
+    if comm is not None and state["slab"]:
+        # The point-to-point exchange has never run between real GPUs (the build box has one).  If it raises on any rank
+        # in its first step, every rank falls back to the full-grid all-reduce (any partition of the sources is fine for
+        # it) instead of losing the run; which path ran is in the JSON (`config.parallelism`).
+        ok = 1.0
+        try:
+            begin_time_step(); step(); fence()
+        except Exception as e:
+            print(f"bench: slab exchange failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
+            ok = 0.0
+        import torch
+        import torch.distributed as dist
+        flag = torch.tensor([ok], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) == 0.0:
+            state["slab"] = False
+            slab = False
+            comm.exchange = "allreduce"
     # the FIRST iteration of a time step additionally forms nHI from xh and zeroes the accumulators on the whole grid
     begin_time_step(); step(); fence()
     t0 = time.perf_counter()
