@@ -24,6 +24,7 @@
 #ifndef ASORA_HIP_H
 #define ASORA_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -133,6 +134,14 @@ int asora_grid_to_device(int which, const double *host, int N, char order);
 int asora_grid_to_host(int which, double *host, int N, char order);
 /* Device-to-device copy between two grids (e.g. xh -> xh_av at the start of a step). */
 int asora_grid_copy(int dst, int src);
+/* Sum over all cells of a grid, evaluated on the device in a fixed order (the two means of the reference's log line,
+ * pyc2ray/evolve.py:160 `ndens.mean()`, `xh.mean()`, without a host pass over N^3 values). */
+int asora_grid_sum(int which, double *sum);
+/* Page-locked host memory for the grids a caller hands to asora_grid_to_host / asora_grid_to_device: copies into
+ * pageable memory that has never been touched run at a fraction of the PCIe rate (page faults inside the copy).
+ * The host side keeps a small pool of these behind the arrays evolve3D returns (pyc2ray_amd/_pinned.py). */
+int asora_host_alloc(size_t bytes, void **host);
+int asora_host_free(void *host);
 /* Raw device pointer of a grid (for zero-copy views, e.g. an RCCL all-reduce of phi_ion
  * through torch.distributed).  NULL when not initialised. */
 void *asora_device_ptr(int which);

@@ -4,6 +4,7 @@ same RuntimeError when something is used before ``device_init``.
 The query is still called ``cuda_is_init`` so that scripts written for the reference run unchanged; the device
 behind it is an MI355X driven through HIP.
 """
+from . import _pinned
 from .load_extensions import load_asora
 
 __all__ = ['cuda_is_init', 'device_init', 'device_close', 'photo_table_to_device']
@@ -37,8 +38,10 @@ def device_init(N, source_batch_size, device_id=None):
 
 
 def device_close():
-    """Release the device grids."""
-    _Lifecycle.library().device_close()
+    """Release the device grids (and the page-locked buffers no result array uses any more)."""
+    lib = _Lifecycle.library()
+    lib.device_close()
+    _pinned.release_free_buffers(lib._lib)
     _Lifecycle.ready = False
 
 

@@ -13,6 +13,8 @@ Differences from the reference:
     3.04 massless neutrinos).  The lite version could not be compared with astropy in the build
     container (astropy absent), so runs that need cosmological time steps to 1e-6 should have astropy.
   * ``use_mpi`` may be ``pyc2ray_amd.dist.MPI`` (torch.distributed/RCCL) as well as mpi4py's ``MPI``.
+  * ``device_resident`` (opt-in attribute, single GPU): ``ndens``, ``temp``, ``xh`` and ``phi_ion`` stay on the MI355X
+    between time steps; see :class:`C2Ray`.
 """
 import atexit
 import re
@@ -26,7 +28,9 @@ except ImportError:  # pragma: no cover
     from yaml import SafeLoader
 
 from .asora_core import cuda_is_init, device_close, device_init, photo_table_to_device
-from .evolve import evolve3D, evolve3D_MPI
+from . import _capi
+from .evolve import evolve3D, evolve3D_MPI, evolve3D_resident
+from .load_extensions import load_asora
 from .radiation import BlackBodySource, make_tau_table
 from .raytracing import do_raytracing
 from .utils.logutils import printlog
@@ -96,7 +100,52 @@ def _make_cosmology(H0, Om0, Tcmb0, Ob0):
         return FlatLambdaCDMLite(H0, Om0, Tcmb0, Ob0=Ob0), False
 
 
+class _DeviceGrid:
+    """A grid attribute of C2Ray that may live on the device (see C2Ray.device_resident).  The host array is the
+    attribute's value as always; what is tracked is which side holds the current data.  Reading the attribute hands
+    out the host array, which the caller may then write into, so every read marks the device copy as out of date
+    (and first fetches the data if the device holds the newer one); assigning replaces the host array."""
+
+    def __init__(self, name, which):
+        self.name, self.which = name, which
+
+    def __set_name__(self, owner, attr):
+        self.attr = "_grid_" + attr
+
+    def __get__(self, obj, objtype=None):
+        if obj is None:
+            return self
+        try:
+            arr = obj.__dict__[self.attr]
+        except KeyError:
+            raise AttributeError(self.name) from None
+        if self.name in obj._device_newer:                   # results of the last step(s) still only on the device
+            load_asora().grid_to_host(self.which, arr)
+            obj._device_newer.discard(self.name)
+        obj._host_newer.add(self.name)                       # the caller may modify what it gets
+        return arr
+
+    def __set__(self, obj, value):
+        obj.__dict__[self.attr] = value
+        obj._device_newer.discard(self.name)
+        obj._host_newer.add(self.name)
+
+
 class C2Ray:
+    #: Opt-in (set on an instance, single GPU, use_gpu=True): ndens, temp, xh and phi_ion stay on the device between time
+    #: steps.  evolve3D then uploads only the grids that were assigned or READ on the host since the last step (a read
+    #: hands out the array, which may be written into -- e.g. ``sim.ndens *= f`` in cosmo_evolve), and downloads xh /
+    #: phi_ion only when they are read.  At 256^3 the five 128 MiB transfers of a time step cost as much as five outer
+    #: iterations.  Contract: do not keep a reference to one of these arrays and write into it later WITHOUT touching the
+    #: attribute again (``x = sim.xh`` ... ``x[...] = 0``): the device copy would not notice.  With the default (False)
+    #: every step uploads and downloads everything, as the reference does.
+    device_resident = False
+
+    ndens = _DeviceGrid("ndens", _capi.GRID_NDENS)
+    temp = _DeviceGrid("temp", _capi.GRID_TEMP)
+    xh = _DeviceGrid("xh", _capi.GRID_XH)
+    phi_ion = _DeviceGrid("phi_ion", _capi.GRID_PHI_ION)
+
     def __init__(self, paramfile, Nmesh, use_gpu, use_mpi):
         """Basis class of a C2Ray simulation (pyc2ray/c2ray_base.py:82-145).
 
@@ -106,6 +155,8 @@ class C2Ray:
                     (sub-boxes, photon loss), evaluated on the GPU through the libc2ray-compatible entry points
         use_mpi   : None/False, mpi4py's MPI module, or pyc2ray_amd.dist.MPI
         """
+        self._host_newer = set()           # grids whose host array holds newer data than the device
+        self._device_newer = set()         # grids whose device copy holds newer data than the host array
         if use_mpi:
             self.mpi = use_mpi
             self.comm = use_mpi.COMM_WORLD
@@ -157,6 +208,8 @@ class C2Ray:
 
     def evolve3D(self, dt, src_flux, src_pos):
         """Evolve the grid over one time step (c2ray_base.py:170-226)."""
+        if self.device_resident and self.gpu and not self.mpi:
+            return self._evolve3D_resident(dt, src_flux, src_pos)
         args = (self.temp, self.ndens, self.xh, self.photo_thin_table, self.photo_thick_table, self.minlogtau,
                 self.dlogtau, self.R_max_LLS, self.convergence_fraction, self.sig, self.bh00, self.albpow,
                 self.colh0, self.temph0, self.abu_c, self.logfile)
@@ -167,6 +220,21 @@ class C2Ray:
         else:
             self.xh, self.phi_ion = evolve3D(dt, self.dr, src_flux, src_pos, self.gpu, self.max_subbox,
                                              self.subboxsize, self.loss_fraction, *args)
+
+    def _evolve3D_resident(self, dt, src_flux, src_pos):
+        """The same step with the grids left on the device (see `device_resident`)."""
+        d = self.__dict__
+        uploads = {}
+        for name, which in (("ndens", _capi.GRID_NDENS), ("temp", _capi.GRID_TEMP), ("xh", _capi.GRID_XH)):
+            if name in self._host_newer:
+                uploads[which] = d["_grid_" + name]
+        if d["_grid_phi_ion"].flags.f_contiguous and not d["_grid_phi_ion"].flags.c_contiguous:
+            d["_grid_phi_ion"] = np.zeros(self.shape)           # the GPU path returns C-ordered rates (evolve.py:200)
+        evolve3D_resident(dt, self.dr, src_flux, src_pos, uploads, self.N, self.photo_thin_table, self.minlogtau, self.dlogtau,
+                          self.R_max_LLS, self.convergence_fraction, self.sig, self.bh00, self.albpow, self.colh0, self.temph0,
+                          self.abu_c, self.logfile)
+        self._host_newer -= {"ndens", "temp", "xh", "phi_ion"}
+        self._device_newer |= {"xh", "phi_ion"}
 
     def cosmo_evolve(self, dt):
         """Advance time and redshift by dt, diluting density and rescaling the cell size when the run is

@@ -97,7 +97,7 @@ static int ensure_temp_probe(double bh00, double albpow, double colh0, double te
     State &st = g_state;
     const double c[4] = {bh00, albpow, colh0, temph0};
     if (st.temp_probe_valid && std::memcmp(c, st.temp_consts, sizeof c) == 0) return 0;
-    if (!st.temp_probe_dev) ASORA_HIP_TRY(hipMalloc(&st.temp_probe_dev, sizeof(double) * 5));
+    if (!st.temp_probe_dev) ASORA_HIP_TRY(hipMalloc(&st.temp_probe_dev, sizeof(double) * 8));
     if (int rc = launch_temp_probe(st, st.grid[ASORA_GRID_TEMP], st.ncell, bh00, albpow, colh0, temph0, st.temp_probe_dev)) return rc;
     ASORA_HIP_TRY(hipMemcpyAsync(st.temp_probe, st.temp_probe_dev, sizeof(double) * 5, hipMemcpyDeviceToHost, st.stream));
     ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
@@ -702,6 +702,38 @@ int asora_grid_copy(int dst, int src)
                                  st.stream));
     st.grid_valid[dst] = true;
     if (dst == ASORA_GRID_TEMP) st.temp_probe_valid = false;
+    return 0;
+}
+
+int asora_grid_sum(int which, double *sum)
+{
+    clear_error();
+    if (int rc = require_init("grid_sum")) return rc;
+    if (which < 0 || which >= ASORA_GRID_COUNT) return fail(3, "grid_sum: bad grid selector");
+    if (!sum) return fail(3, "grid_sum: null output pointer");
+    State &st = g_state;
+    if (!st.grid_valid[which]) return fail(3, "grid_sum: grid " + std::to_string(which) + " holds no data");
+    if (!st.temp_probe_dev) ASORA_HIP_TRY(hipMalloc(&st.temp_probe_dev, sizeof(double) * 8));
+    if (int rc = launch_grid_sum(st, st.grid[which], st.ncell, st.temp_probe_dev + 5)) return rc;
+    ASORA_HIP_TRY(hipMemcpyAsync(sum, st.temp_probe_dev + 5, sizeof(double), hipMemcpyDeviceToHost, st.stream));
+    ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    return 0;
+}
+
+int asora_host_alloc(size_t bytes, void **host)
+{
+    clear_error();
+    if (!host || bytes == 0) return fail(3, "host_alloc: null pointer or zero size");
+    *host = nullptr;
+    ASORA_HIP_TRY(hipHostMalloc(host, bytes, hipHostMallocDefault));
+    return 0;
+}
+
+int asora_host_free(void *host)
+{
+    clear_error();
+    if (!host) return 0;
+    ASORA_HIP_TRY(hipHostFree(host));
     return 0;
 }
 

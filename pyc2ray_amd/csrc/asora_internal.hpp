@@ -149,7 +149,7 @@ struct State {
     bool ev_open = false, ev_first = true;
     bool ev_acc_clean = false;              // both accumulators are known to be zero
     // temperature probe of the TEMP grid: valid for the upload `temp_generation` and the constants in temp_consts
-    double *temp_probe_dev = nullptr;       // [5] device
+    double *temp_probe_dev = nullptr;       // [8] device: the probe's five results, [5] = asora_grid_sum's
     double temp_probe[5] = {0, 0, 0, 0, 0}; // host copy: uniform?, T, brech0, acolh0, t_ok
     bool temp_probe_valid = false;
     double temp_consts[4] = {0, 0, 0, 0};
@@ -271,6 +271,7 @@ struct ChemTileParams {
     int uniform = 0, uniform_t_ok = 0;
     double uniform_T = 0, uniform_brech0 = 0, uniform_acolh0 = 0;
 };
+int launch_grid_sum(State &st, const double *a, size_t n, double *out_dev);
 int launch_temp_probe(State &st, const double *temp, size_t n, double bh00, double albpow, double colh0, double temph0,
                       double *out_dev);
 int launch_chemistry_tiles(State &st, ChemTileParams &p, hipStream_t stream);

@@ -348,6 +348,47 @@ int launch_temp_probe(State &st, const double *temp, size_t n, double bh00, doub
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sum of a grid in a fixed order (the means of the reference's log line, evolve.py:160, without a host pass)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(CH_THREADS) grid_sum_kernel(const double *__restrict__ a, size_t n, double *partial)
+{
+    double s = 0.0;
+    for (size_t q = (size_t)blockIdx.x * CH_THREADS + threadIdx.x; q < n; q += (size_t)gridDim.x * CH_THREADS) s += a[q];
+    __shared__ double sh[CH_THREADS];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = CH_THREADS / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+__global__ void __launch_bounds__(CH_THREADS) grid_sum_final_kernel(const double *partial, int nblocks, double *out)
+{
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += CH_THREADS) s += partial[b];
+    __shared__ double sh[CH_THREADS];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = CH_THREADS / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+int launch_grid_sum(State &st, const double *a, size_t n, double *out_dev)
+{
+    const int blocks = (int)std::min<size_t>(std::max<size_t>(1, (n + CH_THREADS - 1) / CH_THREADS), (size_t)st.red_blocks);
+    hipLaunchKernelGGL(grid_sum_kernel, dim3(blocks), dim3(CH_THREADS), 0, st.stream, a, n, st.red_partial);
+    ASORA_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(grid_sum_final_kernel, dim3(1), dim3(CH_THREADS), 0, st.stream, (const double *)st.red_partial, blocks, out_dev);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int chemistry_reduction_blocks(const State &st) { return st.cu_count * 8; }
 
 int launch_chemistry(State &st, ChemParams &p, hipStream_t stream)

@@ -19,7 +19,7 @@ from .load_extensions import load_asora, load_c2ray
 from .utils import printlog
 from .utils.sourceutils import format_sources
 
-__all__ = ['evolve3D', 'evolve3D_MPI']
+__all__ = ['evolve3D', 'evolve3D_MPI', 'evolve3D_resident']
 
 #: outer iterations enqueued per host round trip of the single-GPU loop (the device evaluates the convergence test
 #: itself; launches enqueued beyond convergence do nothing)
@@ -81,7 +81,9 @@ def _evolve_cpu_semantics(dt, dr, src_flux, src_pos, max_subbox, subboxsize, los
         printlog(f"dr [Mpc]: {dr/3.086e24:.3e}", logfile, quiet)
         printlog(f"dt [years]: {dt/3.15576E+07:.3e}", logfile, quiet)
         printlog(f"Running on {NumSrc:n} source(s), total normalized ionizing flux: {src_flux.sum():.2e}", logfile, quiet)
-        printlog(f"Mean density (cgs): {ndens.mean():.3e}, Mean ionized fraction: {xh.mean():.3e}", logfile, quiet)
+        mean_ndens = libasora.grid_sum(_capi.GRID_NDENS) / NumCells
+        mean_xh = libasora.grid_sum(_capi.GRID_XH) / NumCells
+        printlog(f"Mean density (cgs): {mean_ndens:.3e}, Mean ionized fraction: {mean_xh:.3e}", logfile, quiet)
         printlog(f"Convergence Criterion (Number of points): {conv_criterion : n}", logfile, quiet, end='\n\n')
     while not converged:
         niter += 1
@@ -114,8 +116,8 @@ def _evolve_cpu_semantics(dt, dr, src_flux, src_pos, max_subbox, subboxsize, los
     if rank == 0:
         printlog("Multiple source convergence reached.", logfile, quiet)
     # Fortran-ordered results, as the reference's CPU branch returns them (evolve.py:178)
-    xh_new = libasora.grid_to_host(_capi.GRID_XH_INTERMED, np.empty((N, N, N), order='F'))
-    phi_ion = libasora.grid_to_host(_capi.GRID_PHI_ION, np.empty((N, N, N), order='F'))
+    xh_new = libasora.grid_to_host(_capi.GRID_XH_INTERMED, libasora.host_empty((N, N, N), order='F'))
+    phi_ion = libasora.grid_to_host(_capi.GRID_PHI_ION, libasora.host_empty((N, N, N), order='F'))
     _evolve.last_niter = niter
     return xh_new, phi_ion
 
@@ -134,6 +136,69 @@ def _allreduce_phi(libasora, N, use_mpi, comm, rank):
         comm.Reduce([phi, use_mpi.DOUBLE], None, op=use_mpi.SUM, root=0)
     comm.Bcast([phi, use_mpi.DOUBLE], root=0)
     libasora.grid_to_device(_capi.GRID_PHI_ION, phi)
+
+
+def _device_loop(libasora, chem, R_max_LLS, sig, dr, minlogtau, dlogtau, NumTau, NumSrc_local, conv_criterion,
+                 convergence_fraction, NumCells, logfile, quiet):
+    """One GPU: the whole loop of a time step on the device (include/asora_hip.h, asora_evolve_*).  An iteration is
+    the raytrace plus ONE pass over the grids (rates folded, chemistry, nHI for the next trace, accumulators zeroed); the
+    convergence test of evolve.py:216-236 is evaluated on the device, so EVOLVE_BATCH iterations are enqueued per host
+    round trip and those beyond convergence do nothing.  NDENS, TEMP, XH and the sources must be on the device.
+    Returns (outer iterations, sum of xh_intermed of the last iteration)."""
+    libasora.evolve_begin(*chem, R_max_LLS, sig, dr, minlogtau, dlogtau, NumTau, 0, NumSrc_local,
+                          conv_criterion, convergence_fraction)
+    batch = max(1, min(EVOLVE_BATCH, 32))
+    niter, converged, sum_xh1 = 0, False, 0.0
+    while not converged:
+        t0 = time.time()
+        libasora.evolve_enqueue(batch)
+        _, converged, rows = libasora.evolve_poll(batch)
+        per_iteration = (time.time() - t0) / max(len(rows), 1)
+        for conv_flag, sum_xh1, _s0, rel_change_xh1, _rel0 in rows:
+            niter += 1
+            conv_flag = int(conv_flag)
+            printlog("Doing Raytracing...", logfile, quiet, ' ')
+            printlog(f"took {per_iteration : .1f} s.", logfile, quiet)
+            printlog("Doing Chemistry...", logfile, quiet, ' ')
+            printlog("took  0.0 s. (fused with the raytrace on the device: the time above is for both)", logfile, quiet)
+            printlog(f"Number of non-converged points: {conv_flag} of {NumCells} ({conv_flag / NumCells * 100 : .3f} % ), "
+                     f"Relative change in ionfrac: {rel_change_xh1 : .2e}", logfile, quiet)
+    return niter, float(sum_xh1)
+
+
+def evolve3D_resident(dt, dr, src_flux, src_pos, uploads, N, photo_thin_table, minlogtau, dlogtau, R_max_LLS,
+                      convergence_fraction, sig, bh00, albpow, colh0, temph0, abu_c, logfile="pyC2Ray.log", quiet=False):
+    """evolve3D for a caller that keeps the grids on the device between time steps (the C2Ray class with
+    ``device_resident = True``): same loop, log lines and results as :func:`evolve3D` with ``use_gpu=True``, but only the
+    grids in ``uploads`` ({grid selector: host array}, those the caller changed on the host) cross PCIe, and nothing
+    comes back: afterwards XH_INTERMED == XH == the new ionised fraction and PHI_ION the rates, on the device
+    (``libasora.grid_to_host`` fetches them when someone looks).  Returns the number of outer iterations."""
+    if not cuda_is_init():
+        raise RuntimeError("GPU not initialized. Please initialize it by calling device_init(N)")
+    libasora = load_asora()
+    NumSrc = src_flux.shape[0]
+    NumCells = N * N * N
+    NumTau = photo_thin_table.shape[0]
+    conv_criterion = min(int(convergence_fraction * NumCells), (NumSrc - 1) / 3)          # evolve.py:127
+    srcpos_flat, normflux_flat = format_sources(np.asarray(src_pos), src_flux)
+    libasora.source_data_to_device(srcpos_flat, normflux_flat, NumSrc)
+    for which, grid in uploads.items():
+        libasora.grid_to_device(which, grid)
+    printlog("Copied source data to device.", logfile, quiet)
+    printlog("Calling evolve3D...", logfile, quiet)
+    printlog(f"dr [Mpc]: {dr/3.086e24:.3e}", logfile, quiet)
+    printlog(f"dt [years]: {dt/3.15576E+07:.3e}", logfile, quiet)
+    printlog(f"Running on {NumSrc:n} source(s), total normalized ionizing flux: {src_flux.sum():.2e}", logfile, quiet)
+    mean_ndens = libasora.grid_sum(_capi.GRID_NDENS) / NumCells
+    mean_xh = libasora.grid_sum(_capi.GRID_XH) / NumCells
+    printlog(f"Mean density (cgs): {mean_ndens:.3e}, Mean ionized fraction: {mean_xh:.3e}", logfile, quiet)
+    printlog(f"Convergence Criterion (Number of points): {conv_criterion : n}", logfile, quiet, end='\n\n')
+    niter, _ = _device_loop(libasora, (dt, bh00, albpow, colh0, temph0, abu_c), R_max_LLS, sig, dr, minlogtau, dlogtau,
+                            NumTau, NumSrc, conv_criterion, convergence_fraction, NumCells, logfile, quiet)
+    printlog("Multiple source convergence reached.", logfile, quiet)
+    libasora.grid_copy(_capi.GRID_XH, _capi.GRID_XH_INTERMED)       # the next step starts from the new ionised fraction
+    _evolve.last_niter = niter
+    return niter
 
 
 def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_table, minlogtau, dlogtau,
@@ -206,32 +271,17 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
         printlog(f"dr [Mpc]: {dr/3.086e24:.3e}", logfile, quiet)
         printlog(f"dt [years]: {dt/3.15576E+07:.3e}", logfile, quiet)
         printlog(f"Running on {NumSrc:n} source(s), total normalized ionizing flux: {src_flux.sum():.2e}", logfile, quiet)
-        printlog(f"Mean density (cgs): {ndens.mean():.3e}, Mean ionized fraction: {xh.mean():.3e}", logfile, quiet)
+        # the two means of evolve.py:160, summed on the device from the grids just uploaded
+        mean_ndens = libasora.grid_sum(_capi.GRID_NDENS) / NumCells
+        mean_xh = libasora.grid_sum(_capi.GRID_XH) / NumCells
+        printlog(f"Mean density (cgs): {mean_ndens:.3e}, Mean ionized fraction: {mean_xh:.3e}", logfile, quiet)
         printlog(f"Convergence Criterion (Number of points): {conv_criterion : n}", logfile, quiet, end='\n\n')
 
     chem = (dt, bh00, albpow, colh0, temph0, abu_c)
     if not distributed:
-        # One GPU: the whole loop lives on the device (include/asora_hip.h, asora_evolve_*).  An iteration is the
-        # raytrace plus ONE pass over the grids (rates folded, chemistry, nHI for the next trace, accumulators
-        # zeroed); the convergence test of evolve.py:216-236 is evaluated on the device, so EVOLVE_BATCH iterations
-        # are enqueued per host round trip and those beyond convergence do nothing.
-        libasora.evolve_begin(*chem, R_max_LLS, sig, dr, minlogtau, dlogtau, NumTau, 0, NumSrc_local,
-                              conv_criterion, convergence_fraction)
-        batch = max(1, min(EVOLVE_BATCH, 32))
-        while not converged:
-            t0 = time.time()
-            libasora.evolve_enqueue(batch)
-            _, converged, rows = libasora.evolve_poll(batch)
-            per_iteration = (time.time() - t0) / max(len(rows), 1)
-            for conv_flag, _s1, _s0, rel_change_xh1, _rel0 in rows:
-                niter += 1
-                conv_flag = int(conv_flag)
-                printlog("Doing Raytracing...", logfile, quiet, ' ')
-                printlog(f"took {per_iteration : .1f} s.", logfile, quiet)
-                printlog("Doing Chemistry...", logfile, quiet, ' ')
-                printlog("took  0.0 s. (fused with the raytrace on the device: the time above is for both)", logfile, quiet)
-                printlog(f"Number of non-converged points: {conv_flag} of {NumCells} ({conv_flag / NumCells * 100 : .3f} % ), "
-                         f"Relative change in ionfrac: {rel_change_xh1 : .2e}", logfile, quiet)
+        niter, _ = _device_loop(libasora, chem, R_max_LLS, sig, dr, minlogtau, dlogtau, NumTau, NumSrc_local, conv_criterion,
+                                convergence_fraction, NumCells, logfile, quiet)
+        converged = True
 
     while distributed and not converged:
         niter += 1
@@ -291,8 +341,10 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
     if slab:       # every rank returns the whole fields (evolve.py:480-481,497): collect the owners' slabs
         comm.slab_gather(libasora, plan, _capi.GRID_XH_INTERMED, N)
         comm.slab_gather(libasora, plan, _capi.GRID_PHI_ION, N)
-    xh_new = libasora.grid_to_host(_capi.GRID_XH_INTERMED, np.empty_like(xh, dtype=np.float64))
-    phi_ion = libasora.grid_to_host(_capi.GRID_PHI_ION, np.empty((N, N, N)))
+    # laid out like `xh`, as np.empty_like would; in page-locked memory (pyc2ray_amd/_pinned.py)
+    like_xh = 'F' if (xh.flags.f_contiguous and not xh.flags.c_contiguous) else 'C'
+    xh_new = libasora.grid_to_host(_capi.GRID_XH_INTERMED, libasora.host_empty((N, N, N), order=like_xh))
+    phi_ion = libasora.grid_to_host(_capi.GRID_PHI_ION, libasora.host_empty((N, N, N)))
     _evolve.last_niter = niter
     return xh_new, phi_ion
 

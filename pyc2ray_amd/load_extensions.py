@@ -20,7 +20,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import _capi
+from . import _capi, _pinned
 
 __all__ = ["load_c2ray", "load_asora"]
 
@@ -127,6 +127,15 @@ class _LibAsora:
 
     def grid_copy(self, dst, src):
         _capi.check(self._lib.asora_grid_copy(int(dst), int(src)), "grid_copy")
+
+    def grid_sum(self, which):
+        out = C.c_double(0.0)
+        _capi.check(self._lib.asora_grid_sum(int(which), C.byref(out)), "grid_sum")
+        return out.value
+
+    def host_empty(self, shape, order='C'):
+        """An uninitialised float64 array for a grid download, in page-locked memory when there is some (_pinned.py)."""
+        return _pinned.empty(self._lib, shape, order)
 
     def device_ptr(self, which):
         return self._lib.asora_device_ptr(int(which))

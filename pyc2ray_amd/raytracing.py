@@ -44,9 +44,8 @@ def do_raytracing(dr,
 
     printlog(f"dr [Mpc]: {dr/3.086e24:.3e}", logfile, quiet)
     printlog(f"Running on {NumSrc:n} source(s), total normalized ionizing flux: {src_flux.sum():.2e}", logfile, quiet)
-    printlog(f"Mean density (cgs): {ndens.mean():.3e}, Mean ionized fraction: {xh_av.mean():.3e}", logfile, quiet)
-
     if not use_gpu:
+        printlog(f"Mean density (cgs): {ndens.mean():.3e}, Mean ionized fraction: {xh_av.mean():.3e}", logfile, quiet)
         trt0 = time.time()
         printlog("Doing Raytracing...", logfile, quiet, ' ')
         phi_ion = np.zeros((N, N, N), order='F')                      # raytracing.py:80-83
@@ -67,6 +66,9 @@ def do_raytracing(dr,
     libasora.source_data_to_device(srcpos_flat, normflux_flat, NumSrc)
     libasora.grid_to_device(_capi.GRID_NDENS, ndens)
     libasora.grid_to_device(_capi.GRID_XH_AV, xh_av)
+    # the reference prints the means before the copies (raytracing.py:72-76); here they are summed on the device
+    printlog(f"Mean density (cgs): {libasora.grid_sum(_capi.GRID_NDENS) / N ** 3:.3e}, "
+             f"Mean ionized fraction: {libasora.grid_sum(_capi.GRID_XH_AV) / N ** 3:.3e}", logfile, quiet)
     printlog("Copied source data to device.", logfile, quiet)
 
     # photo-heating: only when real heating tables are passed (the reference's callers pass zeros when
@@ -83,7 +85,7 @@ def do_raytracing(dr,
         libasora.raytrace_device(R_max_LLS, sig, dr, 0, NumSrc, minlogtau, dlogtau, NumTau)
     finally:
         libasora.set_option(_capi.OPT_HEATING, 0)
-    phi_ion = libasora.grid_to_host(_capi.GRID_PHI_ION, np.empty((N, N, N)))
-    phi_heat = libasora.grid_to_host(_capi.GRID_PHI_HEAT, np.empty((N, N, N))) if want_heat else None
+    phi_ion = libasora.grid_to_host(_capi.GRID_PHI_ION, libasora.host_empty((N, N, N)))
+    phi_heat = libasora.grid_to_host(_capi.GRID_PHI_HEAT, libasora.host_empty((N, N, N))) if want_heat else None
     printlog(f"took {(time.time()-trt0) : .1f} s.", logfile, quiet)
     return phi_ion, phi_heat

@@ -26,6 +26,12 @@ class OracleAsora:
         out[...] = self.g[which]
         return out
 
+    def grid_sum(self, which):
+        return float(self.g[which].sum())
+
+    def host_empty(self, shape, order='C'):
+        return np.empty(shape, order=order)
+
     def device_ptr(self, which):
         return 0
 

@@ -269,3 +269,63 @@ def test_paper_test2_cosmological_ionisation_front(tmp_path):
         pc2r.device_close()
     finally:
         os.chdir(cwd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cosmological", [False, True])
+def test_device_resident_grids_give_the_same_run_with_fewer_transfers(tmp_path, cosmological):
+    """`sim.device_resident = True`: ndens, temp, xh and phi_ion stay on the device between time steps.  Same fields as
+    the default run after every step that is looked at; uploads only for grids that were assigned or read on the host
+    (the density every step of a cosmological run: cosmo_evolve scales it in place), downloads only on reading."""
+    import pyc2ray_amd as pc2r
+    from pyc2ray_amd import _capi
+    from pyc2ray_amd.load_extensions import load_asora
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        N = 24
+        with open("src.txt", "w") as f:
+            f.write("2\n12 12 12 6e52 1.0\n5 20 9 2e52 1.0\n")
+        runs = {}
+        for resident in (False, True):
+            if pc2r.cuda_is_init():
+                pc2r.device_close()
+            sim = pc2r.C2Ray_Test(PARAMS, N, True)
+            sim.cosmological = cosmological
+            sim.device_resident = resident
+            srcpos, srcflux = sim.read_sources("src.txt", 2)
+            zs = sim.generate_redshift_array(2, 4e7)
+            dt = sim.set_timestep(zs[0], zs[1], 4)
+            sim.density_init(zs[0])
+            lib = load_asora()
+            counts = {"up": [], "down": []}
+            up, down = lib.grid_to_device, lib.grid_to_host
+            lib.grid_to_device = lambda which, a, _f=up: (counts["up"].append(which), _f(which, a))[1]
+            lib.grid_to_host = lambda which, out, _f=down: (counts["down"].append(which), _f(which, out))[1]
+            try:
+                snaps = []
+                for step in range(4):
+                    sim.cosmo_evolve(dt)
+                    sim.evolve3D(dt, srcflux, srcpos)
+                    if step in (1, 3):                      # the fields are looked at after steps 2 and 4 only
+                        snaps.append((np.array(sim.xh, copy=True), np.array(sim.phi_ion, copy=True), float(sim.ndens.mean())))
+            finally:
+                lib.grid_to_device, lib.grid_to_host = up, down
+            runs[resident] = (snaps, counts)
+            pc2r.device_close()
+        for (x0, p0, n0), (x1, p1, n1) in zip(runs[False][0], runs[True][0]):
+            np.testing.assert_allclose(x1, x0, rtol=1e-11, atol=0)           # atomic summation order only
+            np.testing.assert_allclose(p1, p0, rtol=1e-11, atol=0)
+            assert n1 == n0
+        assert runs[True][0][-1][0].mean() > 0.002 and runs[True][0][-1][0].max() > 0.5       # the sources did ionise their surroundings
+        up0, down0 = runs[False][1]["up"], runs[False][1]["down"]
+        up1, down1 = runs[True][1]["up"], runs[True][1]["down"]
+        assert len(up0) == 3 * 4 and len(down0) == 2 * 4                       # the default: everything, every step
+        # resident: step 1 uploads ndens, temp, xh; afterwards only what the host touched -- the density when cosmo_evolve
+        # scaled it, and xh / ndens again after the snapshot read them (a read may have been a write)
+        assert up1.count(_capi.GRID_TEMP) == 1
+        assert up1.count(_capi.GRID_NDENS) == (4 if cosmological else 2)
+        assert up1.count(_capi.GRID_XH) == 2
+        assert len(down1) == 4                                                 # xh and phi_ion, twice
+    finally:
+        os.chdir(cwd)

@@ -291,7 +291,59 @@ def test_evolve3D_matches_oracle_loop(asora, order, tmp_path):
     np.testing.assert_allclose(xh_new, x_ref, rtol=1e-8, atol=0)
     np.testing.assert_allclose(phi, phi_ref, rtol=1e-7, atol=0)
     assert xh_new.max() > 0.5                                  # the sources did ionise their surroundings
-    assert "Multiple source convergence reached." in open(tmp_path / "log.txt").read()
+    log = open(tmp_path / "log.txt").read()
+    assert "Multiple source convergence reached." in log
+    # the two means of the reference's log line are summed on the device: same printed digits as numpy's
+    assert f"Mean density (cgs): {nd.mean():.3e}, Mean ionized fraction: {xh.mean():.3e}" in log
+
+
+def test_grid_sum_and_page_locked_results(asora, tmp_path):
+    """asora_grid_sum against numpy, and the arrays evolve3D returns: page-locked buffers of the library's pool
+    (pyc2ray_amd/_pinned.py), recycled once the caller has dropped them, never while a view is alive."""
+    import gc
+    from pyc2ray_amd import _pinned
+    p, lib, capi = asora
+    N = 40
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 8)
+    rng = np.random.default_rng(77)
+    a = rng.lognormal(0.0, 2.0, (N, N, N))
+    lib.grid_to_device(capi.GRID_NDENS, a)
+    np.testing.assert_allclose(lib.grid_sum(capi.GRID_NDENS), a.sum(), rtol=1e-13)
+    lib.grid_to_device(capi.GRID_XH, np.asfortranarray(-a))
+    np.testing.assert_allclose(lib.grid_sum(capi.GRID_XH), -a.sum(), rtol=1e-13)
+    with pytest.raises(RuntimeError):
+        lib.grid_sum(capi.GRID_PHI_HEAT)                        # nothing was ever put there
+
+    def owner(arr):
+        while isinstance(arr, np.ndarray):
+            arr = arr.base
+        return arr
+
+    thin, thick, dlog = cases.soft_tables()
+    p.photo_table_to_device(thin, thick)
+    nd, xh, dr = cases.grid(N, "lognormal", 5, 0.15, xlo=1e-4, xhi=2e-3)
+    pos, flux = cases.sources(N, 3, 6, flux=30.0)
+    temp = np.full((N, N, N), 1e4)
+    step = lambda x: p.evolve3D(3.15576e13, dr, flux, pos, True, 1000, N, 1e-2, temp, nd, x, thin, thick, cases.MINLOGTAU, dlog,
+                                9.0, 1e-4, cases.SIG, cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C,
+                                logfile=str(tmp_path / "log.txt"), quiet=True)
+    x1, phi1 = step(xh)
+    assert isinstance(owner(x1), _pinned._Owner) and isinstance(owner(phi1), _pinned._Owner)
+    assert _pinned.stats()["pinned_bytes"] >= 2 * N ** 3 * 8
+    keep, view = x1.copy(), x1[3]
+    addr_x1, addr_phi1 = x1.ctypes.data, phi1.ctypes.data
+    x2, phi2 = step(x1)
+    assert len({addr_x1, addr_phi1, x2.ctypes.data, phi2.ctypes.data}) == 4         # all four alive: four buffers
+    np.testing.assert_array_equal(x1, keep)                                        # and the first result is untouched
+    del x1, phi1
+    gc.collect()
+    x3, phi3 = step(x2)
+    assert phi3.ctypes.data == addr_phi1 or x3.ctypes.data == addr_phi1            # the dropped rate grid's buffer is back in use
+    assert addr_x1 not in (x3.ctypes.data, phi3.ctypes.data)                       # `view` still holds the other one
+    np.testing.assert_array_equal(view, keep[3])
+    assert x3.mean() > x2.mean() > keep.mean()
 
 
 # ---- size-independent properties at the benchmark size ------------------------------------------
