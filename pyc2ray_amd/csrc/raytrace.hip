@@ -166,6 +166,19 @@ __device__ __forceinline__ double photo_rate_per_atom(double flux, double cd_in,
 #define ASORA_UNITS_LARGEST_FIRST 1
 #endif
 
+// A wave whose 64 table entries of a step are all padding: 1 = skips the step's arithmetic and lookups, 2 = skips the
+// interpolation only and issues the (unused) lookups like every other wave, 0 = runs the whole step.  With 1 the number
+// of vector-memory operations in flight differs between the two paths, and where they meet the compiler waits as the
+// shorter one demands (three operations too early on every wait of every step).
+#ifndef ASORA_SKIP_EMPTY_WAVES
+#define ASORA_SKIP_EMPTY_WAVES 2
+#endif
+
+// 1: see the comment at the loop entry of the kernel
+#ifndef ASORA_PRIME_PIPELINE
+#define ASORA_PRIME_PIPELINE 1
+#endif
+
 // waves per SIMD the register allocation must leave room for (2nd argument of __launch_bounds__)
 #ifndef ASORA_MIN_WAVES
 #define ASORA_MIN_WAVES 1
@@ -174,7 +187,11 @@ __device__ __forceinline__ double photo_rate_per_atom(double flux, double cd_in,
 constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_RATE = 1u << 29, CELL_NEG = 1u << 28,
                    CELL_SLOT_MASK = (1u << 28) - 1;   // NEG: the cell lies on the mirrored side of the unit's merge axis
 
-template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP, bool HEAT, int TABCAP, bool SKIP_ZERO = false>
+// GREY (ASORA_OPT_GREY_NOTABLES) is a compile-time variant although its branch is wave-uniform: the compiler counts the
+// vector-memory operations in flight per PATH and, where paths of different counts meet, waits as the shortest one
+// demands -- with the grey branch (one atomic, no lookups) in the loop every wait of the table path was three operations
+// too early, i.e. the lookups had to be back at the top of the next step.
+template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP, bool HEAT, int TABCAP, bool SKIP_ZERO = false, bool GREY = false>
 __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_kernel(const RtParams p)
 {
     extern __shared__ double lds_raw[];
@@ -244,7 +261,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
     const double sig = p.sig, dr = p.dr;
     const unsigned negmask = (sa < 0 ? 1u : 0u) | (sb < 0 ? 2u : 0u) | (sc < 0 ? 4u : 0u);
     const bool ztr = p.z_transposed != 0;
-    const bool grey = p.grey != 0;
+    constexpr bool grey = GREY;
 
     unsigned int n_gamma = 0, n_eval = 0;
 
@@ -311,7 +328,11 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
 
         const bool valid = (cur_A.y & CELL_VALID) != 0;
         // waves whose 64 entries are all padding skip the arithmetic (wave-uniform branch)
+#if ASORA_SKIP_EMPTY_WAVES
         const bool wave_has_work = __builtin_amdgcn_readfirstlane((int)__any(valid)) != 0;
+#else
+        const bool wave_has_work = true;
+#endif
         bool rated = false;
         double cd_in = 0.0, cd_out = 0.0, vol_nhi = 1.0;
         double *dst = p.phi;
@@ -381,7 +402,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
         // ---- rates, raytracing.cu:315-328 + rates.cu:16-41 ---------------------------------------
         if (grey) {
             if (rated) unsafeAtomicAdd(dst, grey_rate_per_atom(flux, cd_in, cd_out, vol_nhi, p));
-        } else if (wave_has_work) {
+        } else if (wave_has_work || ASORA_SKIP_EMPTY_WAVES == 2) {
             // (lanes without a rate run the lookups on whatever they hold: the index is clamped for any input)
             const double tau_in = mul_unfused(cd_in, sig), tau_out = mul_unfused(cd_out, sig);   // un-fused, see rate_issue
             // TAU_PHOTO_LIMIT: rates.cu:7 (double 1e-7) or photorates.f90:69 (single 1e-7 promoted)
@@ -468,6 +489,20 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
     uint4 A2, B2;
     unsigned idx0, idx1 = 0, idx2 = 0;
     double nhi0 = *nhi_address(A0.x, A0.y, idx0), nhi1 = 0.0, nhi2 = 0.0;
+#if ASORA_LATE_LOOKUP && ASORA_PRIME_PIPELINE
+    // The loop is entered with the loads in flight that a step leaves behind, in the same order (tables, nHI, two lookups):
+    // the compiler merges the counts of outstanding operations of the loop entry with those of the back edge and waits as
+    // the SHORTER history demands, so without these two (unused) lookups every first step of the unrolled three waited
+    // for its nHI and its predecessor's lookups as if nothing else were in flight.
+    if (!GREY) {
+        __builtin_amdgcn_sched_barrier(0);          // behind the nHI load, as in a step
+        const double2 *__restrict__ prime = p.tables + (threadIdx.x & 1);
+        pend_A.t = prime[0];
+        if (HEAT) pend_A.h = prime[2 * p.table_len];
+        pend_B.t = prime[p.table_len];
+        if (HEAT) pend_B.h = prime[3 * p.table_len - 1];
+    }
+#endif
 
     // nsteps is a multiple of 3 (the tables are padded to it) and is followed by two more
     // all-invalid steps, so every look-ahead stays inside the tables.
@@ -1139,21 +1174,23 @@ template <int T, int TABCAP>
 static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t lds_bytes, bool use_lds, bool dump, bool heat,
                           hipStream_t stream)
 {
-#define ASORA_LAUNCH(GS, DP, HT)                                                                                   \
+#define ASORA_LAUNCH(GS, DP, HT, SZ, GR)                                                                           \
     do {                                                                                                           \
-        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, GS, DP, HT, TABCAP>,             \
+        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, GS, DP, HT, TABCAP, SZ, GR>,     \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));            \
-        hipLaunchKernelGGL((raytrace_octant_kernel<T, GS, DP, HT, TABCAP>), dim3(grid), dim3(T), lds_bytes,        \
+        hipLaunchKernelGGL((raytrace_octant_kernel<T, GS, DP, HT, TABCAP, SZ, GR>), dim3(grid), dim3(T), lds_bytes, \
                            stream, q);                                                                          \
     } while (0)
-    if (T == 256 && dump) { if (use_lds) ASORA_LAUNCH(false, true, false); else ASORA_LAUNCH(true, true, false); }
-    else if (heat)        { if (use_lds) ASORA_LAUNCH(false, false, true); else ASORA_LAUNCH(true, false, true); }
-    else if (use_lds && std::isfinite(q.tau_zero)) {       // ASORA_OPT_SKIP_ZERO_RATES: the variant that leaves exact zeros out
-        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, false, TABCAP, true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, false, TABCAP, true>), dim3(grid), dim3(T), lds_bytes, stream, q);
+    const bool grey = q.grey != 0;
+    if (T == 256 && dump) {
+        if (grey)         { if (use_lds) ASORA_LAUNCH(false, true, false, false, true); else ASORA_LAUNCH(true, true, false, false, true); }
+        else              { if (use_lds) ASORA_LAUNCH(false, true, false, false, false); else ASORA_LAUNCH(true, true, false, false, false); }
     }
-    else                  { if (use_lds) ASORA_LAUNCH(false, false, false); else ASORA_LAUNCH(true, false, false); }
+    else if (grey)        { if (use_lds) ASORA_LAUNCH(false, false, false, false, true); else ASORA_LAUNCH(true, false, false, false, true); }
+    else if (heat)        { if (use_lds) ASORA_LAUNCH(false, false, true, false, false); else ASORA_LAUNCH(true, false, true, false, false); }
+    // ASORA_OPT_SKIP_ZERO_RATES: the variant that leaves exact zeros out
+    else if (use_lds && std::isfinite(q.tau_zero)) ASORA_LAUNCH(false, false, false, true, false);
+    else                  { if (use_lds) ASORA_LAUNCH(false, false, false, false, false); else ASORA_LAUNCH(true, false, false, false, false); }
 #undef ASORA_LAUNCH
     ASORA_HIP_TRY(hipGetLastError());
     return 0;
