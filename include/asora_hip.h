@@ -273,7 +273,11 @@ enum {
      *    last entry (the benchmark medium at r_RT = 64: -25 %); costs 4.5 % where nothing can be left out, hence
      *    0 (default): every rated cell is looked up and added, as the reference does (rates.cu:16-41, raytracing.cu:328). */
     ASORA_OPT_SKIP_ZERO_RATES = 11,
-    ASORA_OPT_COUNT = 12
+    /* 1: the rate atomics are global_atomic_add_f64 under `if (lane has a rate)` even where the grids are small enough for
+     *    the default, buffer_atomic_add_f64 through a descriptor over [phi | phi_t] with out-of-range offsets for lanes
+     *    without a rate (N <= 512).  Same arithmetic; for A/B runs and the parity test of the two forms. */
+    ASORA_OPT_GLOBAL_ATOMICS = 12,
+    ASORA_OPT_COUNT = 13
 };
 int asora_set_option(int option, int value);
 int asora_get_option(int option);

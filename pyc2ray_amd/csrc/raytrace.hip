@@ -137,11 +137,18 @@ __device__ __forceinline__ double photo_rate_per_atom(double flux, double cd_in,
 // atomics, 2 the rates, 4 the shell barriers, to attribute kernel time.  Production builds contain none of it.
 #ifdef ASORA_ENABLE_ABLATION
 #define ASORA_ABLATED(bit) ((p.ablate & (bit)) != 0)
-#define ASORA_RATE_ATOMIC(dst, v) do { if (!(p.ablate & 1)) unsafeAtomicAdd((dst), (v)); else if ((v) == 1.2345e-300) (dst)[0] = (v); } while (0)
 #else
 #define ASORA_ABLATED(bit) false
-#define ASORA_RATE_ATOMIC(dst, v) unsafeAtomicAdd((dst), (v))
 #endif
+
+// buffer_atomic_add_f64 through a raw buffer descriptor: a lane whose offset lies beyond the descriptor's range is dropped
+// by the hardware, so "this lane has nothing to add" is an offset of -1 and the instruction needs no branch around it
+// (clang has no builtin for the f64 form; this binds the LLVM intrinsic).
+// The offset of such a lane is 2 GiB, and the descriptors never span more than 2 GiB: the range check is
+// offset + 8 > num_records in 32-bit arithmetic, so an offset near 2^32 would wrap around and pass it.
+#define ASORA_OOB_OFFSET ((int)0x80000000u)
+extern "C" __device__ double asora_buffer_atomic_fadd_f64(double, __amdgpu_buffer_rsrc_t, int, int, int)
+    __asm("llvm.amdgcn.raw.ptr.buffer.atomic.fadd.f64");
 
 // 1: the rate atomic of a step is issued in the NEXT step, right behind that step's table-lookup loads.  Vector
 // memory operations complete in issue order, so a lookup issued after an atomic cannot return before the atomic has
@@ -179,6 +186,13 @@ __device__ __forceinline__ double photo_rate_per_atom(double flux, double cd_in,
 #define ASORA_PRIME_PIPELINE 1
 #endif
 
+// 1: a scheduling barrier between the unrolled steps.  Without it the compiler hoists the decoding of a table entry (the
+// address of the NEXT step's nHI) into the step that loaded the entry, i.e. waits for a load issued 250 instructions ago
+// with two newer ones in flight instead of a whole step later.
+#ifndef ASORA_STEP_SCHED_BARRIER
+#define ASORA_STEP_SCHED_BARRIER 1
+#endif
+
 // waves per SIMD the register allocation must leave room for (2nd argument of __launch_bounds__)
 #ifndef ASORA_MIN_WAVES
 #define ASORA_MIN_WAVES 1
@@ -191,7 +205,12 @@ constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_RATE = 1u <
 // vector-memory operations in flight per PATH and, where paths of different counts meet, waits as the shortest one
 // demands -- with the grey branch (one atomic, no lookups) in the loop every wait of the table path was three operations
 // too early, i.e. the lookups had to be back at the top of the next step.
-template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP, bool HEAT, int TABCAP, bool SKIP_ZERO = false, bool GREY = false>
+// BUFATOM: the rate atomics go through buffer descriptors over [phi | phi_t] and [heat | heat_t] (possible while the
+// pair of grids stays within 2 GiB, N <= 512): the atomic of a step is then ONE unconditional instruction -- with
+// `if (lane has a rate) atomic` the compiler sees a path without the atomic and counts one operation too few in flight
+// behind every earlier load, i.e. every wait for a lookup also waited for the atomic issued after it.
+template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP, bool HEAT, int TABCAP, bool SKIP_ZERO = false, bool GREY = false,
+          bool BUFATOM = false>
 __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_kernel(const RtParams p)
 {
     extern __shared__ double lds_raw[];
@@ -265,6 +284,20 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
 
     unsigned int n_gamma = 0, n_eval = 0;
 
+    // rate accumulation: `idx` indexes [phi | phi_t] (and [heat | heat_t])
+    __amdgpu_buffer_rsrc_t rs_phi = __builtin_amdgcn_make_buffer_rsrc(p.phi, 0, BUFATOM ? (int)(16u * p.ncell) : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_heat = __builtin_amdgcn_make_buffer_rsrc(HEAT ? p.heat : p.phi, 0, (BUFATOM && HEAT) ? (int)(16u * p.ncell) : 0, 0x00020000);
+    auto add_phi = [&](bool ok, unsigned idx, double v) {
+        if (ASORA_ABLATED(1)) ok = ok && v == 1.2345e-300;
+        if (ASORA_ABLATED(64)) idx &= 0xFFFFu;            // diagnostic: all rates into a 512 KiB window (wrong results)
+        if (BUFATOM) (void)asora_buffer_atomic_fadd_f64(v, rs_phi, ok ? (int)(idx * 8u) : ASORA_OOB_OFFSET, 0, 0);
+        else if (ok) unsafeAtomicAdd(p.phi + idx, v);
+    };
+    auto add_heat = [&](bool ok, unsigned idx, double v) {
+        if (BUFATOM) (void)asora_buffer_atomic_fadd_f64(v, rs_heat, ok ? (int)(idx * 8u) : ASORA_OOB_OFFSET, 0, 0);
+        else if (ok) unsafeAtomicAdd(p.heat + idx, v);
+    };
+
     // ---- shell 0: the source cell (raytracing.cu:285-294) -----------------------------------
     if (threadIdx.x == 0) {
         const unsigned idx = ((unsigned)i0 * N + j0) * N + k0;
@@ -298,6 +331,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
         const bool zt = ztr && (abc >> 30) == 2;
         // the [k][j][i] copies follow the [i][j][k] grids in memory: one 32-bit index covers both
         idx = zt ? (k * N + j) * N + i + p.ncell : (i * N + j) * N + k;
+        if (ASORA_ABLATED(128)) return p.nhi + (idx & 0xFFFFu);   // diagnostic: nHI from a 512 KiB window (wrong results)
         return p.nhi + idx;
     };
 
@@ -311,7 +345,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
 #if !ASORA_LATE_LOOKUP
     double late_v = 0.0, late_h = 0.0;
 #endif
-    double *late_dst = p.phi;
+    unsigned late_idx = 0;
 #if ASORA_LATE_LOOKUP
     Lookup pend_A, pend_B;             // lookups issued in the previous step, consumed in this one
     pend_A.t = pend_B.t = pend_A.h = pend_B.h = double2{0.0, 0.0};
@@ -322,8 +356,17 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
 
     auto step = [&](unsigned e_pf, const uint4 &cur_A, const uint4 &cur_B, const double cur_nhi, const unsigned cur_idx,
                     const uint4 &nxt_A, double &nxt_nhi, unsigned &nxt_idx, uint4 &pf_A, uint4 &pf_B) {
+#if ASORA_STEP_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);      // nothing of this step is scheduled into the previous one (see the macro)
+#endif
         pf_A = cellA[e_pf];                                         // two steps ahead
         pf_B = cellB[e_pf];
+#ifdef ASORA_DIAG_EXTRA_TABLE_LOAD      // diagnostic build only: 16 more bytes per lane and step from ANOTHER unit's table (equal sizes: octants)
+        {
+            const uint4 extra = p.geom[(unit + 1) % p.units].cellA[e_pf];
+            n_eval += (extra.x == 0xdeadbeefu && extra.w == 0x12345u) ? 1u : 0u;
+        }
+#endif
         nxt_nhi = *nhi_address(nxt_A.x, nxt_A.y, nxt_idx);          // one step ahead
 
         const bool valid = (cur_A.y & CELL_VALID) != 0;
@@ -335,7 +378,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
 #endif
         bool rated = false;
         double cd_in = 0.0, cd_out = 0.0, vol_nhi = 1.0;
-        double *dst = p.phi;
+        unsigned dst_idx = 0;
         if (wave_has_work) {
         const unsigned abc = cur_A.x;
         const int a = abc & 1023, b = (abc >> 10) & 1023, c = (abc >> 20) & 1023;
@@ -362,7 +405,11 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
         const double m12 = m1 * m2, m34 = m3 * m4;
         const double q1 = (fu * fv) * (m2 * m34), q2 = (fv * gu) * (m1 * m34);
         const double q3 = (fu * gv) * (m12 * m4), q4 = (gu * gv) * (m12 * m3);
+#ifdef ASORA_DIAG_NO_DIVISION        // diagnostic build only (wrong values): what the two divisions of a cell cost
+        cd_in = (x1 * q1 + x2 * q2 + x3 * q3 + x4 * q4) * __builtin_amdgcn_rcp(q1 + q2 + q3 + q4);
+#else
         cd_in = (x1 * q1 + x2 * q2 + x3 * q3 + x4 * q4) / (q1 + q2 + q3 + q4);
+#endif
         if (s == 1) {                                    // diagonal neighbours of the source, cu:431-441
             const int nz = (a == 0) + (b == 0) + (c == 0);
             const double r3 = p.fortran_consts ? (double)1.7320507764816284 : 1.73205080757; // f90:608 / cu:435
@@ -391,7 +438,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
         n_gamma += (owner && cd_in <= maxcd) ? 1u : 0u;
         const double n2 = (double)(a * a + b * b + c * c);
         vol_nhi = n2 * (dr * dr * FOURPI) * path * nHI;                     // raytracing.cu:302-307
-        dst = p.phi + cur_idx;
+        dst_idx = cur_idx;
         }
 
         if (__builtin_amdgcn_readfirstlane(cur_A.y) & CELL_LAST) {   // shell finished: publish it
@@ -401,7 +448,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
 
         // ---- rates, raytracing.cu:315-328 + rates.cu:16-41 ---------------------------------------
         if (grey) {
-            if (rated) unsafeAtomicAdd(dst, grey_rate_per_atom(flux, cd_in, cd_out, vol_nhi, p));
+            add_phi(rated, dst_idx, grey_rate_per_atom(flux, cd_in, cd_out, vol_nhi, p));
         } else if (wave_has_work || ASORA_SKIP_EMPTY_WAVES == 2) {
             // (lanes without a rate run the lookups on whatever they hold: the index is clamped for any input)
             const double tau_in = mul_unfused(cd_in, sig), tau_out = mul_unfused(cd_out, sig);   // un-fused, see rate_issue
@@ -437,26 +484,27 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
                 Lookup A2 = pend_A, B2 = pend_B;
                 double pref = 0.0;
                 if (wave_adds) {
+#ifdef ASORA_DIAG_NO_DIVISION
+                    pref = flux * __builtin_amdgcn_rcp(vol_nhi);
+#else
                     pref = flux / vol_nhi;
+#endif
                     A2 = lookup_issue<HEAT>(tab, thick ? tau_in : tau_thin, p, logtab);
                     B2 = lookup_issue<HEAT>(tab, thick ? tau_out : tau_thin, p, logtab);
                 }
-                if (late_ok) {
-                    ASORA_RATE_ATOMIC(late_dst, v_prev);
-                    if (HEAT) unsafeAtomicAdd(p.heat + (late_dst - p.phi), h_prev);
-                }
+                add_phi(late_ok, late_idx, v_prev);
+                if (HEAT) add_heat(late_ok, late_idx, h_prev);
                 pend_A = A2; pend_B = B2; pend_thick = thick; pend_pref = pref; pend_dtau = dtau;
-                late_dst = dst;
+                late_idx = dst_idx;
                 late_ok = add;
             }
 #elif ASORA_LATE_ATOMIC
             const double pref = flux / vol_nhi;
             const Lookup A = lookup_issue<HEAT>(tab, thick ? tau_in : tau_thin, p, logtab);
             const Lookup B = lookup_issue<HEAT>(tab, thick ? tau_out : tau_thin, p, logtab);
-            if (late_ok) {       // the previous step's rate, behind this step's lookups in the memory pipeline
-                ASORA_RATE_ATOMIC(late_dst, late_v);
-                if (HEAT) unsafeAtomicAdd(p.heat + (late_dst - p.phi), late_h);
-            }
+            // the previous step's rate, behind this step's lookups in the memory pipeline
+            add_phi(late_ok, late_idx, late_v);
+            if (HEAT) add_heat(late_ok, late_idx, late_h);
             {
                 const double ta = lookup_value(A), tb = lookup_value(B);
                 late_v = thick ? pref * (ta - tb) : pref * dtau * ta;     // see rate_value on the form of the difference
@@ -464,19 +512,19 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
                     const double ha = lookup_heat(A), hb = lookup_heat(B);
                     late_h = thick ? pref * (ha - hb) : pref * dtau * ha;
                 }
-                late_dst = dst;
+                late_idx = dst_idx;
                 late_ok = rated;
             }
 #else
             const double pref = flux / vol_nhi;
             const Lookup A = lookup_issue<HEAT>(tab, thick ? tau_in : tau_thin, p, logtab);
             const Lookup B = lookup_issue<HEAT>(tab, thick ? tau_out : tau_thin, p, logtab);
-            if (rated) {
+            {
                 const double ta = lookup_value(A), tb = lookup_value(B);
-                ASORA_RATE_ATOMIC(dst, thick ? pref * (ta - tb) : pref * dtau * ta);
+                add_phi(rated, dst_idx, thick ? pref * (ta - tb) : pref * dtau * ta);
                 if (HEAT) {      // photorates.f90:118,124 with the same table index and residual
                     const double ha = lookup_heat(A), hb = lookup_heat(B);
-                    unsafeAtomicAdd(p.heat + (dst - p.phi), thick ? pref * (ha - hb) : pref * dtau * ha);
+                    add_heat(rated, dst_idx, thick ? pref * (ha - hb) : pref * dtau * ha);
                 }
             }
 #endif
@@ -501,6 +549,11 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
         if (HEAT) pend_A.h = prime[2 * p.table_len];
         pend_B.t = prime[p.table_len];
         if (HEAT) pend_B.h = prime[3 * p.table_len - 1];
+        if (BUFATOM) {                              // ... and the (dropped) atomic that follows them
+            __builtin_amdgcn_sched_barrier(0);
+            (void)asora_buffer_atomic_fadd_f64(0.0, rs_phi, ASORA_OOB_OFFSET, 0, 0);
+            if (HEAT) (void)asora_buffer_atomic_fadd_f64(0.0, rs_heat, ASORA_OOB_OFFSET, 0, 0);
+        }
     }
 #endif
 
@@ -512,19 +565,17 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
         step(e + 4 * RT_THREADS, A2, B2, nhi2, idx2, A0, nhi0, idx0, A1, B1);
     }
 #if ASORA_LATE_LOOKUP
-    if (late_ok) {
+    {
         const double ta = lookup_value(pend_A), tb = lookup_value(pend_B);
-        ASORA_RATE_ATOMIC(late_dst, pend_thick ? pend_pref * (ta - tb) : pend_pref * pend_dtau * ta);
+        add_phi(late_ok, late_idx, pend_thick ? pend_pref * (ta - tb) : pend_pref * pend_dtau * ta);
         if (HEAT) {
             const double ha = lookup_heat(pend_A), hb = lookup_heat(pend_B);
-            unsafeAtomicAdd(p.heat + (late_dst - p.phi), pend_thick ? pend_pref * (ha - hb) : pend_pref * pend_dtau * ha);
+            add_heat(late_ok, late_idx, pend_thick ? pend_pref * (ha - hb) : pend_pref * pend_dtau * ha);
         }
     }
 #else
-    if (late_ok) {
-        ASORA_RATE_ATOMIC(late_dst, late_v);
-        if (HEAT) unsafeAtomicAdd(p.heat + (late_dst - p.phi), late_h);
-    }
+    add_phi(late_ok, late_idx, late_v);
+    if (HEAT) add_heat(late_ok, late_idx, late_h);
 #endif
 
     // work accounting: one atomic per wave
@@ -1174,23 +1225,25 @@ template <int T, int TABCAP>
 static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t lds_bytes, bool use_lds, bool dump, bool heat,
                           hipStream_t stream)
 {
-#define ASORA_LAUNCH(GS, DP, HT, SZ, GR)                                                                           \
+#define ASORA_LAUNCH(GS, DP, HT, SZ, GR, BA)                                                                           \
     do {                                                                                                           \
-        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, GS, DP, HT, TABCAP, SZ, GR>,     \
+        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, GS, DP, HT, TABCAP, SZ, GR, BA>, \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));            \
-        hipLaunchKernelGGL((raytrace_octant_kernel<T, GS, DP, HT, TABCAP, SZ, GR>), dim3(grid), dim3(T), lds_bytes, \
-                           stream, q);                                                                          \
+        hipLaunchKernelGGL((raytrace_octant_kernel<T, GS, DP, HT, TABCAP, SZ, GR, BA>), dim3(grid), dim3(T),       \
+                           lds_bytes, stream, q);                                                                  \
     } while (0)
     const bool grey = q.grey != 0;
+    // rate atomics through buffer descriptors (see the kernel's BUFATOM): [phi | phi_t] must not exceed 2 GiB
+    const bool ba = use_lds && 16ull * q.ncell <= 0x80000000ull && !st.opt[ASORA_OPT_GLOBAL_ATOMICS];
     if (T == 256 && dump) {
-        if (grey)         { if (use_lds) ASORA_LAUNCH(false, true, false, false, true); else ASORA_LAUNCH(true, true, false, false, true); }
-        else              { if (use_lds) ASORA_LAUNCH(false, true, false, false, false); else ASORA_LAUNCH(true, true, false, false, false); }
+        if (grey)         { if (use_lds) ASORA_LAUNCH(false, true, false, false, true, false); else ASORA_LAUNCH(true, true, false, false, true, false); }
+        else              { if (use_lds) ASORA_LAUNCH(false, true, false, false, false, false); else ASORA_LAUNCH(true, true, false, false, false, false); }
     }
-    else if (grey)        { if (use_lds) ASORA_LAUNCH(false, false, false, false, true); else ASORA_LAUNCH(true, false, false, false, true); }
-    else if (heat)        { if (use_lds) ASORA_LAUNCH(false, false, true, false, false); else ASORA_LAUNCH(true, false, true, false, false); }
+    else if (grey)        { if (ba) ASORA_LAUNCH(false, false, false, false, true, true); else if (use_lds) ASORA_LAUNCH(false, false, false, false, true, false); else ASORA_LAUNCH(true, false, false, false, true, false); }
+    else if (heat)        { if (ba) ASORA_LAUNCH(false, false, true, false, false, true); else if (use_lds) ASORA_LAUNCH(false, false, true, false, false, false); else ASORA_LAUNCH(true, false, true, false, false, false); }
     // ASORA_OPT_SKIP_ZERO_RATES: the variant that leaves exact zeros out
-    else if (use_lds && std::isfinite(q.tau_zero)) ASORA_LAUNCH(false, false, false, true, false);
-    else                  { if (use_lds) ASORA_LAUNCH(false, false, false, false, false); else ASORA_LAUNCH(true, false, false, false, false); }
+    else if (use_lds && std::isfinite(q.tau_zero)) ASORA_LAUNCH(false, false, false, true, false, false);
+    else                  { if (ba) ASORA_LAUNCH(false, false, false, false, false, true); else if (use_lds) ASORA_LAUNCH(false, false, false, false, false, false); else ASORA_LAUNCH(true, false, false, false, false, false); }
 #undef ASORA_LAUNCH
     ASORA_HIP_TRY(hipGetLastError());
     return 0;
@@ -1226,7 +1279,10 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
     const size_t fixed_bytes = lds_table_bytes(big_tables ? 1024 : small_tables ? 64 : 256);
     const size_t shell_bytes = 2 * slots * sizeof(double);
     const bool use_lds = shell_bytes + fixed_bytes <= LDS_LIMIT_BYTES;
-    const size_t lds_bytes = (use_lds ? shell_bytes : 0) + fixed_bytes;
+    size_t lds_bytes = (use_lds ? shell_bytes : 0) + fixed_bytes;
+#ifdef ASORA_ENABLE_ABLATION        // diagnostic builds only: unused LDS per workgroup, to lower the occupancy (ASORA_DIAG_EXTRA_LDS bytes)
+    if (const char *e = getenv("ASORA_DIAG_EXTRA_LDS")) lds_bytes = std::min<size_t>(LDS_LIMIT_BYTES, lds_bytes + (size_t)atol(e));
+#endif
     // launches that share the global shell scratch stay on the main stream (one at a time)
     hipStream_t stream = (side && use_lds) ? side : st.stream;
     if (side && !use_lds) {       // ... behind whatever the side streams still run, and the side streams behind it

@@ -1064,6 +1064,73 @@ def test_leaving_out_exactly_zero_rates_changes_nothing(asora):
         assert (zeros > 0.5) if tau_cell == 3000.0 else (zeros < 0.5)
 
 
+def test_buffer_and_global_rate_atomics_give_the_same_rates(asora):
+    """The rate atomics go through buffer descriptors by default (out-of-range offset = lane has nothing to add) and as
+    global atomics under a branch with ASORA_OPT_GLOBAL_ATOMICS: one source (no summation-order freedom) -> IDENTICAL grids,
+    for every decomposition (octants, sectors, mirrored pairs, quarter sectors), with heating, with the grey opacity and
+    with the [k][j][i] accumulator copy on and off; several sources against the oracle."""
+    p, lib, capi = asora
+    N = 40
+    thin, thick, dlog = cases.soft_tables(400)
+    heat_thin, heat_thick = 0.7 * thin + 0.01, 0.6 * thick + 0.02
+    nd, xh, dr = cases.grid(N, "lognormal", 11, 0.4, xlo=1e-4, xhi=1e-2)
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 8)
+    p.photo_table_to_device(thin, thick)
+    lib.heat_table_to_device(heat_thin, heat_thick, thin.shape[0])
+    lib.grid_to_device(capi.GRID_NDENS, nd)
+    lib.grid_to_device(capi.GRID_XH_AV, xh)
+    pos, flux = np.array([[N], [1], [17]]), np.array([3.0])           # on a corner plane: the periodic wrap is in play
+    p0, f0 = cases.flat_sources(pos, flux)
+    lib.source_data_to_device(p0, f0, 1)
+
+    def trace(R, n=1):
+        lib.raytrace_device(R, cases.SIG, dr, 0, n, cases.MINLOGTAU, dlog, thin.shape[0])
+        return lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+
+    def both(R, **opts):
+        out = []
+        for glob in (0, 1):
+            lib.set_option(capi.OPT_GLOBAL_ATOMICS, glob)
+            for k, v in opts.items():
+                lib.set_option(getattr(capi, k), v)
+            try:
+                phi = trace(R)
+                heat = lib.grid_to_host(capi.GRID_PHI_HEAT, np.empty((N, N, N))) if opts.get("OPT_HEATING") else None
+            finally:
+                lib.set_option(capi.OPT_GLOBAL_ATOMICS, 0)
+                for k in opts:
+                    lib.set_option(getattr(capi, k), 1 if k == "OPT_Z_TRANSPOSED" else 0)
+            out.append((phi, heat))
+        assert np.array_equal(out[0][0], out[1][0]) and out[0][0].max() > 0
+        if out[0][1] is not None:
+            assert np.array_equal(out[0][1], out[1][1]) and out[0][1].max() > 0
+        return out[0][0]
+
+    for R in (6.5, 13.0, 1000.0):
+        for mode in (0, 1, 2, 3, 4):                              # automatic, octants, sectors, mirrored pairs, quarter sectors
+            both(R, OPT_SECTORS=mode)
+        both(R, OPT_HEATING=1)
+        both(R, OPT_GREY_NOTABLES=1)
+        both(R, OPT_Z_TRANSPOSED=0)
+    # many sources, both forms against the oracle
+    pos, flux = cases.sources(N, 9, 12, flux=2.0)
+    p0, f0 = cases.flat_sources(pos, flux)
+    lib.source_data_to_device(p0, f0, 9)
+    ref = O.asora_do_all_sources(9.0, cases.SIG, dr, nd, xh, p0, f0, thin, thick, cases.MINLOGTAU, dlog,
+                                 NumTau=thin.shape[0], flags=O.ASORA_MODE)["phi_ion"]
+    for glob in (0, 1):
+        lib.set_option(capi.OPT_GLOBAL_ATOMICS, glob)
+        try:
+            phi = trace(9.0, 9)
+        finally:
+            lib.set_option(capi.OPT_GLOBAL_ATOMICS, 0)
+        assert np.array_equal(phi == 0, ref == 0)
+        w = ref != 0
+        np.testing.assert_allclose(phi[w], ref[w], rtol=GAMMA_RTOL, atol=0)
+
+
 def test_randomised_time_steps_of_the_device_resident_loop_against_the_oracle_loop(asora, tmp_path):
     """Seeded sweep of whole time steps through evolve3D (device-resident loop): odd and even meshes (tiles of the fused
     pass cut by the mesh edge), radii from one cell to beyond the box, 1 to 6 sources (criterion (NumSrc-1)/3 = 0 for one
