@@ -42,6 +42,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -955,6 +956,10 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
     }
     std::vector<HostGeom> hg(units);
     OctGeomDev od[MAX_UNITS];
+    const bool geom_timing = getenv("ASORA_GEOM_TIMING") != nullptr;
+    auto now_s = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now_s();
+    double t_sectors = t_begin;
     int Smax = 0;
     uint32_t max_cells = 1;
     const uint32_t MARK = 0xffffffffu;
@@ -963,18 +968,37 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
         // cells per unit set -- ~1 s on one core at 320^3)
         std::vector<std::thread> workers;
         const double R_all = p.R, dr_all = p.dr;
-        for (int u = 0; u < units; ++u) {
-            if (owner[u] != u) continue;
-            workers.emplace_back([&hg, &spec, u, R_all, dr_all, q_max, threads]() {
-                if (spec[u].wedge < 0) { build_unit_geometry(hg[u], spec[u], R_all, dr_all, q_max, MARK, threads); return; }
-                HostGeom sector;                     // the whole sector first, then the wedge and what it reads
-                UnitSpec whole = spec[u];
-                whole.wedge = -1;
-                build_unit_geometry(sector, whole, R_all, dr_all, q_max, MARK, threads);
-                hg[u] = restrict_to_wedge(sector, spec[u].wedge, threads, MARK);
-            });
+        if (units != 96) {
+            for (int u = 0; u < units; ++u) {
+                if (owner[u] != u) continue;
+                workers.emplace_back([&hg, &spec, u, R_all, dr_all, q_max, threads]() {
+                    build_unit_geometry(hg[u], spec[u], R_all, dr_all, q_max, MARK, threads);
+                });
+            }
+            for (auto &w : workers) w.join();
+        } else {
+            // quarter sectors: every distinct sector ONCE (units 0..23 are the wedge-0 units, one per sector and octant),
+            // then its four wedges and what they read, again side by side
+            std::vector<HostGeom> sector(24);
+            for (int v = 0; v < 24; ++v) {
+                if (owner[v] != v) continue;
+                workers.emplace_back([&sector, &spec, v, R_all, dr_all, q_max, threads]() {
+                    UnitSpec whole = spec[v];
+                    whole.wedge = -1;
+                    build_unit_geometry(sector[v], whole, R_all, dr_all, q_max, MARK, threads);
+                });
+            }
+            for (auto &w : workers) w.join();
+            workers.clear();
+            t_sectors = now_s();
+            for (int u = 0; u < units; ++u) {
+                if (owner[u] != u) continue;
+                workers.emplace_back([&hg, &sector, &spec, &owner, u, threads]() {
+                    hg[u] = restrict_to_wedge(sector[owner[u % 24]], spec[u].wedge, threads, MARK);
+                });
+            }
+            for (auto &w : workers) w.join();
         }
-        for (auto &w : workers) w.join();
     }
     for (int u = 0; u < units; ++u) {
         if (owner[u] != u) continue;
@@ -984,6 +1008,7 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
         max_cells = std::max(max_cells, hg[u].max_cells);
         dr_matters = dr_matters || hg[u].on_sphere;
     }
+    const double t_built = now_s();
     // zero-slot marker -> max_cells (the slot that holds 0.0), then upload
     for (int u = 0; u < units; ++u) {
         if (owner[u] != u) continue;
@@ -1002,6 +1027,12 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
         od[u] = d;
     }
     for (int u = 0; u < units; ++u) { od[u] = od[owner[u]]; od[u].info = info[u]; }
+    if (geom_timing) {
+        size_t entries = 0;
+        for (int u = 0; u < units; ++u) if (owner[u] == u) entries += hg[u].cellA.size();
+        fprintf(stderr, "asora geometry: %d units, %.1f M entries (%.0f MB); sectors %.3f s, wedges/units %.3f s, markers + upload %.3f s\n",
+                units, entries * 1e-6, entries * 32e-6, t_sectors - t_begin, t_built - t_sectors, now_s() - t_built);
+    }
 
     if (int rc = ensure_logtab(st)) return rc;
     const double2 *ltd = st.logtab_dev;
