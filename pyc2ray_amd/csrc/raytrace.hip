@@ -161,7 +161,7 @@ extern "C" __device__ double asora_buffer_atomic_fadd_f64(double, __amdgpu_buffe
 
 // 1: the table lookups of a step are CONSUMED in the next step (their rate is formed there, right before that step's
 // own lookups are issued, and added behind them): a whole step of arithmetic hides their latency.  Pays where the
-// kernel is latency-bound; costs 14 VGPRs (119 instead of 105: still 4 waves per SIMD).  Measured on MI355X, 1000 sources,
+// kernel is latency-bound; costs 14 VGPRs (the kernel as a whole needs 96 with buffer atomics).  Measured on MI355X, 1000 sources,
 // 256^3 (tools/ab_macro.sh ASORA_LATE_LOOKUP "0 1" ...): R = 16 -1.0 %, 24 -3.5 %, 32 -1.9 %, 48 -1.7 %, 64 -1.7 %.
 #ifndef ASORA_LATE_LOOKUP
 #define ASORA_LATE_LOOKUP 1
