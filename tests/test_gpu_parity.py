@@ -1066,11 +1066,12 @@ def test_leaving_out_exactly_zero_rates_changes_nothing(asora):
 
 def test_buffer_and_global_rate_atomics_give_the_same_rates(asora):
     """The rate atomics go through buffer descriptors by default (out-of-range offset = lane has nothing to add) and as
-    global atomics under a branch with ASORA_OPT_GLOBAL_ATOMICS: one source (no summation-order freedom) -> IDENTICAL grids,
-    for every decomposition (octants, sectors, mirrored pairs, quarter sectors), with heating, with the grey opacity and
-    with the [k][j][i] accumulator copy on and off; several sources against the oracle."""
+    global atomics under a branch with ASORA_OPT_GLOBAL_ATOMICS.  80 sources whose spheres do not overlap (no
+    summation-order freedom) -> IDENTICAL grids, for every decomposition (octants, sectors, mirrored pairs), with heating,
+    with the grey opacity and with the [k][j][i] accumulator copy on and off; overlapping sources of both forms against the
+    oracle."""
     p, lib, capi = asora
-    N = 40
+    N = 96
     thin, thick, dlog = cases.soft_tables(400)
     heat_thin, heat_thick = 0.7 * thin + 0.01, 0.6 * thick + 0.02
     nd, xh, dr = cases.grid(N, "lognormal", 11, 0.4, xlo=1e-4, xhi=1e-2)
@@ -1081,11 +1082,16 @@ def test_buffer_and_global_rate_atomics_give_the_same_rates(asora):
     lib.heat_table_to_device(heat_thin, heat_thick, thin.shape[0])
     lib.grid_to_device(capi.GRID_NDENS, nd)
     lib.grid_to_device(capi.GRID_XH_AV, xh)
-    pos, flux = np.array([[N], [1], [17]]), np.array([3.0])           # on a corner plane: the periodic wrap is in play
+    lattice = np.array([(i, j, k) for i in range(1, N, 12) for j in range(1, N, 12) for k in range(1, N, 12)]).T     # spacing 12 > 2 R
+    rng = np.random.RandomState(3)
+    pick = rng.permutation(lattice.shape[1])[:80]
+    pos = lattice[:, pick].copy()
+    pos[:, 0] = [1, 1, 1]                                       # a corner: the periodic wrap is in play
+    flux = rng.uniform(1.0, 5.0, 80)
     p0, f0 = cases.flat_sources(pos, flux)
-    lib.source_data_to_device(p0, f0, 1)
+    lib.source_data_to_device(p0, f0, 80)
 
-    def trace(R, n=1):
+    def trace(R, n):
         lib.raytrace_device(R, cases.SIG, dr, 0, n, cases.MINLOGTAU, dlog, thin.shape[0])
         return lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
 
@@ -1096,7 +1102,7 @@ def test_buffer_and_global_rate_atomics_give_the_same_rates(asora):
             for k, v in opts.items():
                 lib.set_option(getattr(capi, k), v)
             try:
-                phi = trace(R)
+                phi = trace(R, 80)
                 heat = lib.grid_to_host(capi.GRID_PHI_HEAT, np.empty((N, N, N))) if opts.get("OPT_HEATING") else None
             finally:
                 lib.set_option(capi.OPT_GLOBAL_ATOMICS, 0)
@@ -1108,22 +1114,21 @@ def test_buffer_and_global_rate_atomics_give_the_same_rates(asora):
             assert np.array_equal(out[0][1], out[1][1]) and out[0][1].max() > 0
         return out[0][0]
 
-    for R in (6.5, 13.0, 1000.0):
-        for mode in (0, 1, 2, 3, 4):                              # automatic, octants, sectors, mirrored pairs, quarter sectors
-            both(R, OPT_SECTORS=mode)
+    for R in (4.0, 5.5):
+        ref = both(R)
+        assert int((ref != 0).sum()) > 80 * 200
+        for mode in (1, 2, 3):                                  # octants, sectors, mirrored pairs
+            np.testing.assert_allclose(both(R, OPT_SECTORS=mode), ref, rtol=1e-13, atol=0)
         both(R, OPT_HEATING=1)
         both(R, OPT_GREY_NOTABLES=1)
-        both(R, OPT_Z_TRANSPOSED=0)
-    # many sources, both forms against the oracle
-    pos, flux = cases.sources(N, 9, 12, flux=2.0)
-    p0, f0 = cases.flat_sources(pos, flux)
-    lib.source_data_to_device(p0, f0, 9)
+        np.testing.assert_allclose(both(R, OPT_Z_TRANSPOSED=0), ref, rtol=1e-13, atol=0)
+    # overlapping spheres, both forms against the oracle
     ref = O.asora_do_all_sources(9.0, cases.SIG, dr, nd, xh, p0, f0, thin, thick, cases.MINLOGTAU, dlog,
                                  NumTau=thin.shape[0], flags=O.ASORA_MODE)["phi_ion"]
     for glob in (0, 1):
         lib.set_option(capi.OPT_GLOBAL_ATOMICS, glob)
         try:
-            phi = trace(9.0, 9)
+            phi = trace(9.0, 80)
         finally:
             lib.set_option(capi.OPT_GLOBAL_ATOMICS, 0)
         assert np.array_equal(phi == 0, ref == 0)
