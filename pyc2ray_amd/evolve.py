@@ -17,6 +17,7 @@ from . import _capi
 from .asora_core import cuda_is_init
 from .load_extensions import load_asora, load_c2ray
 from .utils import printlog
+from .utils.logutils import printlog_lines
 from .utils.sourceutils import format_sources
 
 __all__ = ['evolve3D', 'evolve3D_MPI', 'evolve3D_resident']
@@ -154,15 +155,16 @@ def _device_loop(libasora, chem, R_max_LLS, sig, dr, minlogtau, dlogtau, NumTau,
         libasora.evolve_enqueue(batch)
         _, converged, rows = libasora.evolve_poll(batch)
         per_iteration = (time.time() - t0) / max(len(rows), 1)
+        lines = []
         for conv_flag, sum_xh1, _s0, rel_change_xh1, _rel0 in rows:
             niter += 1
             conv_flag = int(conv_flag)
-            printlog("Doing Raytracing...", logfile, quiet, ' ')
-            printlog(f"took {per_iteration : .1f} s.", logfile, quiet)
-            printlog("Doing Chemistry...", logfile, quiet, ' ')
-            printlog("took  0.0 s. (fused with the raytrace on the device: the time above is for both)", logfile, quiet)
-            printlog(f"Number of non-converged points: {conv_flag} of {NumCells} ({conv_flag / NumCells * 100 : .3f} % ), "
-                     f"Relative change in ionfrac: {rel_change_xh1 : .2e}", logfile, quiet)
+            lines += [("Doing Raytracing...", ' '), (f"took {per_iteration : .1f} s.", '\n'),
+                      ("Doing Chemistry...", ' '),
+                      ("took  0.0 s. (fused with the raytrace on the device: the time above is for both)", '\n'),
+                      (f"Number of non-converged points: {conv_flag} of {NumCells} ({conv_flag / NumCells * 100 : .3f} % ), "
+                       f"Relative change in ionfrac: {rel_change_xh1 : .2e}", '\n')]
+        printlog_lines(lines, logfile, quiet)
     return niter, float(sum_xh1)
 
 
