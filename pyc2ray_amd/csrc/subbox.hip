@@ -149,12 +149,16 @@ __global__ void __launch_bounds__(SB_THREADS) subbox_sweep_kernel(const SubboxPa
     for (int s = p.s_begin + 1; s <= p.s_end; ++s) {
         const double sd = (double)s;
         const double alam = (sd - 0.5) / sd;                 // f90:612 in source-relative form
-        const int Az = min(s, Ea), Bz = min(s, Eb);
-        const int Ay = min(s, Ea), Cy = min(s - 1, Ec);
-        const int Bx = min(s - 1, Eb), Cx = min(s - 1, Ec);
-        const int nz = s <= Ec ? (Az + 1) * (Bz + 1) : 0;
-        const int ny = s <= Eb ? (Ay + 1) * (Cy + 1) : 0;
-        const int nx = s <= Ea ? (Bx + 1) * (Cx + 1) : 0;
+        // transverse offsets beyond sqrt(R^2 - s^2) lie beyond the radius (see `beyond` below): unless this source's column
+        // densities go back to the caller, the faces are only walked up to there (+1: the exact test is `beyond`'s)
+        const double q2 = R2 * (1.0 + 1e-9) + 1e-9 - sd * sd;
+        const int qlim = dump ? N : (q2 < 0.0 ? -1 : (int)sqrt(q2) + 1);
+        const int Az = min(min(s, Ea), qlim), Bz = min(min(s, Eb), qlim);
+        const int Ay = min(min(s, Ea), qlim), Cy = min(min(s - 1, Ec), qlim);
+        const int Bx = min(min(s - 1, Eb), qlim), Cx = min(min(s - 1, Ec), qlim);
+        const int nz = (s <= Ec && qlim >= 0) ? (Az + 1) * (Bz + 1) : 0;
+        const int ny = (s <= Eb && qlim >= 0) ? (Ay + 1) * (Cy + 1) : 0;
+        const int nx = (s <= Ea && qlim >= 0) ? (Bx + 1) * (Cx + 1) : 0;
         const int ntot = nz + ny + nx;
         const int sm = s - 1;
         // row = t / rowlength without an integer division: (t + 1/2) * (1/rowlength) in single precision is off by
@@ -176,6 +180,15 @@ __global__ void __launch_bounds__(SB_THREADS) subbox_sweep_kernel(const SubboxPa
                 c = r - row * (Cx + 1); b = row; a = s;
                 U = b; V = c; face = 0;
             }
+
+            // A cell beyond R_max_LLS gets no rate (f90:474-478) and adds nothing to the photon loss; its column density
+            // is only ever read by cells further out (every upstream corner has coordinates <= its own, and the rounded
+            // distance is monotone in each of them), i.e. by cells beyond the radius as well.  So unless this source's
+            // column densities are what the caller gets back (the last source of the call), it is not evaluated: for a
+            // box of +-R that is half of the cube.
+            const double dist2 = dist2_reference(a, b, c, dr);
+            const bool beyond = dist2 / (dr * dr) > R2;                                         // f90:474
+            if (beyond && !dump) continue;
 
             // ---- cinterp, f90:576-815, in source-relative octant coordinates -----------------
             const double u = (double)U, v = (double)V;
@@ -224,9 +237,8 @@ __global__ void __launch_bounds__(SB_THREADS) subbox_sweep_kernel(const SubboxPa
             const int i = wrap_once(i0 + sa * a, N), j = wrap_once(j0 + sb * b, N), k = wrap_once(k0 + sc * c, N);
             const unsigned idx_plain = ((unsigned)i * N + j) * N + k;
             const unsigned idx = face == 2 ? ((unsigned)k * N + j) * N + i + p.ncell : idx_plain;
-            const double dist2 = dist2_reference(a, b, c, dr);
             const double vol = dist2 * path * FOURPI;                                          // f90:457
-            const bool stop = dist2 / (dr * dr) > R2 || cd_in > maxcd;                          // f90:474-478
+            const bool stop = beyond || cd_in > maxcd;                                          // f90:474-478
             // a cell on an octant-boundary plane is the business of the octant with the + sign there
             const bool owner = (a > 0 || sa > 0) && (b > 0 || sb > 0) && (c > 0 || sc > 0);
             const bool on_edge = a == fa || b == fb || c == fc;

@@ -55,7 +55,9 @@ for R in a.R:
     m = int(R)
     rr = np.arange(-m, m + 1)
     rated = int(((rr[:, None, None] ** 2 + rr[None, :, None] ** 2 + rr[None, None, :] ** 2) <= R * R).sum()) * ns
-    swept = (2 * sub + 1) ** 3 * (nbox // max(ns, 1)) ** 0 * ns if nbox == ns else None      # one box of +-subboxsize per source
+    # one box of +-subboxsize per source; only the LAST source's column densities go back to the caller, so only its cube is
+    # evaluated beyond the radius (subbox.hip: `beyond`)
+    swept = rated + ((2 * sub + 1) ** 3 - rated // ns) if nbox == ns else None
     algo_bytes = 32 * rated + 8 * ((swept - rated) if swept else 0)                          # 32 B per rated cell, 8 B (nHI) per carried-on cell
     out = {"call": "libc2ray.raytracing.do_all_sources on the GPU (host grids in/out, Fortran order)", "N": N,
            "roofline_sweep_kernel": {"bound": "hbm", "algorithmic_bytes_per_call": algo_bytes, "rated_cells": rated, "swept_cells": swept,
