@@ -283,6 +283,11 @@ __global__ void subbox_decide_kernel(int mode, int count, const double *src_flux
     }
 }
 
+// threads per workgroup of the sweep when there are enough sources to fill the chip (A/B: tools/ab_oneoff.sh)
+#ifndef ASORA_SB_THREADS
+#define ASORA_SB_THREADS 256
+#endif
+
 template <int T>
 static int launch_subbox_variant(State &st, const SubboxParams &p, unsigned grid, bool lds, size_t lds_bytes)
 {
@@ -307,7 +312,9 @@ int launch_subbox_sweep(State &st, const SubboxParams &p)
     const size_t lds_bytes = (size_t)6 * p.W * p.W * sizeof(double);
     const bool lds = lds_bytes <= 56 * 1024 && !st.opt[ASORA_OPT_SUBBOX_GLOBAL_SHELLS];
     if ((long)p.src_count * 8 < (long)st.cu_count) return launch_subbox_variant<1024>(st, p, grid, lds, lds_bytes);
-    return launch_subbox_variant<256>(st, p, grid, lds, lds_bytes);
+    // small boxes: shells of a few hundred cells fill 128 threads better (+-16: 0.65 -> 0.59 ms per 1000 sources; +-32: 256)
+    if (ASORA_SB_THREADS == 256 && p.W <= 20) return launch_subbox_variant<128>(st, p, grid, lds, lds_bytes);
+    return launch_subbox_variant<ASORA_SB_THREADS>(st, p, grid, lds, lds_bytes);
 }
 
 int launch_subbox_decide(State &st, int mode, int count, const double *src_flux, int src_begin, double loss_fraction,
