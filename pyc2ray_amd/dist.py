@@ -56,7 +56,11 @@ def init_process_group_from_env(backend=None):
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # a collective that never completes aborts the job after this long instead of the backend's default of ten minutes
+        # and more (PYC2RAY_AMD_DIST_TIMEOUT_S)
+        import datetime
+        timeout = datetime.timedelta(seconds=float(os.environ.get("PYC2RAY_AMD_DIST_TIMEOUT_S", "300")))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, world, local_rank
 
 
