@@ -141,3 +141,20 @@ def test_blackbody_heating_tables_grey_closed_form():
     i = int(np.searchsorted(tau, 5.0))
     assert h2thick[i] / h2thick[0] > np.exp(-tau[i])
     assert np.all(np.diff(h2thick) <= 1e-9 * h2thick[0])
+
+
+def test_printlog_lines_writes_what_printlog_would(tmp_path, capsys):
+    """The batch form used by the loop of a time step: same file content, same terminal output as one printlog per line."""
+    from pyc2ray_amd.utils.logutils import printlog, printlog_lines
+    lines = [("Doing Raytracing...", ' '), ("took  0.0 s.", '\n'), ("Number of non-converged points: 3", '\n')]
+    a, b = tmp_path / "a.log", tmp_path / "b.log"
+    for text, end in lines:
+        printlog(text, str(a), quiet=False, end=end)
+    one = capsys.readouterr().out
+    printlog_lines(lines, str(b), quiet=False)
+    two = capsys.readouterr().out
+    assert open(a).read() == open(b).read() == "Doing Raytracing... took  0.0 s.\nNumber of non-converged points: 3\n"
+    assert one == two
+    printlog_lines([], str(b), quiet=True)
+    printlog_lines(lines, None, quiet=True)
+    assert capsys.readouterr().out == ""
