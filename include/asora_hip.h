@@ -251,7 +251,8 @@ enum {
     /* Decomposition of a source: 0 (default) = chosen from R; 1 = one workgroup per octant;
      * 2 = one per octant and dominant-axis sector (24 per source, diagonal planes re-derived);
      * 3 = one per pair of mirrored sectors (12 per source; rows are full chords of the sphere);
-     * 4 = one per quarter of a sector plus the cells it reads (96 per source: a handful of sources). */
+     * 4 = one per quarter of a sector plus the cells it reads (96 per source: a handful of sources);
+     * 5 = one per pair of whole octants mirrored in x (4 per source). */
     ASORA_OPT_SECTORS = 5,
     /* 1: the raytrace also accumulates the photo-heating rate into ASORA_GRID_PHI_HEAT
      *    (src/c2ray/photorates.f90:118,124; src/c2ray/raytracing.f90:532,537); needs heat tables. */

@@ -22,6 +22,12 @@ struct OctGeomDev {
 constexpr int MAX_UNITS = 96;   // workgroups per source: 8 octants, 12 mirrored sector pairs, 24 sectors or 96 sector wedges
 
 // Parameters of one raytrace launch (raytrace.hip)
+// The work counters of a trace (rated pairs, evaluated cells): every wave adds its share when it ends.  On TWO addresses those
+// adds serialise in the memory-side atomic unit at ~12 ns each and set a floor of 25 ns per workgroup under the whole
+// launch (0.2 ms for 8000 workgroups, whatever the radius); spread over COUNTER_SLOTS addresses by workgroup index they cost
+// nothing, and asora_last_raytrace_counts sums the slots.
+constexpr int COUNTER_SLOTS = 4096;
+
 struct RtParams {
     int N;
     int S;                 // last Chebyshev shell over all octants
@@ -138,7 +144,7 @@ struct State {
     double *red_host = nullptr;    // pinned [3]
     int red_blocks = 0;
 
-    unsigned long long *counters = nullptr; // [2] device: gamma cells, evaluated cells
+    unsigned long long *counters = nullptr; // [2 * COUNTER_SLOTS] device: gamma cells, evaluated cells, spread over the slots
     long long last_gamma_cells = 0, last_eval_cells = 0;
 
     // fused evolve loop (asora_evolve_*): raytrace accumulators of their own ([i][j][k] then [k][j][i]; the chemistry

@@ -585,8 +585,9 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
         n_eval += __shfl_down(n_eval, o);
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&p.counters[0], (unsigned long long)n_gamma);
-        atomicAdd(&p.counters[1], (unsigned long long)n_eval);
+        unsigned long long *slot = p.counters + 2 * (blockIdx.x & (COUNTER_SLOTS - 1));     // (see COUNTER_SLOTS)
+        atomicAdd(slot, (unsigned long long)n_gamma);
+        atomicAdd(slot + 1, (unsigned long long)n_eval);
     }
 }
 
@@ -908,6 +909,7 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
     // Units of a source:
     //    8: unit = octant                              (bit ax of the octant index = negative side of axis ax)
     //   24: unit = sector*8 + octant                   (sector = face code 0:x 1:y 2:z)
+    //    4: unit = q, two whole octants mirrored in x  (q = sign bits of (y,z))
     //   12: unit = sector*4 + q, two mirrored sectors  (z-sector mirrored in x: q = sign bits of (y,z);
     //                                                   y- and x-sector mirrored in z: q = sign bits of (x,y))
     // Units with the same sector and the same periodic window share one table; when the sphere does not reach
@@ -925,6 +927,10 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
             us.face = (u % 24) >> 3;
             us.merge_axis = -1;
             for (int ax = 0; ax < 3; ++ax) neg[ax] = ((u & 7) >> ax) & 1;
+        } else if (units == 4) {                      // two whole octants mirrored in x: q = sign bits of (y,z)
+            us.face = -1;
+            us.merge_axis = 0;
+            neg[1] = u & 1; neg[2] = (u >> 1) & 1;
         } else if (units == 12) {
             us.face = u >> 2;
             us.merge_axis = us.face == 2 ? 0 : 2;
@@ -1211,16 +1217,21 @@ static const size_t LDS_LIMIT_BYTES = 160 * 1024;
 // octant shell); a large one needs so much LDS per octant that few workgroups fit a CU.  From about R = 20 on,
 // one workgroup per pair of mirrored sectors wins: its rows are full chords of the sphere, which lowers the
 // number of 64-B atomic requests per rated cell (the binding resource) by ~15 %.
-// Thresholds from sweeps on MI355X (1000 sources, 256^3; tools/sweep_threads.sh):
-//   R <= 19: octants x 64 threads | 20..27: sector pairs x 64 | 28..35: pairs x 128 | 36..54: x 256 | >= 55: x 512
+// Thresholds from sweeps on MI355X (1000 sources, 256^3; tools/sweep_threads.sh, re-done once the work counters no longer
+// serialised the launch: profiles/r02_ab_work_counters.txt):
+//   R <= 12: octant pairs x 64 threads | 13..14: octant pairs x 128 | 15..19: octants x 64 | 20..22: sector pairs x 64 |
+//   23..28: octant pairs x 256 | 29..35: sector pairs x 128 | 36..54: x 256 | >= 55: x 512
 static void pick_launch_shape(const State &st, double R, int N, int src_count, bool dump, int &units, int &threads)
 {
     const double r = std::min(R, 0.87 * N);                 // the window cuts the trace at ~sqrt(3)/2 N
     const double est_cells = 1.2 * r * r;                   // largest shell of an octant
-    if (est_cells <= 450.0) { units = 8; threads = 64; }
-    else if (est_cells <= 900.0) { units = 12; threads = 64; }
-    else if (est_cells <= 1500.0) { units = 12; threads = 128; }
-    else if (est_cells <= 3500.0) { units = 12; threads = 256; }
+    if (r <= 12.5) { units = 4; threads = 64; }             // pairs of whole octants mirrored in x
+    else if (r <= 14.5) { units = 4; threads = 128; }
+    else if (est_cells <= 450.0) { units = 8; threads = 64; }        // r <= 19.4
+    else if (r <= 22.5) { units = 12; threads = 64; }
+    else if (r <= 28.5) { units = 4; threads = 256; }
+    else if (est_cells <= 1500.0) { units = 12; threads = 128; }     // r <= 35.3
+    else if (est_cells <= 3500.0) { units = 12; threads = 256; }     // r <= 54
     else { units = 12; threads = 512; }
     // Few sources (fewer workgroups than CUs): the time of the call is the time of ONE workgroup, so cut a source
     // into more (24 sectors) and wider pieces.  One source, 128^3, R = 64: 0.235 -> 0.146 ms (tools/sweep_single_source.sh)
@@ -1245,6 +1256,7 @@ static void pick_launch_shape(const State &st, double R, int N, int src_count, b
     if (want_sectors == 2) units = 24;
     if (want_sectors == 3) units = 12;
     if (want_sectors == 4) units = 96;
+    if (want_sectors == 5) units = 4;
     const int forced = st.opt[ASORA_OPT_BLOCK_THREADS];
     if (forced == 64 || forced == 128 || forced == 256 || forced == 512 || forced == 1024) threads = forced;
     if (dump) threads = 256;                                // the column-density dump variant is built for 256 only

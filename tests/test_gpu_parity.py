@@ -143,7 +143,8 @@ def test_z_transposed_layout_is_only_a_layout(asora):
 @pytest.mark.parametrize("name", ["u16_1src_R8", "l16_7src_R5.5", "l17_3src_Rbox", "l32_5src_R10", "l16_thick"])
 @pytest.mark.parametrize("threads", [64, 128, 256, 512, 1024])
 def test_decomposition_and_workgroup_size_do_not_change_results(asora, name, threads):
-    """One workgroup per octant vs one per (octant, sector), per mirrored sector pair and per quarter sector, at every
+    """One workgroup per octant vs one per (octant, sector), per mirrored sector pair, per quarter sector and per mirrored pair
+    of whole octants, at every
     workgroup size: same Gamma and the same count of rated pairs; the sector forms evaluate more column densities
     (re-derived planes; the quarter sectors re-derive what feeds them)."""
     p, lib, capi = asora
@@ -156,7 +157,7 @@ def test_decomposition_and_workgroup_size_do_not_change_results(asora, name, thr
     out = {}
     try:
         lib.set_option(capi.OPT_BLOCK_THREADS, threads)
-        for mode in (1, 2, 3, 4):
+        for mode in (1, 2, 3, 4, 5):
             lib.set_option(capi.OPT_SECTORS, mode)
             phi = _asora_call(lib, c, N, numtau)
             np.testing.assert_allclose(phi, ref, rtol=GAMMA_RTOL, atol=0)
@@ -167,7 +168,8 @@ def test_decomposition_and_workgroup_size_do_not_change_results(asora, name, thr
     np.testing.assert_allclose(out[1][0], out[2][0], rtol=1e-12, atol=0)
     np.testing.assert_allclose(out[1][0], out[3][0], rtol=1e-12, atol=0)
     np.testing.assert_allclose(out[1][0], out[4][0], rtol=1e-12, atol=0)
-    assert out[1][1][0] == out[2][1][0] == out[3][1][0] == out[4][1][0]    # rated pairs
+    np.testing.assert_allclose(out[1][0], out[5][0], rtol=1e-12, atol=0)
+    assert out[1][1][0] == out[2][1][0] == out[3][1][0] == out[4][1][0] == out[5][1][0]    # rated pairs
     assert out[2][1][1] >= out[1][1][1]               # evaluations (re-derived planes)
     assert out[4][1][1] >= out[2][1][1]               # quarter sectors re-derive the inner part of their sector
 
