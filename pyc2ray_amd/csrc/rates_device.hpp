@@ -81,6 +81,21 @@ __device__ __forceinline__ double add_unfused(double a, double b)
     return a + b;
 }
 
+// x / y for finite y != 0 of ordinary magnitude: hardware reciprocal, two Newton steps, one correction of the quotient --
+// 8 instructions instead of the 12 of the IEEE sequence (v_div_scale x 2, v_div_fmas, v_div_fixup guard against operands
+// near the ends of the exponent range, which column densities, interpolation weights and cell volumes are not).  The
+// quotient is within half an ulp of the exact one in all but ~1e-4 of the cases and within one ulp otherwise; results
+// are compared with the oracle at 1e-8 (rates) and 1e-12 (column densities).  y = 0 gives NaN: callers that can meet it
+// handle it themselves (see pref in raytrace.hip).
+__device__ __forceinline__ double div_newton(double x, double y)
+{
+    double r = __builtin_amdgcn_rcp(y);
+    r = fma(fma(-y, r, 1.0), r, r);
+    r = fma(fma(-y, r, 1.0), r, r);
+    const double q = x * r;
+    return fma(fma(-y, q, x), r, q);
+}
+
 __device__ __forceinline__ int wrap_once(int x, int N)
 {
     return x < 0 ? x + N : (x >= N ? x - N : x);

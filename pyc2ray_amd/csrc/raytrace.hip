@@ -194,6 +194,17 @@ extern "C" __device__ double asora_buffer_atomic_fadd_f64(double, __amdgpu_buffe
 #define ASORA_STEP_SCHED_BARRIER 1
 #endif
 
+// 1: the two divisions of a cell (interpolation, flux / volume) through div_newton (rates_device.hpp) instead of the IEEE
+// sequence.  Pays since the work counters stopped serialising the launch and the kernel runs at ~80 % of VALU issue.
+#ifndef ASORA_NEWTON_DIVISION
+#define ASORA_NEWTON_DIVISION 1
+#endif
+#if ASORA_NEWTON_DIVISION
+#define ASORA_DIV(x, y) div_newton((x), (y))
+#else
+#define ASORA_DIV(x, y) ((x) / (y))
+#endif
+
 // waves per SIMD the register allocation must leave room for (2nd argument of __launch_bounds__)
 #ifndef ASORA_MIN_WAVES
 #define ASORA_MIN_WAVES 1
@@ -409,7 +420,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
 #ifdef ASORA_DIAG_NO_DIVISION        // diagnostic build only (wrong values): what the two divisions of a cell cost
         cd_in = (x1 * q1 + x2 * q2 + x3 * q3 + x4 * q4) * __builtin_amdgcn_rcp(q1 + q2 + q3 + q4);
 #else
-        cd_in = (x1 * q1 + x2 * q2 + x3 * q3 + x4 * q4) / (q1 + q2 + q3 + q4);
+        cd_in = ASORA_DIV(x1 * q1 + x2 * q2 + x3 * q3 + x4 * q4, q1 + q2 + q3 + q4);     // (the weights sum to 1, each max() is >= 0.6)
 #endif
         if (s == 1) {                                    // diagonal neighbours of the source, cu:431-441
             const int nz = (a == 0) + (b == 0) + (c == 0);
@@ -488,7 +499,8 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
 #ifdef ASORA_DIAG_NO_DIVISION
                     pref = flux * __builtin_amdgcn_rcp(vol_nhi);
 #else
-                    pref = flux / vol_nhi;
+                    // (nHI = 0 -- a fully ionised or empty cell: the reference divides by zero; flux / +0 = flux * inf)
+                    pref = vol_nhi == 0.0 ? flux * INFINITY : ASORA_DIV(flux, vol_nhi);
 #endif
                     A2 = lookup_issue<HEAT>(tab, thick ? tau_in : tau_thin, p, logtab);
                     B2 = lookup_issue<HEAT>(tab, thick ? tau_out : tau_thin, p, logtab);
