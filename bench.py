@@ -526,8 +526,8 @@ def main():
             "algorithmic_bytes_per_launch": RT_BYTES_PER_UPDATE * gamma_cells,
             "avg_launch_ms": rt_ms / max(rt_n, 1),
             "launches_timed": rt_n,
-            "binding_resource": ("memory-side atomic request rate: TCC_EA0_ATOMIC %.3g 64-B requests per launch (%s) against "
-                                 "~2.0e10 requests/s chip-wide (MI355X_MICROARCH.md, Global float atomics)"
+            "binding_resource": ("FP64/integer VALU issue (~225 wave-instructions per 64 cells: ~80 %% of the launch), then the memory-side "
+                                 "rate atomics (TCC_EA0_ATOMIC %.3g 64-B requests per launch, %s; ~10 %% of the launch); DESIGN.md 8.1"
                                  % (rt_counters.get("TCC_EA0_ATOMIC_sum", float("nan")), PMC_SUMMARY)) if default_job else None,
         },
         "roofline_kernels": [

@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
     const int blk = blockIdx.x;
     // blocks b and b+8 share an XCD (round-robin dispatch): keep the 8 octants of one source
     // on one XCD so that they share its L2 lines of nHI.  Speed only, never correctness.
-    // p.units workgroups per source (8, 24, 12 or 96: see ensure_geometry).
+    // p.units workgroups per source (8, 24, 12, 96 or 4: see ensure_geometry).
     // p.spread (a handful of sources): consecutive blocks are the units of ONE source, i.e. they go to different XCDs --
     // with the grouping above a single source would keep all its workgroups on one XCD's 32 CUs.
     int src_local, unit;
@@ -332,8 +332,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
     // The tables of a step do not depend on the medium, and the address of a cell's nHI only on
     // its table entry, so both are fetched ahead of the dependent arithmetic: tables two steps
     // ahead, nHI one step ahead.  The rate lookups of a step are issued after its shell barrier, so
-    // their latency never holds the barrier up.  (Consuming them a step later was tried: no gain,
-    // 19 VGPRs -- the kernel is bound by the atomic request rate)
+    // their latency never holds the barrier up, and consumed a step later (ASORA_LATE_LOOKUP).
     // (The tables carry two all-invalid steps of padding at the end: prefetches stay in bounds.)
     auto nhi_address = [&](unsigned abc, unsigned flags, unsigned &idx) -> const double * {
         const bool neg = (flags & CELL_NEG) != 0;
@@ -1228,7 +1227,7 @@ static const size_t LDS_LIMIT_BYTES = 160 * 1024;
 // Decomposition and workgroup size.  Shells of a small trace do not fill 256 lanes (R=16: <= 310 cells per
 // octant shell); a large one needs so much LDS per octant that few workgroups fit a CU.  From about R = 20 on,
 // one workgroup per pair of mirrored sectors wins: its rows are full chords of the sphere, which lowers the
-// number of 64-B atomic requests per rated cell (the binding resource) by ~15 %.
+// number of 64-B atomic requests per rated cell by ~15 %.
 // Thresholds from sweeps on MI355X (1000 sources, 256^3; tools/sweep_threads.sh, re-done once the work counters no longer
 // serialised the launch: profiles/r02_ab_work_counters.txt):
 //   R <= 12: octant pairs x 64 threads | 13..14: octant pairs x 128 | 15..19: octants x 64 | 20..22: sector pairs x 64 |
