@@ -205,13 +205,16 @@ extern "C" __device__ double asora_buffer_atomic_fadd_f64(double, __amdgpu_buffe
 #define ASORA_DIV(x, y) ((x) / (y))
 #endif
 
-// waves per SIMD the register allocation must leave room for (2nd argument of __launch_bounds__)
+// waves per SIMD the register allocation must leave room for (2nd argument of __launch_bounds__; workgroups of up to 512
+// threads).  Left alone the kernel takes 100 VGPRs (4 waves per SIMD); asked for 5 it fits 96 with three dwords spilled
+// outside the loop, and is slower (R = 16 +5 %, R = 32 +2 %: profiles/r02_ab_work_counters.txt).
 #ifndef ASORA_MIN_WAVES
 #define ASORA_MIN_WAVES 1
 #endif
 
 constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_RATE = 1u << 29, CELL_NEG = 1u << 28,
-                   CELL_SLOT_MASK = (1u << 28) - 1;   // NEG: the cell lies on the mirrored side of the unit's merge axis
+                   CELL_ZERO_SHIFT = 25,              // bits 25..27: which of the offsets (a, b, c) are zero
+                   CELL_SLOT_MASK = (1u << 25) - 1;   // NEG: the cell lies on the mirrored side of the unit's merge axis
 
 // GREY (ASORA_OPT_GREY_NOTABLES) is a compile-time variant although its branch is wave-uniform: the compiler counts the
 // vector-memory operations in flight per PATH and, where paths of different counts meet, waits as the shortest one
@@ -223,7 +226,7 @@ constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_RATE = 1u <
 // behind every earlier load, i.e. every wait for a lookup also waited for the atomic issued after it.
 template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP, bool HEAT, int TABCAP, bool SKIP_ZERO = false, bool GREY = false,
           bool BUFATOM = false>
-__global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_kernel(const RtParams p)
+__global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAVES : 1)) raytrace_octant_kernel(const RtParams p)
 {
     extern __shared__ double lds_raw[];
 
@@ -294,7 +297,9 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
     const bool ztr = p.z_transposed != 0;
     constexpr bool grey = GREY;
 
+    // work accounting, per wave (scalar registers: population counts of the lane masks, no per-lane adds)
     unsigned int n_gamma = 0, n_eval = 0;
+    unsigned int src_cell_gamma = 0, src_cell_eval = 0;      // the source cell (thread 0 only)
 
     // rate accumulation: `idx` indexes [phi | phi_t] (and [heat | heat_t])
     __amdgpu_buffer_rsrc_t rs_phi = __builtin_amdgcn_make_buffer_rsrc(p.phi, 0, BUFATOM ? (int)(16u * p.ncell) : 0, 0x00020000);
@@ -317,13 +322,13 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
         const double path = 0.5 * dr;
         const double cd_out = 0.0 + nHI * path;
         prev[0] = cd_out;
-        ++n_eval;
+        src_cell_eval = 1;
         if (uinfo & 32) {                             // the source cell is rated by exactly one unit
             if (DUMP) p.dump[idx] = cd_out;
             const double phi = photo_rate_per_atom(flux, 0.0, cd_out, dr * dr * dr * nHI, p, logtab);
             unsafeAtomicAdd(&p.phi[idx], phi);
             if (HEAT && !p.grey) unsafeAtomicAdd(&p.heat[idx], heat_rate_per_atom(flux, 0.0, cd_out, dr * dr * dr * nHI, p, logtab));
-            ++n_gamma;
+            src_cell_gamma = 1;
         }
     }
     __syncthreads();
@@ -433,9 +438,9 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
         const double nHI = cur_nhi;
         cd_out = fma(nHI, path, cd_in);
         if (valid) cur[cur_A.y & CELL_SLOT_MASK] = cd_out;
-        n_eval += valid ? 1u : 0u;
+        n_eval += (unsigned)__builtin_popcountll(__ballot(valid));
         // a cell on an octant-boundary plane is rated by the octant with the + sign there
-        const unsigned zmask = (a == 0 ? 1u : 0u) | (b == 0 ? 2u : 0u) | (c == 0 ? 4u : 0u);
+        const unsigned zmask = (cur_A.y >> CELL_ZERO_SHIFT) & 7u;        // (a == 0) | (b == 0) << 1 | (c == 0) << 2, tabulated
         const double maxcd = p.fortran_consts ? (double)2e30f : 2e30;                    // raytracing.cu:15
         const bool owner = valid && (cur_A.y & CELL_RATE) && (zmask & negmask) == 0;
         if (DUMP) {
@@ -446,7 +451,7 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
             }
         }
         rated = owner && cd_in <= maxcd && !ASORA_ABLATED(2);
-        n_gamma += (owner && cd_in <= maxcd) ? 1u : 0u;
+        n_gamma += (unsigned)__builtin_popcountll(__ballot(owner && cd_in <= maxcd));
         const double n2 = (double)(a * a + b * b + c * c);
         vol_nhi = n2 * (dr * dr * FOURPI) * path * nHI;                     // raytracing.cu:302-307
         dst_idx = cur_idx;
@@ -590,15 +595,11 @@ __global__ void __launch_bounds__(RT_THREADS, ASORA_MIN_WAVES) raytrace_octant_k
     if (HEAT) add_heat(late_ok, late_idx, late_h);
 #endif
 
-    // work accounting: one atomic per wave
-    for (int o = 32; o > 0; o >>= 1) {
-        n_gamma += __shfl_down(n_gamma, o);
-        n_eval += __shfl_down(n_eval, o);
-    }
+    // work accounting: one atomic per wave and counter
     if ((threadIdx.x & 63) == 0) {
         unsigned long long *slot = p.counters + 2 * (blockIdx.x & (COUNTER_SLOTS - 1));     // (see COUNTER_SLOTS)
-        atomicAdd(slot, (unsigned long long)n_gamma);
-        atomicAdd(slot + 1, (unsigned long long)n_eval);
+        atomicAdd(slot, (unsigned long long)(n_gamma + src_cell_gamma));
+        atomicAdd(slot + 1, (unsigned long long)(n_eval + src_cell_eval));
     }
 }
 
@@ -740,7 +741,8 @@ void build_unit_geometry(HostGeom &h, const UnitSpec &us, double R, double dr, i
             const bool neg = us.merge_axis >= 0 && x[us.merge_axis] < 0;
             uint4 ca;
             ca.x = (uint32_t)a | ((uint32_t)b << 10) | ((uint32_t)c << 20) | ((uint32_t)face << 30);
-            ca.y = count | CELL_VALID | (rate ? CELL_RATE : 0u) | (neg ? CELL_NEG : 0u);
+            ca.y = count | CELL_VALID | (rate ? CELL_RATE : 0u) | (neg ? CELL_NEG : 0u) |
+                   (((a == 0 ? 1u : 0u) | (b == 0 ? 2u : 0u) | (c == 0 ? 4u : 0u)) << CELL_ZERO_SHIFT);
             ca.z = (uint32_t)(pbits & 0xffffffffu);
             ca.w = (uint32_t)(pbits >> 32);
             h.cellA.push_back(ca);
@@ -836,7 +838,7 @@ HostGeom restrict_to_wedge(const HostGeom &full, int wedge, int RT_THREADS, uint
         for (size_t q = 0; q < shells[si].size(); ++q) {
             if (!keep[si][q]) continue;
             Entry e = shells[si][q];
-            const uint32_t flags = e.a.y & (CELL_NEG);
+            const uint32_t flags = e.a.y & (CELL_NEG | (7u << CELL_ZERO_SHIFT));
             e.a.y = count | CELL_VALID | flags | (in_wedge(e.a) ? CELL_RATE : 0u);
             if (si > 0) {       // corners of shell 1 point into shell 0 (the source cell, slot 0): unchanged
                 auto remap = [&](uint32_t slot) -> uint32_t {
