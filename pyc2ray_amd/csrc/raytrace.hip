@@ -346,7 +346,9 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
         const unsigned k = (neg && merge_axis == 2) ? wm[(abc >> 20) & 1023] : wk[(abc >> 20) & 1023];
         const bool zt = ztr && (abc >> 30) == 2;
         // the [k][j][i] copies follow the [i][j][k] grids in memory: one 32-bit index covers both
-        idx = zt ? (k * N + j) * N + i + p.ncell : (i * N + j) * N + k;
+        // (one formula with the outer and inner coordinate swapped, rather than two under a branch)
+        const unsigned outer = zt ? k : i, inner = zt ? i : k;
+        idx = (outer * N + j) * N + inner + (zt ? p.ncell : 0u);
         if (ASORA_ABLATED(128)) return p.nhi + (idx & 0xFFFFu);   // diagnostic: nHI from a 512 KiB window (wrong results)
         return p.nhi + idx;
     };
@@ -388,7 +390,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
         const bool valid = (cur_A.y & CELL_VALID) != 0;
         // waves whose 64 entries are all padding skip the arithmetic (wave-uniform branch)
 #if ASORA_SKIP_EMPTY_WAVES
-        const bool wave_has_work = __builtin_amdgcn_readfirstlane((int)__any(valid)) != 0;
+        const bool wave_has_work = __builtin_amdgcn_ballot_w64(valid) != 0ull;
 #else
         const bool wave_has_work = true;
 #endif
@@ -438,7 +440,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
         const double nHI = cur_nhi;
         cd_out = fma(nHI, path, cd_in);
         if (valid) cur[cur_A.y & CELL_SLOT_MASK] = cd_out;
-        n_eval += (unsigned)__builtin_popcountll(__ballot(valid));
+        n_eval += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid));
         // a cell on an octant-boundary plane is rated by the octant with the + sign there
         const unsigned zmask = (cur_A.y >> CELL_ZERO_SHIFT) & 7u;        // (a == 0) | (b == 0) << 1 | (c == 0) << 2, tabulated
         const double maxcd = p.fortran_consts ? (double)2e30f : 2e30;                    // raytracing.cu:15
@@ -451,7 +453,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
             }
         }
         rated = owner && cd_in <= maxcd && !ASORA_ABLATED(2);
-        n_gamma += (unsigned)__builtin_popcountll(__ballot(owner && cd_in <= maxcd));
+        n_gamma += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(owner && cd_in <= maxcd));
         const double n2 = (double)(a * a + b * b + c * c);
         vol_nhi = n2 * (dr * dr * FOURPI) * path * nHI;                     // raytracing.cu:302-307
         dst_idx = cur_idx;
