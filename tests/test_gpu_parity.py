@@ -207,7 +207,7 @@ def test_large_radius_and_window_clipping(asora, N, R):
     np.testing.assert_allclose(phi, ref, rtol=GAMMA_RTOL, atol=0)
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 4, 0])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 0])
 def test_large_shells_global_scratch_and_large_lds(asora, mode):
     """N=168 full box.  One workgroup per octant (mode 1): shell buffers 2*21.8k*8 B = 349 KB > 160 KB of LDS
     -> the global-scratch variant.  One per (octant, sector) (mode 2, what the library picks at this size):
