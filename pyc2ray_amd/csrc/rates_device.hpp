@@ -44,8 +44,8 @@ __device__ __forceinline__ double log2_pos(double x, const double2 *__restrict__
 struct Lookup { double2 t; double2 h; double residual; };   // h: the heating-table pair at the same index
 template <bool HEAT = false, typename Params = RtParams>
 __device__ __forceinline__ Lookup lookup_issue(const double2 *__restrict__ table, double tau, const Params &p,
-                                               const double2 *__restrict__ logtab)
-{
+                                               const double2 *__restrict__ logtab, int offset = 0)
+{   // offset: entries to skip in front (the thin table follows the thick one: a per-lane offset instead of a per-lane pointer)
 #ifdef ASORA_ENABLE_ABLATION
     const double l2 = log2_pos(fmax(1.0e-20, tau), logtab, p.ablate & 16);
 #else
@@ -54,8 +54,8 @@ __device__ __forceinline__ Lookup lookup_issue(const double2 *__restrict__ table
     const double real_i = fmin(p.numtau_f, fmax(0.0, fma(l2, p.lut_k1, p.lut_k0)));
     const int i0 = (int)real_i;
     Lookup L;
-    L.residual = real_i - (double)i0;
-    int i = min(i0, p.table_len - 1);
+    L.residual = __builtin_amdgcn_fract(real_i);          // real_i - (double)i0 for real_i >= 0, one instruction
+    int i = min(i0, p.table_len - 1) + offset;
 #ifdef ASORA_ENABLE_ABLATION
     if (p.ablate & 8) i = 15000 + (threadIdx.x & 3);   // diagnostic: perfectly coalesced lookups
 #endif

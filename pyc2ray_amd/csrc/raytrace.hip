@@ -474,9 +474,12 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
             const double limit = p.fortran_consts ? (double)1.0e-7f : 1.0e-7;
             const double dtau = tau_out - tau_in;
             const bool thick = fabs(dtau) > limit;
-            const double tau_thin = p.fortran_consts ? tau_in : tau_out;                 // photorates.f90:121 / rates.cu:37
-            // one code path for both kinds of cell: per-lane table offset and arguments
-            const double2 *tab = p.tables + (thick ? 0 : p.table_len);
+            // one code path for both kinds of cell: per-lane table offset and arguments.  A thin cell looks its tau_thin up
+            // twice: tau_in with the Fortran's constants (photorates.f90:121), tau_out with the CUDA library's (rates.cu:37)
+            const double2 *tab = p.tables;
+            const int toff = thick ? 0 : p.table_len;
+            const double arg_A = (thick || p.fortran_consts) ? tau_in : tau_out;
+            const double arg_B = (thick || !p.fortran_consts) ? tau_out : tau_in;
 #if ASORA_LATE_LOOKUP
             // SKIP_ZERO (ASORA_OPT_SKIP_ZERO_RATES): a thick cell whose tau_in lies beyond the last table entry gets
             // pref * (T_last - T_last) = exactly +0; adding it changes nothing, so the atomic is not issued -- and when no
@@ -508,8 +511,8 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
                     // (nHI = 0 -- a fully ionised or empty cell: the reference divides by zero; flux / +0 = flux * inf)
                     pref = vol_nhi == 0.0 ? flux * INFINITY : ASORA_DIV(flux, vol_nhi);
 #endif
-                    A2 = lookup_issue<HEAT>(tab, thick ? tau_in : tau_thin, p, logtab);
-                    B2 = lookup_issue<HEAT>(tab, thick ? tau_out : tau_thin, p, logtab);
+                    A2 = lookup_issue<HEAT>(tab, arg_A, p, logtab, toff);
+                    B2 = lookup_issue<HEAT>(tab, arg_B, p, logtab, toff);
                 }
                 add_phi(late_ok, late_idx, v_prev);
                 if (HEAT) add_heat(late_ok, late_idx, h_prev);
@@ -519,8 +522,8 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
             }
 #elif ASORA_LATE_ATOMIC
             const double pref = flux / vol_nhi;
-            const Lookup A = lookup_issue<HEAT>(tab, thick ? tau_in : tau_thin, p, logtab);
-            const Lookup B = lookup_issue<HEAT>(tab, thick ? tau_out : tau_thin, p, logtab);
+            const Lookup A = lookup_issue<HEAT>(tab, arg_A, p, logtab, toff);
+            const Lookup B = lookup_issue<HEAT>(tab, arg_B, p, logtab, toff);
             // the previous step's rate, behind this step's lookups in the memory pipeline
             add_phi(late_ok, late_idx, late_v);
             if (HEAT) add_heat(late_ok, late_idx, late_h);
@@ -536,8 +539,8 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
             }
 #else
             const double pref = flux / vol_nhi;
-            const Lookup A = lookup_issue<HEAT>(tab, thick ? tau_in : tau_thin, p, logtab);
-            const Lookup B = lookup_issue<HEAT>(tab, thick ? tau_out : tau_thin, p, logtab);
+            const Lookup A = lookup_issue<HEAT>(tab, arg_A, p, logtab, toff);
+            const Lookup B = lookup_issue<HEAT>(tab, arg_B, p, logtab, toff);
             {
                 const double ta = lookup_value(A), tb = lookup_value(B);
                 add_phi(rated, dst_idx, thick ? pref * (ta - tb) : pref * dtau * ta);
