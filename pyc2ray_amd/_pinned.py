@@ -21,7 +21,8 @@ import numpy as np
 MAX_FREE_PER_SIZE = 4
 MAX_PINNED_BYTES = int(float(os.environ.get("PYC2RAY_AMD_PINNED_GIB", "8")) * 2 ** 30)
 
-_lock = threading.Lock()
+# re-entrant: _Owner.__del__ may run (cyclic GC) while this thread is inside _take / _give_back and holds the lock
+_lock = threading.RLock()
 _free = {}              # nbytes -> [address, ...]
 _pinned_bytes = 0
 _enabled = os.environ.get("PYC2RAY_AMD_PINNED_RESULTS", "1") != "0"

@@ -120,7 +120,12 @@ class _DeviceGrid:
         except KeyError:
             raise AttributeError(self.name) from None
         if self.name in obj._device_newer:                   # results of the last step(s) still only on the device
-            load_asora().grid_to_host(self.which, arr)
+            # into a FRESH array, as the reference binds a fresh array per step (c2ray_base.py:205-226): a caller that keeps
+            # `prev = sim.xh` or appends sim.xh to a history must not see it change under its feet
+            lib = load_asora()
+            order = 'F' if (arr.flags.f_contiguous and not arr.flags.c_contiguous) else 'C'
+            arr = lib.grid_to_host(self.which, lib.host_empty(arr.shape, order=order))
+            obj.__dict__[self.attr] = arr
             obj._device_newer.discard(self.name)
         obj._host_newer.add(self.name)                       # the caller may modify what it gets
         return arr
@@ -228,7 +233,8 @@ class C2Ray:
         for name, which in (("ndens", _capi.GRID_NDENS), ("temp", _capi.GRID_TEMP), ("xh", _capi.GRID_XH)):
             if name in self._host_newer:
                 uploads[which] = d["_grid_" + name]
-        if d["_grid_phi_ion"].flags.f_contiguous and not d["_grid_phi_ion"].flags.c_contiguous:
+        phi_host = d.get("_grid_phi_ion")                       # (a subclass may never have assigned phi_ion)
+        if phi_host is None or (phi_host.flags.f_contiguous and not phi_host.flags.c_contiguous):
             d["_grid_phi_ion"] = np.zeros(self.shape)           # the GPU path returns C-ordered rates (evolve.py:200)
         evolve3D_resident(dt, self.dr, src_flux, src_pos, uploads, self.N, self.photo_thin_table, self.minlogtau, self.dlogtau,
                           self.R_max_LLS, self.convergence_fraction, self.sig, self.bh00, self.albpow, self.colh0, self.temph0,

@@ -125,6 +125,18 @@ static int ensure_red_capacity(size_t entries)
     return 0;
 }
 
+// The heating-rate grid and its [k][j][i] twin (2 N^3 doubles: 2 GiB at 512^3) exist only once something heats: the heating
+// tables are uploaded, or a caller hands the grid over (evolve3D never does)
+static int ensure_heat_grid()
+{
+    State &st = g_state;
+    if (st.grid[ASORA_GRID_PHI_HEAT]) return 0;
+    ASORA_HIP_TRY(hipMalloc(&st.grid[ASORA_GRID_PHI_HEAT], 2 * st.ncell * sizeof(double)));
+    st.heat_t = st.grid[ASORA_GRID_PHI_HEAT] + st.ncell;
+    st.grid_valid[ASORA_GRID_PHI_HEAT] = false;
+    return 0;
+}
+
 static int release_all()
 {
     State &st = g_state;
@@ -457,7 +469,17 @@ static int do_all_sources_pipelined(double R, double sig, double dr, const doubl
     if (hipHostRegister((void *)phi_ion, bytes, hipHostRegisterDefault) != hipSuccess) {
         (void)hipGetLastError(); (void)hipHostUnregister((void *)xh_av); return 0;
     }
-    struct Unpin { const void *a, *b; ~Unpin() { (void)hipHostUnregister((void *)a); (void)hipHostUnregister((void *)b); } } unpin{xh_av, phi_ion};
+    // on EVERY exit path -- also the error returns below, with copies into and out of the caller's buffers possibly still in
+    // flight -- the three streams are drained before the buffers are unregistered and handed back
+    struct Unpin {
+        const void *a, *b;
+        ~Unpin()
+        {
+            State &s = g_state;
+            for (hipStream_t q : {s.side[0], s.side[1], s.stream}) if (q) (void)hipStreamSynchronize(q);
+            (void)hipHostUnregister((void *)a); (void)hipHostUnregister((void *)b);
+        }
+    } unpin{xh_av, phi_ion};
 
     while ((int)st.pipe_events.size() < 2 * K) {
         hipEvent_t e = nullptr;
@@ -618,15 +640,20 @@ int asora_device_init_ex(int N, int num_src_par, int device_id)
     const size_t bytes = st.ncell * sizeof(double);
     // the rate grids and nHI carry their [k][j][i] twin directly behind them (one 32-bit index reaches both)
     for (int g = 0; g < ASORA_GRID_COUNT; ++g) {
-        const bool twin = (g == ASORA_GRID_PHI_ION || g == ASORA_GRID_PHI_HEAT);
-        ASORA_HIP_TRY(hipMalloc(&st.grid[g], twin ? 2 * bytes : bytes));
+        if (g == ASORA_GRID_PHI_HEAT) continue;                     // on first use: ensure_heat_grid
+        ASORA_HIP_TRY(hipMalloc(&st.grid[g], g == ASORA_GRID_PHI_ION ? 2 * bytes : bytes));
     }
     ASORA_HIP_TRY(hipMalloc(&st.nhi, 2 * bytes));
     st.nhi_t = st.nhi + st.ncell;
     st.phi_t = st.grid[ASORA_GRID_PHI_ION] + st.ncell;
-    st.heat_t = st.grid[ASORA_GRID_PHI_HEAT] + st.ncell;
+    st.heat_t = nullptr;
     ASORA_HIP_TRY(hipMalloc(&st.staging, bytes));
-    if (int rc = ensure_red_capacity(3 * chemistry_tile_blocks(st, N, N))) return rc;
+    {   // per-workgroup partials of the tiled chemistry pass: the j-chunk count is rounded up per (k tile x i tile), so a
+        // RANGE of planes (asora_chemistry_range: a multi-GPU rank's slab) can need more workgroups than the whole grid
+        size_t worst = 0;
+        for (int planes = 1; planes <= N; ++planes) worst = std::max(worst, chemistry_tile_blocks(st, N, planes));
+        if (int rc = ensure_red_capacity(3 * worst)) return rc;
+    }
     st.init = true;
     return 0;
 }
@@ -657,6 +684,7 @@ int asora_grid_to_device(int which, const double *host, int N, char order)
     if (which < 0 || which >= ASORA_GRID_COUNT) return fail(3, "grid_to_device: bad grid selector");
     if (!host) return fail(3, "grid_to_device: null host pointer");
     State &st = g_state;
+    if (which == ASORA_GRID_PHI_HEAT) { if (int rc = ensure_heat_grid()) return rc; }
     const size_t bytes = st.ncell * sizeof(double);
     if (order == 'C' || order == 'c') {
         ASORA_HIP_TRY(hipMemcpyAsync(st.grid[which], host, bytes, hipMemcpyHostToDevice, st.stream));
@@ -679,7 +707,7 @@ int asora_grid_to_host(int which, double *host, int N, char order)
     if (which < 0 || which >= ASORA_GRID_COUNT) return fail(3, "grid_to_host: bad grid selector");
     if (!host) return fail(3, "grid_to_host: null host pointer");
     State &st = g_state;
-    if (!st.grid_valid[which]) return fail(3, "grid_to_host: grid " + std::to_string(which) + " holds no data");
+    if (!st.grid[which] || !st.grid_valid[which]) return fail(3, "grid_to_host: grid " + std::to_string(which) + " holds no data");
     const size_t bytes = st.ncell * sizeof(double);
     if (order == 'C' || order == 'c') {
         ASORA_HIP_TRY(hipMemcpyAsync(host, st.grid[which], bytes, hipMemcpyDeviceToHost, st.stream));
@@ -700,6 +728,7 @@ int asora_grid_copy(int dst, int src)
         return fail(3, "grid_copy: bad grid selectors");
     State &st = g_state;
     if (!st.grid_valid[src]) return fail(3, "grid_copy: source grid holds no data");
+    if (dst == ASORA_GRID_PHI_HEAT) { if (int rc = ensure_heat_grid()) return rc; }
     ASORA_HIP_TRY(hipMemcpyAsync(st.grid[dst], st.grid[src], st.ncell * sizeof(double), hipMemcpyDeviceToDevice,
                                  st.stream));
     st.grid_valid[dst] = true;
@@ -783,6 +812,7 @@ int asora_heat_table_to_device(const double *heat_thin_table, const double *heat
     if (NumTau != st.table_len || !heat_thin_table || !heat_thick_table)
         return fail(3, "heat_table_to_device: the heating tables must have the length of the photo tables (" +
                            std::to_string(st.table_len) + ")");
+    if (int rc = ensure_heat_grid()) return rc;
     std::vector<double2> pairs(2 * (size_t)NumTau);
     for (int t = 0; t < 2; ++t) {
         const double *src = t == 0 ? heat_thick_table : heat_thin_table;
@@ -985,6 +1015,7 @@ int asora_chemistry_range(double dt, double bh00, double albpow, double colh0, d
     p.xh_av_in = st.grid[ASORA_GRID_XH_AV];
     p.gamma = st.grid[ASORA_GRID_PHI_ION];
     p.xh_av = st.grid[ASORA_GRID_XH_AV]; p.xh_intermed = st.grid[ASORA_GRID_XH_INTERMED];
+    if (int rc = ensure_red_capacity(3 * chemistry_tile_blocks(st, st.N, i_count))) return rc;    // (sized for every range at init)
     p.red_partial = st.red_partial; p.red_final = st.red_final;
     p.accumulate = first ? 0 : 1;
     if (int rc = ensure_temp_probe(bh00, albpow, colh0, temph0)) return rc;
@@ -1239,6 +1270,7 @@ int asora_evolve_begin(double dt, double bh00, double albpow, double colh0, doub
     st.ev_chem[5] = abu_c;
     st.ev_first = true;
     st.ev_reported = 0;
+    st.ev_enqueued = 0;
     st.ev_open = true;
     return 0;
 }
@@ -1250,6 +1282,11 @@ int asora_evolve_enqueue(int iterations)
     State &st = g_state;
     if (!st.ev_open) return fail(4, "evolve_enqueue: no evolve step in progress (call asora_evolve_begin)");
     if (iterations < 1 || iterations > EVOLVE_HIST / 2) return fail(3, "evolve_enqueue: between 1 and 32 iterations per call");
+    // the per-iteration history is a ring of EVOLVE_HIST rows on the device: rows not yet handed out by asora_evolve_poll
+    // must not be overwritten
+    if (st.ev_enqueued - st.ev_reported + iterations > EVOLVE_HIST)
+        return fail(4, "evolve_enqueue: " + std::to_string(st.ev_enqueued - st.ev_reported) + " iterations enqueued since the last "
+                           "asora_evolve_poll; the history ring holds " + std::to_string(EVOLVE_HIST) + " (poll first)");
     for (int it = 0; it < iterations; ++it) {
         if (st.ev_src_count > 0) {
             RtParams p = st.ev_rt;
@@ -1273,6 +1310,7 @@ int asora_evolve_enqueue(int iterations)
         st.ev_acc_clean = true;
         st.ev_first = false;
     }
+    st.ev_enqueued += iterations;
     st.grid_valid[ASORA_GRID_XH_AV] = st.grid_valid[ASORA_GRID_XH_INTERMED] = st.grid_valid[ASORA_GRID_PHI_ION] = true;
     return 0;
 }
@@ -1289,7 +1327,10 @@ int asora_evolve_poll(int *niter, int *converged, double *history, int history_r
     int rows = 0;
     for (int it = st.ev_reported; it < h.niter && history && rows < history_rows; ++it, ++rows)
         for (int q = 0; q < 5; ++q) history[5 * rows + q] = h.hist[it % EVOLVE_HIST][q];
+    // everything enqueued has run by now (iterations enqueued beyond convergence did nothing and never will)
+    st.ev_enqueued = h.niter;
     if (history) st.ev_reported += rows;
+    else st.ev_reported = h.niter;           // a caller that does not ask for the rows gives them up
     if (rows_written) *rows_written = rows;
     if (niter) *niter = h.niter;
     if (converged) *converged = h.done;
@@ -1307,6 +1348,7 @@ int asora_planes_to_host(int which, int i_begin, int i_count, double *host)
     if (i_begin < 0 || i_count < 0 || i_begin + i_count > st.N) return fail(3, "planes_to_host: bad plane range");
     if (i_count == 0) return 0;
     if (!host) return fail(3, "planes_to_host: null host pointer");
+    if (!st.grid_valid[which]) return fail(3, "planes_to_host: grid " + std::to_string(which) + " holds no data");
     const size_t plane = (size_t)st.N * st.N;
     ASORA_HIP_TRY(hipMemcpyAsync(host, st.grid[which] + (size_t)i_begin * plane, (size_t)i_count * plane * sizeof(double),
                                  hipMemcpyDeviceToHost, st.stream));
@@ -1323,10 +1365,13 @@ int asora_planes_to_device(int which, int i_begin, int i_count, const double *ho
     if (i_begin < 0 || i_count < 0 || i_begin + i_count > st.N) return fail(3, "planes_to_device: bad plane range");
     if (i_count == 0) return 0;
     if (!host) return fail(3, "planes_to_device: null host pointer");
+    if (which == ASORA_GRID_PHI_HEAT) { if (int rc = ensure_heat_grid()) return rc; }
     const size_t plane = (size_t)st.N * st.N;
     ASORA_HIP_TRY(hipMemcpyAsync(st.grid[which] + (size_t)i_begin * plane, host, (size_t)i_count * plane * sizeof(double),
                                  hipMemcpyHostToDevice, st.stream));
     ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    st.grid_valid[which] = true;             // (the caller vouches for the planes it did not write)
+    if (which == ASORA_GRID_TEMP) st.temp_probe_valid = false;
     return 0;
 }
 

@@ -160,6 +160,7 @@ struct State {
     bool temp_probe_valid = false;
     double temp_consts[4] = {0, 0, 0, 0};
     int ev_reported = 0;                    // iterations already handed to the caller by asora_evolve_poll
+    int ev_enqueued = 0;                    // upper bound of the iterations carried out (enqueued) in this step
     double ev_chem[6] = {0, 0, 0, 0, 0, 0}; // dt, bh00, albpow, colh0, temph0, abu_c
     int ev_src_begin = 0, ev_src_count = 0;
     RtParams ev_rt;

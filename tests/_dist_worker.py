@@ -9,6 +9,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def _shutdown():
+    """Take the process group down in an orderly way (gloo's threads otherwise race the interpreter's exit)."""
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     overlap = len(sys.argv) > 5 and sys.argv[5] == "overlap"
@@ -68,6 +75,15 @@ def main():
             def Bcast(self, buf, root=0):
                 return comm.Bcast(buf, root=root)
         the_comm = _MPIOnly()
+    golden_case = None
+    if spec[0] == "mpigolden":
+        # a use_gpu=True case of tests/cases.py, every time step of it: compared with the REFERENCE'S evolve3D_MPI
+        # (tests/golden/evolve_mpi.npz) by the caller
+        golden_case = cases.evolve_case(spec[1])
+        c = golden_case
+        N, R, dt, nd, xh, temp, pos, flux, dr = c["N"], c["R"], c["dt"], c["ndens"], c["xh"], c["temp"], c["pos"], c["flux"], c["dr"]
+        thin, thick, dlog = c["thin"], c["thick"], c["dlogtau"]
+        comm.exchange = "allreduce" if "allreduce" in spec[2:] else "slab"
     fake = OracleAsora(thin, thick)
     if real:
         import pyc2ray_amd as p
@@ -77,12 +93,24 @@ def main():
         ev.load_asora = lambda: fake
         ev.cuda_is_init = lambda: True
         ev.load_c2ray = lambda: OracleC2Ray()
+    if golden_case is not None:
+        res = {}
+        for step in range(golden_case["steps"]):
+            xh, phi = ev.evolve3D_MPI(dt, dr, flux, pos, True, 1000, N, 1e-2, use_mpi, the_comm, rank, world, temp, nd, xh,
+                                      thin, thick, cases.MINLOGTAU, dlog, R, golden_case["convergence_fraction"], cases.SIG,
+                                      cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C, logfile=None, quiet=True)
+            res[f"xh{step}"], res[f"phi{step}"], res[f"niter{step}"] = np.array(xh), np.array(phi), ev._evolve.last_niter
+        np.savez(out, **res)
+        comm.Barrier()
+        _shutdown()
+        return
     xh_new, phi = ev.evolve3D_MPI(dt, dr, flux, pos, not cpu_semantics, 1000, 3, 1e-2, use_mpi, the_comm, rank, world,
                                   temp, nd, xh, thin, thick, cases.MINLOGTAU, dlog, R, 1e-4, cases.SIG,
                                   cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C,
                                   logfile=None, quiet=True)
     np.savez(out, xh=xh_new, phi=phi, niter=ev._evolve.last_niter, nsrc=(fake.flux.shape[0] if fake.flux is not None else -1))
     comm.Barrier()
+    _shutdown()
 
 
 if __name__ == "__main__":

@@ -308,12 +308,16 @@ def test_device_resident_grids_give_the_same_run_with_fewer_transfers(tmp_path, 
                     sim.cosmo_evolve(dt)
                     sim.evolve3D(dt, srcflux, srcpos)
                     if step in (1, 3):                      # the fields are looked at after steps 2 and 4 only
-                        snaps.append((np.array(sim.xh, copy=True), np.array(sim.phi_ion, copy=True), float(sim.ndens.mean())))
+                        kept = sim.xh                        # a reference a script might keep (history.append(sim.xh))
+                        snaps.append((np.array(kept, copy=True), np.array(sim.phi_ion, copy=True), float(sim.ndens.mean()), kept))
             finally:
                 lib.grid_to_device, lib.grid_to_host = up, down
             runs[resident] = (snaps, counts)
             pc2r.device_close()
-        for (x0, p0, n0), (x1, p1, n1) in zip(runs[False][0], runs[True][0]):
+        for snaps, _ in runs.values():                         # every step's result is a fresh array, as in the reference:
+            assert snaps[0][3] is not snaps[1][3]              # what was kept after step 2 is not the array of step 4 ...
+            assert np.array_equal(snaps[0][3], snaps[0][0])    # ... and still holds step 2's values
+        for (x0, p0, n0, _k0), (x1, p1, n1, _k1) in zip(runs[False][0], runs[True][0]):
             np.testing.assert_allclose(x1, x0, rtol=1e-11, atol=0)           # atomic summation order only
             np.testing.assert_allclose(p1, p0, rtol=1e-11, atol=0)
             assert n1 == n0

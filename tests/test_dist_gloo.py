@@ -214,3 +214,40 @@ def test_slab_exchange_with_the_hip_library(tmp_path, world, N, ns, R):
     assert int(res[0]["niter"]) == niter_ref
     np.testing.assert_allclose(res[0]["xh"], x_ref, rtol=1e-7, atol=0)
     np.testing.assert_allclose(res[0]["phi"], phi_ref, rtol=1e-7, atol=0)
+
+
+# ---- evolve3D_MPI against the REFERENCE'S OWN evolve3D_MPI (tests/golden/make_mpi_golden.py) ---------------------------
+def _check_against_reference_mpi(res, name, world, rtol_x, rtol_phi):
+    g = np.load(os.path.join(HERE, "golden", "evolve_mpi.npz"))
+    c = cases.evolve_case(name)
+    assert bool(g[f"{name}__P{world}__ranks_identical"])
+    done = 0
+    for step in range(c["steps"]):
+        for r in res[1:]:
+            assert np.array_equal(r[f"xh{step}"], res[0][f"xh{step}"]) and np.array_equal(r[f"phi{step}"], res[0][f"phi{step}"])
+        niter = int(res[0][f"niter{step}"])
+        done += niter
+        np.testing.assert_allclose(res[0][f"xh{step}"], g[f"{name}__P{world}__xh{step}"], rtol=rtol_x, atol=0)
+        want = g[f"{name}__P{world}__phi{step}"]
+        w = want != 0
+        assert np.array_equal(res[0][f"phi{step}"] != 0, w)
+        np.testing.assert_allclose(res[0][f"phi{step}"][w], want[w], rtol=rtol_phi, atol=0)
+    assert done == len(g[f"{name}__P{world}__rows"])        # outer iterations over all time steps, from the reference's log
+
+
+@pytest.mark.parametrize("world,name,exchange", [(2, "l16_gpu_F", "slab"), (3, "l16_gpu_F", "allreduce"),
+                                                 (2, "l24_gpu_F_37src", "allreduce"), (3, "l24_gpu_F_37src", "slab")])
+def test_evolve3D_MPI_reproduces_the_reference_evolve3D_MPI(tmp_path, world, name, exchange):
+    """The fixture is the reference's own evolve3D_MPI (pyc2ray/evolve.py:249-498) run with 1, 2 and 3 ranks over its
+    Reduce / Bcast calls.  Here: this package's evolve3D_MPI over gloo (oracle-backed compute), slab exchange and full-grid
+    all-reduce: same number of outer iterations in every time step, same fields on every rank."""
+    res = _run_workers(tmp_path, world, f"mpigolden:{name}:{exchange}")
+    _check_against_reference_mpi(res, name, world, 1e-10, 1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,name", [(2, "l24_gpu_F_37src"), (3, "l16_gpu_F")])
+def test_evolve3D_MPI_with_the_hip_library_reproduces_the_reference_evolve3D_MPI(tmp_path, world, name):
+    """The same with the HIP library under every rank (all ranks on GPU 0, exchanges staged through the host by gloo)."""
+    res = _run_workers(tmp_path, world, f"mpigolden:{name}:slab:real")
+    _check_against_reference_mpi(res, name, world, 1e-8, 1e-7)

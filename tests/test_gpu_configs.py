@@ -5,8 +5,12 @@
   configs[2]  256^3 uniform, 1000 RandomState(100) sources, r_RT = 16 / 32 / 64: against sparse fixtures produced
               by the REFERENCE Fortran at this size (tests/golden/make_fullsize_golden.py)
   configs[3]  256^3 log-normal density, sources on the densest cells (adjacent sources, same-address atomics):
-              against the oracle on the host cores of the GPU box
-  configs[4]  512^3 (indices beyond 2^31 bytes): corner sources, exact pair counts, one source against the oracle
+              ALL 1000 sources against a sparse fixture produced by the REFERENCE Fortran (tests/golden/
+              make_bigconfig_golden.py), 96 of them (plus coincident ones) against the oracle on the host cores of the GPU box
+  configs[4]  512^3 (indices beyond 2^31 bytes): ALL 1e5 sources on the densest cells through two iterations of the evolve
+              loop (counts, finiteness, fused loop == separate calls), 256 of them against a sparse fixture produced by the
+              REFERENCE Fortran, superposition; corner sources, exact pair counts, one source against the oracle
+  a-7         libc2ray.raytracing.do_all_sources (sub-box semantics) on configs[2] itself: 256^3, 1000 sources, r_RT = 32
 """
 import os
 import sys
@@ -149,6 +153,50 @@ def test_config3_256_lognormal_clustered_sources_against_oracle(asora, bench_tab
     np.testing.assert_allclose(lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))[w], phi[w], rtol=1e-11)
 
 
+def _against_bigconfig_fixture(phi, g, MB, N, pos):
+    flat = phi.ravel()
+    np.testing.assert_allclose(flat[MB.sample_indices(N, pos, 20260300 + N)], g["vals"], rtol=1e-8, atol=0)
+    src_flat = ((pos[0] - 1) * N + (pos[1] - 1)) * N + (pos[2] - 1)
+    np.testing.assert_allclose(flat[src_flat], g["src_vals"], rtol=1e-8, atol=0)
+    d = MB.digest(phi)
+    assert int(d["nonzero"]) == int(g["nonzero"])
+    np.testing.assert_allclose(d["plane_sums"], g["plane_sums"], rtol=1e-9)
+    np.testing.assert_allclose(d["block_sums"], g["block_sums"], rtol=1e-9, atol=1e-12 * float(np.abs(g["block_sums"]).max()))
+    np.testing.assert_allclose(float(d["total"]), float(g["total"]), rtol=1e-10)
+
+
+def test_config3_256_lognormal_all_1000_sources_against_reference_fortran(asora, bench_tables):
+    """BASELINE configs[3] at its full workload: every one of the 1000 sources on the densest cells of the log-normal
+    256^3 density, fluxes proportional to the density, against the reference Fortran (one call per source: its
+    do_all_sources rates every source with the LAST source's flux, raytracing.f90:500)."""
+    import bench
+    import make_bigconfig_golden as MB
+    p, lib, capi = asora
+    N, NS, R = 256, 1000, 32.0
+    g = np.load(os.path.join(G, "fullsize_cosmo256_R32.npz"))
+    thin, thick, dlog = bench_tables
+    np.testing.assert_allclose([thin.sum(), thick.sum()], g["table_sums"], rtol=1e-13)
+    ndens, xh, temp, dr, pos, flux = bench.make_workload("cosmo", N, NS)
+    chk = MB.input_checksums(ndens, pos, flux)      # the regenerated inputs are the fixture's inputs
+    assert int(chk["pos_sum"]) == int(g["pos_sum"])
+    np.testing.assert_allclose([float(chk["ndens_sum"]), float(chk["flux_sum"])], [float(g["ndens_sum"]), float(g["flux_sum"])], rtol=1e-12)
+    _fresh(p, N)
+    p.photo_table_to_device(thin, thick)
+    p0, f0 = cases.flat_sources(pos, flux)
+    lib.source_data_to_device(p0, f0, NS)
+    lib.grid_to_device(capi.GRID_NDENS, ndens)
+    lib.grid_to_device(capi.GRID_XH_AV, xh)
+    lib.set_option(capi.OPT_FORTRAN_CONSTANTS, 1)
+    try:
+        lib.raytrace_device(R, bench.SIG, dr, 0, NS, bench.MINLOGTAU, dlog, thin.shape[0] - 1)
+    finally:
+        lib.set_option(capi.OPT_FORTRAN_CONSTANTS, 0)
+    phi = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+    gam, _ = lib.last_raytrace_counts()
+    assert gam == NS * _lattice_points_within(R)
+    _against_bigconfig_fixture(phi, g, MB, N, pos)
+
+
 # ---- configs[4] ---------------------------------------------------------------------------------------------------
 def test_config4_512_corner_sources_and_large_indices(asora):
     """512^3: the [k][j][i] twins of the grids start 2^30 bytes in and end beyond 2^31 bytes.  Sources on the first
@@ -197,6 +245,127 @@ def test_config4_512_corner_sources_and_large_indices(asora):
         acc += trace(np.array([s]))
     np.testing.assert_allclose(acc, full, rtol=1e-11, atol=0)
     p.device_close()
+
+
+def test_config4_512_all_1e5_sources_evolve_loop_and_reference_subset(asora, bench_tables):
+    """BASELINE configs[4] at its workload: 512^3 log-normal density (seed of bench.make_workload), 1e5 sources on the
+    densest cells, r_RT = 32.
+      (a) 256 of the sources (spread from the densest cell to the 1e5-th densest) against the reference Fortran's sparse
+          fixture; the two halves of that subset add up to the whole (superposition at this size);
+      (b) all 1e5 sources -- 1.2 M workgroups per launch -- through TWO outer iterations of the device-resident evolve
+          loop (1 GiB grids, the fused pass, the reduction buffers): exact pair counts, every field finite, and the same
+          convergence numbers, ionised fraction and rates as raytrace_device + chemistry_device called separately."""
+    import bench
+    import make_bigconfig_golden as MB
+    p, lib, capi = asora
+    N, NS, R = 512, 100000, 32.0
+    g = np.load(os.path.join(G, "fullsize_cosmo512_R32.npz"))
+    thin, thick, dlog = bench_tables
+    np.testing.assert_allclose([thin.sum(), thick.sum()], g["table_sums"], rtol=1e-13)
+    ndens, xh, temp, dr, pos, flux = bench.make_workload("cosmo", N, NS)
+    chk = MB.input_checksums(ndens, pos, flux)
+    assert int(chk["pos_sum"]) == int(g["pos_sum"])
+    np.testing.assert_allclose([float(chk["ndens_sum"]), float(chk["flux_sum"])], [float(g["ndens_sum"]), float(g["flux_sum"])], rtol=1e-12)
+    numtau = thin.shape[0] - 1
+    _fresh(p, N)
+    p.photo_table_to_device(thin, thick)
+    lib.grid_to_device(capi.GRID_NDENS, ndens)
+    lib.grid_to_device(capi.GRID_XH_AV, xh)
+
+    # (a) the fixture's subset, with the Fortran's constants
+    sub = MB.subset_indices(NS, int(g["nsub"]))
+    spos, sflux = pos[:, sub], flux[sub]
+
+    def trace(sel):
+        q0, g0 = cases.flat_sources(spos[:, sel], sflux[sel])
+        lib.source_data_to_device(q0, g0, g0.shape[0])
+        lib.raytrace_device(R, bench.SIG, dr, 0, g0.shape[0], bench.MINLOGTAU, dlog, numtau)
+        return lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+
+    lib.set_option(capi.OPT_FORTRAN_CONSTANTS, 1)
+    try:
+        both = trace(np.arange(sub.size))
+        gam, _ = lib.last_raytrace_counts()
+        assert gam == sub.size * _lattice_points_within(R)
+        _against_bigconfig_fixture(both, g, MB, N, spos)
+        half = trace(np.arange(sub.size // 2))
+        half += trace(np.arange(sub.size // 2, sub.size))
+    finally:
+        lib.set_option(capi.OPT_FORTRAN_CONSTANTS, 0)
+    w = both != 0
+    assert np.array_equal(half != 0, w)
+    np.testing.assert_allclose(half[w], both[w], rtol=1e-11, atol=0)
+    del both, half, w
+
+    # (b) the whole list through the loop
+    p0, f0 = cases.flat_sources(pos, flux)
+    lib.source_data_to_device(p0, f0, NS)
+    lib.grid_to_device(capi.GRID_TEMP, temp)
+    lib.grid_to_device(capi.GRID_XH, xh)
+    chem = (1e13, bench.BH00, bench.ALBPOW, bench.COLH0, bench.TEMPH0, bench.ABU_C)     # dt of SURVEY 8d(5)
+    lib.grid_copy(capi.GRID_XH_AV, capi.GRID_XH)
+    lib.grid_copy(capi.GRID_XH_INTERMED, capi.GRID_XH)
+    sep = []
+    for it in range(2):
+        lib.raytrace_device(R, bench.SIG, dr, 0, NS, bench.MINLOGTAU, dlog, numtau)
+        gam, ev = lib.last_raytrace_counts()
+        assert gam == NS * _lattice_points_within(R) and ev > gam
+        sep.append(lib.chemistry_device(*chem))
+    x_sep = lib.grid_to_host(capi.GRID_XH_INTERMED, np.empty((N, N, N)))
+    phi_sep = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+    assert np.isfinite(x_sep).all() and np.isfinite(phi_sep).all() and (phi_sep >= 0).all()
+    assert 0 <= sep[0][0] <= N ** 3 and x_sep.min() > 0.0 and x_sep.max() <= 1.0
+    lib.evolve_begin(*chem, R, bench.SIG, dr, bench.MINLOGTAU, dlog, numtau, 0, NS, -1.0, 1e-4)
+    lib.evolve_enqueue(2)
+    n_done, done, rows = lib.evolve_poll()
+    assert n_done == 2 and len(rows) == 2
+    gam, _ = lib.last_raytrace_counts()
+    assert gam == 2 * NS * _lattice_points_within(R)            # the loop's counters run on from evolve_begin
+    for it in range(2):
+        assert int(rows[it][0]) == sep[it][0]
+        np.testing.assert_allclose(rows[it][1:3], sep[it][1:3], rtol=1e-12)
+    x_fused = lib.grid_to_host(capi.GRID_XH_INTERMED, np.empty((N, N, N)))
+    np.testing.assert_allclose(x_fused, x_sep, rtol=1e-11, atol=0)
+    del x_fused, x_sep
+    phi_fused = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+    w = phi_sep != 0
+    assert np.array_equal(phi_fused != 0, w)
+    np.testing.assert_allclose(phi_fused[w], phi_sep[w], rtol=1e-11, atol=0)
+    p.device_close()
+
+
+# ---- a-7 at the benchmark's size ----------------------------------------------------------------------------------------
+def test_c2ray_do_all_sources_256_uniform_1000_sources_against_reference_fortran(asora, bench_tables):
+    """libc2ray.raytracing.do_all_sources -- the reference's CPU function, evaluated by the sub-box kernels -- on the
+    benchmark workload itself (256^3, 1000 sources, one sub-box of +-32 cells, R_max_LLS = 32: the call of
+    raytracing_benchmark/run_test.py:88), host arrays in and out, against the reference Fortran's fixture."""
+    import bench
+    import make_fullsize_golden as MG
+    from pyc2ray_amd.load_extensions import load_c2ray
+    p, lib, capi = asora
+    N, NS, R = 256, 1000, 32
+    g = np.load(os.path.join(G, f"fullsize_uniform_R{R}.npz"))
+    thin, thick, dlog = bench_tables
+    ndens, xh, temp, dr, pos, flux = bench.make_workload("uniform", N, NS)
+    if p.cuda_is_init():
+        p.device_close()
+    f = lambda a: np.asfortranarray(a)
+    cd, phi, heat = (np.zeros((N, N, N), order="F") for _ in range(3))
+    zeros = np.zeros(thin.shape[0])
+    nbox, loss = load_c2ray().raytracing.do_all_sources(flux, pos.astype(np.int32), R, R, cd, bench.SIG, dr, f(ndens), f(xh), phi,
+                                                        heat, 0.0, thin, thick, zeros, zeros, bench.MINLOGTAU, dlog, float(R))
+    assert nbox == int(g["nsubbox"]) == NS
+    flat = np.ascontiguousarray(phi).ravel()
+    np.testing.assert_allclose(flat[MG.sample_indices(R)], g["vals"], rtol=1e-8, atol=0)
+    src_flat = ((pos[0] - 1) * N + (pos[1] - 1)) * N + (pos[2] - 1)
+    np.testing.assert_allclose(flat[src_flat], g["src_vals"], rtol=1e-8, atol=0)
+    d = MG.digest(np.ascontiguousarray(phi))
+    assert int(d["nonzero"]) == int(g["nonzero"])
+    np.testing.assert_allclose(d["plane_sums"], g["plane_sums"], rtol=1e-9)
+    np.testing.assert_allclose(d["block_sums"], g["block_sums"], rtol=1e-9)
+    np.testing.assert_allclose(float(d["total"]), float(g["total"]), rtol=1e-10)
+    # the column densities that come back are the LAST source's, over its whole +-32 cube (raytracing.f90:181,488)
+    assert np.count_nonzero(cd) == (2 * R + 1) ** 3 and np.isfinite(cd).all() and not heat.any()
 
 
 # ---- configs[1] ---------------------------------------------------------------------------------------------------

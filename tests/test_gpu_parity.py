@@ -912,6 +912,46 @@ def test_chemistry_slabs_equal_the_whole_pass_for_odd_and_even_meshes(asora, N):
     np.testing.assert_allclose(xa, xa_ref, rtol=1e-9, atol=0)
 
 
+def test_chemistry_range_of_any_plane_count_fits_the_reduction_buffer(asora):
+    """A range of planes can need MORE workgroups than the whole grid (the j-chunk count is rounded up per tile): at 256^3,
+    65..96 planes ask for up to 4104 against 4096 -- the slab of a 3-rank run (85/86 planes).  Every such range must run,
+    its three reductions must add up to the whole pass, and the rest of the grid must be left alone."""
+    p, lib, capi = asora
+    N = 256
+    rng = np.random.default_rng(256)
+    nd = 1e-3 * np.exp(0.5 * rng.standard_normal((N, N, N), dtype=np.float32).astype(np.float64))
+    xh = np.full((N, N, N), 2e-4)
+    temp = np.full((N, N, N), 1e4)
+    phi = 1e-13 * rng.random((N, N, N), dtype=np.float32).astype(np.float64) ** 4
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 8)
+    chem = (3.15576e13, cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C)
+
+    def load():
+        for which, a in ((capi.GRID_NDENS, nd), (capi.GRID_TEMP, temp), (capi.GRID_XH, xh), (capi.GRID_XH_AV, xh),
+                         (capi.GRID_XH_INTERMED, xh), (capi.GRID_PHI_ION, phi)):
+            lib.grid_to_device(which, a)
+
+    load()
+    conv, s1, s0 = lib.chemistry_device(*chem)
+    xi = lib.grid_to_host(capi.GRID_XH_INTERMED, np.empty((N, N, N)))
+    assert conv > 1000
+    for cuts in ([0, 85, 170, 256], [0, 65, 161, 256], [0, 96, 96 + 75, 256]):       # 3 ranks; 65, 96 and 75 planes
+        load()
+        for q in range(len(cuts) - 1):
+            lib.chemistry_range(*chem, cuts[q], cuts[q + 1] - cuts[q], q == 0)
+        conv2, s1b, s0b = lib.chemistry_finish()
+        assert conv2 == conv
+        np.testing.assert_allclose([s1b, s0b], [s1, s0], rtol=1e-13)
+        assert np.array_equal(lib.grid_to_host(capi.GRID_XH_INTERMED, np.empty((N, N, N))), xi)
+    load()
+    lib.chemistry_range(*chem, 100, 70, True)              # one range alone: the planes outside it keep their values
+    part = lib.grid_to_host(capi.GRID_XH_INTERMED, np.empty((N, N, N)))
+    assert np.array_equal(part[100:170], xi[100:170]) and np.all(part[:100] == 2e-4) and np.all(part[170:] == 2e-4)
+    p.device_close()
+
+
 @pytest.mark.parametrize("N,ns,R", [(17, 3, 1000.0), (32, 5, 9.0), (40, 11, 13.5)])
 def test_device_resident_loop_equals_the_step_by_step_loop(asora, N, ns, R, monkeypatch, tmp_path):
     """evolve3D on one GPU enqueues batches of outer iterations and lets the device evaluate the convergence test.

@@ -118,6 +118,30 @@ def test_tau_and_blackbody_tables():
     assert np.isclose(thick[0], 1e48) and np.all(np.diff(thick) <= 1e-9 * thick[0]) and thin[0] < thick[0]
 
 
+def test_radiation_tables_equal_the_reference_python():
+    """tests/golden/radiation.npz holds make_tau_table(-20, 4, 2000) and the photo-ionisation tables of Teff = 5e3, 5e4,
+    1e5 K, grey and power-law cross sections, produced by the reference's own pyc2ray/radiation/{common,blackbody}.py
+    (tests/golden/make_radiation_golden.py).  The benchmark, paper test 3 and the hackathon test all run on such tables."""
+    from pyc2ray_amd.radiation import BlackBodySource, make_tau_table
+    g = np.load(os.path.join(ROOT, "tests", "golden", "radiation.npz"))
+    tau, dlog = make_tau_table(-20.0, 4.0, 2000)
+    assert np.array_equal(tau, g["tau"]) and dlog == float(g["dlogtau"])
+    ev2fr = 0.241838e15
+    f1, f2 = ev2fr * 13.598, 10 * ev2fr * 54.416
+    for teff in g["teffs"]:
+        for grey in (True, False):
+            src = BlackBodySource(float(teff), grey, f1, 2.8)
+            thin, thick = src.make_photo_table(tau, f1, f2, 1e48)
+            key = f"T{teff:g}_{'grey' if grey else 'pl'}"
+            np.testing.assert_allclose(src.R_star, float(g[key + "_Rstar"]), rtol=1e-13)
+            for got, name in ((thin, "_thin"), (thick, "_thick")):
+                want = g[key + name]
+                assert np.array_equal(got != 0, want != 0), key + name       # the table's cut-off (tau a > 700) in the same place
+                np.testing.assert_allclose(got, want, rtol=1e-10, atol=0, err_msg=key + name)
+            if not grey:      # the shape the grey closed form cannot see: harder photons are absorbed less
+                assert thin[0] < 0.95 * thick[0] and thick[1500] > 1e48 * np.exp(-tau[1500])
+
+
 def test_blackbody_heating_tables_grey_closed_form():
     """Grey opacity: every photon sees the same optical depth, so both heating tables are H0 * exp(-tau) with
     H0 = int h (nu - nu_HI) S(nu) dnu, and the mean energy per ionisation H0/S_star lies between 0 and
