@@ -216,8 +216,9 @@ class _LibAsora:
         iterations carried out since the last poll."""
         niter, done, got = C.c_int(0), C.c_int(0), C.c_int(0)
         hist = np.zeros((int(max_rows), 5))
-        _capi.check(self._lib.asora_evolve_poll(C.byref(niter), C.byref(done), _capi.dptr(hist), int(max_rows),
-                                                C.byref(got)), "evolve_poll")
+        # max_rows = 0: the caller gives the rows up (the library's history ring holds 64 iterations between polls)
+        _capi.check(self._lib.asora_evolve_poll(C.byref(niter), C.byref(done), _capi.dptr(hist) if max_rows > 0 else None,
+                                                int(max_rows), C.byref(got)), "evolve_poll")
         return niter.value, bool(done.value), hist[:got.value]
 
     def planes_to_host(self, which, i_begin, i_count, N):
