@@ -251,7 +251,8 @@ def main():
     ap.add_argument("--overlap", type=int, default=-1,
                     help="N>1: 1 = pipeline the all-reduce of the rate grid with the raytrace (sources traced in order of "
                          "their first coordinate), 0 = trace, then all-reduce; default: env PYC2RAY_AMD_OVERLAP or 0")
-    ap.add_argument("--sectors", type=int, default=0, help="0 auto, 1 octant workgroups, 2 octant x sector workgroups")
+    ap.add_argument("--sectors", type=int, default=0, help="decomposition of a source (ASORA_OPT_SECTORS): 0 auto, 1 octants, 2 sectors, 3 sector pairs, 5 octant pairs, 6 whole sphere, 7 half spheres, 8 all-sign sectors")
+    ap.add_argument("--pair-sources", type=int, default=0, help="raytrace, two sources per workgroup: 0 auto, 1 never, 2 always")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -349,6 +350,7 @@ def main():
     lib.set_option(_capi.OPT_Z_TRANSPOSED, args.z_transposed)
     lib.set_option(_capi.OPT_BLOCK_THREADS, args.block_threads)
     lib.set_option(_capi.OPT_SECTORS, args.sectors)
+    lib.set_option(_capi.OPT_PAIR_SOURCES, args.pair_sources)
 
     chem = (MYR, BH00, ALBPOW, COLH0, TEMPH0, ABU_C)
     state = {"first": True, "slab": slab}

@@ -252,7 +252,12 @@ enum {
      * 2 = one per octant and dominant-axis sector (24 per source, diagonal planes re-derived);
      * 3 = one per pair of mirrored sectors (12 per source; rows are full chords of the sphere);
      * 4 = one per quarter of a sector plus the cells it reads (96 per source: a handful of sources);
-     * 5 = one per pair of whole octants mirrored in x (4 per source). */
+     * 5 = one per pair of whole octants mirrored in x (4 per source);
+     * 6 = ONE workgroup per source: the whole sphere (nothing evaluated twice, every row a full chord, the least padding;
+     *     the shell buffers must fit LDS: small radii);
+     * 7 = one per half sphere (x and z mirrored, split by the sign of dj: 2 per source);
+     * 8 = one per dominant-axis sector with all signs (3 per source);
+     * 9 = one per sector and sign of its dominant offset, both transverse axes mirrored (6 per source). */
     ASORA_OPT_SECTORS = 5,
     /* 1: the raytrace also accumulates the photo-heating rate into ASORA_GRID_PHI_HEAT
      *    (src/c2ray/photorates.f90:118,124; src/c2ray/raytracing.f90:532,537); needs heat tables. */
@@ -278,7 +283,12 @@ enum {
      *    the default, buffer_atomic_add_f64 through a descriptor over [phi | phi_t] with out-of-range offsets for lanes
      *    without a rate (N <= 512).  Same arithmetic; for A/B runs and the parity test of the two forms. */
     ASORA_OPT_GLOBAL_ATOMICS = 12,
-    ASORA_OPT_COUNT = 13
+    /* raytrace: one workgroup sweeps its unit for TWO consecutive sources at once (the source-independent geometry is
+     * decoded once per lane-step, two dependency chains per wave).  0 = the library decides from the radius and the
+     * number of sources (default), 1 = never, 2 = whenever the variant exists (table rates, no heating, shell buffers
+     * in LDS, buffer atomics).  Same rates either way, up to the order in which the atomics add them up. */
+    ASORA_OPT_PAIR_SOURCES = 13,
+    ASORA_OPT_COUNT = 14
 };
 int asora_set_option(int option, int value);
 int asora_get_option(int option);

@@ -212,9 +212,15 @@ extern "C" __device__ double asora_buffer_atomic_fadd_f64(double, __amdgpu_buffe
 #define ASORA_MIN_WAVES 1
 #endif
 
-constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_RATE = 1u << 29, CELL_NEG = 1u << 28,
+// the same for the paired-sources variant (NSRC = 2): left alone it takes 134 VGPRs (3 waves per SIMD)
+#ifndef ASORA_PAIR_MIN_WAVES
+#define ASORA_PAIR_MIN_WAVES 1
+#endif
+
+constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_RATE = 1u << 29,
                    CELL_ZERO_SHIFT = 25,              // bits 25..27: which of the offsets (a, b, c) are zero
-                   CELL_SLOT_MASK = (1u << 25) - 1;   // NEG: the cell lies on the mirrored side of the unit's merge axis
+                   CELL_NEG_SHIFT = 22,               // bits 22..24: the cell lies on the mirrored side of axis 0 / 1 / 2 (axes the unit merges)
+                   CELL_SLOT_MASK = (1u << 22) - 1;
 
 // GREY (ASORA_OPT_GREY_NOTABLES) is a compile-time variant although its branch is wave-uniform: the compiler counts the
 // vector-memory operations in flight per PATH and, where paths of different counts meet, waits as the shortest one
@@ -224,11 +230,19 @@ constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_RATE = 1u <
 // pair of grids stays within 2 GiB, N <= 512): the atomic of a step is then ONE unconditional instruction -- with
 // `if (lane has a rate) atomic` the compiler sees a path without the atomic and counts one operation too few in flight
 // behind every earlier load, i.e. every wait for a lookup also waited for the atomic issued after it.
+// NSRC = 2: one workgroup sweeps its unit for TWO sources at once (consecutive entries of the source list, which a whole-list
+// call has ordered by position: neighbours).  Everything a step derives from the table entry alone -- offsets, face, shell,
+// bilinear weights and their products, path, volume factor, owner bits, the shell barrier -- is then evaluated once per
+// lane-step instead of once per source (~45 of ~230 VALU instructions), the tables are streamed once, and a wave carries
+// two independent dependency chains (LDS reads -> interpolation -> LDS write) that interleave.  What stays per source:
+// the shell buffers and wrapped-coordinate tables in LDS, nHI, the interpolation, the lookups and the atomic.  An odd
+// source count leaves the last workgroup with a copy of its first source whose rates are dropped (`have`).
 template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP, bool HEAT, int TABCAP, bool SKIP_ZERO = false, bool GREY = false,
-          bool BUFATOM = false>
-__global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAVES : 1)) raytrace_octant_kernel(const RtParams p)
+          bool BUFATOM = false, int NSRC = 1>
+__global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? ASORA_PAIR_MIN_WAVES : ASORA_MIN_WAVES) : 1)) raytrace_octant_kernel(const RtParams p)
 {
     extern __shared__ double lds_raw[];
+    static_assert(NSRC == 1 || (ASORA_LATE_LOOKUP && !GLOBAL_SCRATCH && !DUMP && !SKIP_ZERO), "paired sources: production variant only");
 
     if (p.done_flag && *p.done_flag) return;   // evolve loop: an iteration enqueued beyond convergence does nothing
     const int blk = blockIdx.x;
@@ -237,7 +251,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
     // p.units workgroups per source (8, 24, 12, 96 or 4: see ensure_geometry).
     // p.spread (a handful of sources): consecutive blocks are the units of ONE source, i.e. they go to different XCDs --
     // with the grouping above a single source would keep all its workgroups on one XCD's 32 CUs.
-    int src_local, unit;
+    int src_local, unit;      // src_local: index of the group of NSRC sources this workgroup sweeps
     if (p.spread) {
         src_local = blk / p.units;
         unit = blk % p.units;
@@ -248,30 +262,37 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
 #if ASORA_UNITS_LARGEST_FIRST
     unit = p.units - 1 - unit;   // sector units: z (most cells) first, x (fewest) last in dispatch order
 #endif
-    if (src_local >= p.src_count) return;
-    const int ns = p.src_begin + src_local;
+    if (src_local * NSRC >= p.src_count) return;
 
     const uint4 *__restrict__ cellA = p.geom[unit].cellA;
     const uint4 *__restrict__ cellB = p.geom[unit].cellB;
     const int nsteps = p.geom[unit].nsteps;
-    const int uinfo = p.geom[unit].info;           // sign bits of the unit | (merge axis + 1) << 3 | rates-source << 5
-    const int merge_axis = ((uinfo >> 3) & 3) - 1;
+    const int uinfo = p.geom[unit].info;           // sign bits of the unit | merged axes << 3 | rates-source << 6
     const int N = p.N;
-    const int i0 = p.src_pos[3 * ns + 0];
-    const int j0 = p.src_pos[3 * ns + 1];
-    const int k0 = p.src_pos[3 * ns + 2];
-    const double flux = p.src_flux[ns];
+    int i0[NSRC], j0[NSRC], k0[NSRC];
+    double flux[NSRC];
+    bool have[NSRC];
+    unsigned nreal = 0;
+#pragma unroll
+    for (int q = 0; q < NSRC; ++q) {
+        have[q] = src_local * NSRC + q < p.src_count;
+        const int ns = p.src_begin + (have[q] ? src_local * NSRC + q : src_local * NSRC);
+        i0[q] = p.src_pos[3 * ns + 0];
+        j0[q] = p.src_pos[3 * ns + 1];
+        k0[q] = p.src_pos[3 * ns + 2];
+        flux[q] = p.src_flux[ns];
+        nreal += have[q] ? 1u : 0u;
+    }
     const int sa = (uinfo & 1) ? -1 : 1, sb = (uinfo & 2) ? -1 : 1, sc = (uinfo & 4) ? -1 : 1;
 
     // LDS: the small tables sit first, at compile-time offsets (TABCAP entries each), then the shell buffers
     double2 *logtab = reinterpret_cast<double2 *>(lds_raw);
     double *inv_s = reinterpret_cast<double *>(logtab + LOG_TABLE_SIZE);
-    int *wi = reinterpret_cast<int *>(inv_s + TABCAP);
-    int *wj = wi + TABCAP;
-    int *wk = wj + TABCAP;
-    int *wm = wk + TABCAP;                         // mirrored side of the merge axis
-    double *shells = reinterpret_cast<double *>(wm + TABCAP);
+    // per source, per axis: wrapped position of offset t on the unit's side [0, TABCAP) and on the mirrored side [TABCAP, 2 TABCAP)
+    int *wtab = reinterpret_cast<int *>(inv_s + TABCAP);
+    double *shells = reinterpret_cast<double *>(wtab + NSRC * 6 * TABCAP);
     const int slots = (p.max_cells + 2) & ~1;      // cells + the zero slot, even (keeps 16-B alignment)
+    // source q's two shell buffers follow source q-1's: prev/cur of source q = prev/cur + q * 2 * slots
     double *prev, *cur;
     if (GLOBAL_SCRATCH) {
         prev = p.shell_scratch + (size_t)blk * 2 * slots;
@@ -280,16 +301,26 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
         prev = shells;
         cur = prev + slots;
     }
+    const int src_stride = 2 * slots;
 
     for (int t = threadIdx.x; t < LOG_TABLE_SIZE; t += RT_THREADS) logtab[t] = p.logtab[t];
     for (int t = threadIdx.x; t <= p.S; t += RT_THREADS) {
         inv_s[t] = 1.0 / (double)max(t, 1);
-        wi[t] = wrap_once(i0 + sa * t, N);      // periodic position of offset t along each axis
-        wj[t] = wrap_once(j0 + sb * t, N);      // (|offset| <= N/2: one wrap suffices, raytracing.cu:270-272)
-        wk[t] = wrap_once(k0 + sc * t, N);
-        wm[t] = merge_axis == 0 ? wrap_once(i0 - t, N) : wrap_once(k0 - t, N);
+#pragma unroll
+        for (int q = 0; q < NSRC; ++q) {
+            int *w = wtab + q * 6 * TABCAP;
+            w[t] = wrap_once(i0[q] + sa * t, N);      // periodic position of offset t along each axis
+            w[TABCAP + t] = wrap_once(i0[q] - sa * t, N);      // (|offset| <= N/2: one wrap suffices, raytracing.cu:270-272)
+            w[2 * TABCAP + t] = wrap_once(j0[q] + sb * t, N);
+            w[3 * TABCAP + t] = wrap_once(j0[q] - sb * t, N);
+            w[4 * TABCAP + t] = wrap_once(k0[q] + sc * t, N);
+            w[5 * TABCAP + t] = wrap_once(k0[q] - sc * t, N);
+        }
     }
-    if (threadIdx.x == 0) { prev[p.max_cells] = 0.0; cur[p.max_cells] = 0.0; }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < NSRC; ++q) { prev[q * src_stride + p.max_cells] = 0.0; cur[q * src_stride + p.max_cells] = 0.0; }
+    }
     __syncthreads();
 
     const double sig = p.sig, dr = p.dr;
@@ -317,18 +348,21 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
 
     // ---- shell 0: the source cell (raytracing.cu:285-294) -----------------------------------
     if (threadIdx.x == 0) {
-        const unsigned idx = ((unsigned)i0 * N + j0) * N + k0;
-        const double nHI = p.nhi[idx];
-        const double path = 0.5 * dr;
-        const double cd_out = 0.0 + nHI * path;
-        prev[0] = cd_out;
-        src_cell_eval = 1;
-        if (uinfo & 32) {                             // the source cell is rated by exactly one unit
-            if (DUMP) p.dump[idx] = cd_out;
-            const double phi = photo_rate_per_atom(flux, 0.0, cd_out, dr * dr * dr * nHI, p, logtab);
-            unsafeAtomicAdd(&p.phi[idx], phi);
-            if (HEAT && !p.grey) unsafeAtomicAdd(&p.heat[idx], heat_rate_per_atom(flux, 0.0, cd_out, dr * dr * dr * nHI, p, logtab));
-            src_cell_gamma = 1;
+#pragma unroll
+        for (int q = 0; q < NSRC; ++q) {
+            const unsigned idx = ((unsigned)i0[q] * N + j0[q]) * N + k0[q];
+            const double nHI = p.nhi[idx];
+            const double path = 0.5 * dr;
+            const double cd_out = 0.0 + nHI * path;
+            prev[q * src_stride] = cd_out;
+            src_cell_eval += have[q] ? 1u : 0u;
+            if ((uinfo & 64) && have[q]) {                 // the source cell is rated by exactly one unit
+                if (DUMP) p.dump[idx] = cd_out;
+                const double phi = photo_rate_per_atom(flux[q], 0.0, cd_out, dr * dr * dr * nHI, p, logtab);
+                unsafeAtomicAdd(&p.phi[idx], phi);
+                if (HEAT && !p.grey) unsafeAtomicAdd(&p.heat[idx], heat_rate_per_atom(flux[q], 0.0, cd_out, dr * dr * dr * nHI, p, logtab));
+                src_cell_gamma += 1;
+            }
         }
     }
     __syncthreads();
@@ -339,11 +373,12 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
     // ahead, nHI one step ahead.  The rate lookups of a step are issued after its shell barrier, so
     // their latency never holds the barrier up, and consumed a step later (ASORA_LATE_LOOKUP).
     // (The tables carry two all-invalid steps of padding at the end: prefetches stay in bounds.)
-    auto nhi_address = [&](unsigned abc, unsigned flags, unsigned &idx) -> const double * {
-        const bool neg = (flags & CELL_NEG) != 0;
-        const unsigned i = (neg && merge_axis == 0) ? wm[abc & 1023] : wi[abc & 1023];
-        const unsigned j = wj[(abc >> 10) & 1023];
-        const unsigned k = (neg && merge_axis == 2) ? wm[(abc >> 20) & 1023] : wk[(abc >> 20) & 1023];
+    auto nhi_address = [&](int q, unsigned abc, unsigned flags, unsigned &idx) -> const double * {
+        const int *w = wtab + q * 6 * TABCAP;
+        // (a cell on the mirrored side of an axis the unit merges reads the second half of that axis's table)
+        const unsigned i = w[(abc & 1023) + ((flags >> CELL_NEG_SHIFT) & 1u) * TABCAP];
+        const unsigned j = w[2 * TABCAP + ((abc >> 10) & 1023) + ((flags >> (CELL_NEG_SHIFT + 1)) & 1u) * TABCAP];
+        const unsigned k = w[4 * TABCAP + ((abc >> 20) & 1023) + ((flags >> (CELL_NEG_SHIFT + 2)) & 1u) * TABCAP];
         const bool zt = ztr && (abc >> 30) == 2;
         // the [k][j][i] copies follow the [i][j][k] grids in memory: one 32-bit index covers both
         // (one formula with the outer and inner coordinate swapped, rather than two under a branch)
@@ -359,21 +394,30 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
     // step's (its nHI is requested here), `pf_*` the register set the entry two steps ahead is
     // loaded into.  The loop below is unrolled three times with the three register sets rotating,
     // so the pipeline needs no register-to-register copies.
-    bool late_ok = false;              // a rate computed in the previous step, not yet added (ASORA_LATE_ATOMIC)
+    bool late_ok[NSRC];                // a rate computed in the previous step, not yet added (ASORA_LATE_ATOMIC)
 #if !ASORA_LATE_LOOKUP
-    double late_v = 0.0, late_h = 0.0;
+    double late_v[NSRC], late_h[NSRC];
 #endif
-    unsigned late_idx = 0;
+    unsigned late_idx[NSRC];
 #if ASORA_LATE_LOOKUP
-    Lookup pend_A, pend_B;             // lookups issued in the previous step, consumed in this one
-    pend_A.t = pend_B.t = pend_A.h = pend_B.h = double2{0.0, 0.0};
-    pend_A.residual = pend_B.residual = 0.0;
-    bool pend_thick = false;
-    double pend_pref = 0.0, pend_dtau = 0.0;
+    Lookup pend_A[NSRC], pend_B[NSRC];             // lookups issued in the previous step, consumed in this one
+    bool pend_thick[NSRC];
+    double pend_pref[NSRC], pend_dtau[NSRC];
 #endif
+#pragma unroll
+    for (int q = 0; q < NSRC; ++q) {
+        late_ok[q] = false; late_idx[q] = 0;
+#if !ASORA_LATE_LOOKUP
+        late_v[q] = 0.0; late_h[q] = 0.0;
+#else
+        pend_A[q].t = pend_B[q].t = pend_A[q].h = pend_B[q].h = double2{0.0, 0.0};
+        pend_A[q].residual = pend_B[q].residual = 0.0;
+        pend_thick[q] = false; pend_pref[q] = 0.0; pend_dtau[q] = 0.0;
+#endif
+    }
 
-    auto step = [&](unsigned e_pf, const uint4 &cur_A, const uint4 &cur_B, const double cur_nhi, const unsigned cur_idx,
-                    const uint4 &nxt_A, double &nxt_nhi, unsigned &nxt_idx, uint4 &pf_A, uint4 &pf_B) {
+    auto step = [&](unsigned e_pf, const uint4 &cur_A, const uint4 &cur_B, const double (&cur_nhi)[NSRC], const unsigned (&cur_idx)[NSRC],
+                    const uint4 &nxt_A, double (&nxt_nhi)[NSRC], unsigned (&nxt_idx)[NSRC], uint4 &pf_A, uint4 &pf_B) {
 #if ASORA_STEP_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);      // nothing of this step is scheduled into the previous one (see the macro)
 #endif
@@ -385,7 +429,8 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
             n_eval += (extra.x == 0xdeadbeefu && extra.w == 0x12345u) ? 1u : 0u;
         }
 #endif
-        nxt_nhi = *nhi_address(nxt_A.x, nxt_A.y, nxt_idx);          // one step ahead
+#pragma unroll
+        for (int q = 0; q < NSRC; ++q) nxt_nhi[q] = *nhi_address(q, nxt_A.x, nxt_A.y, nxt_idx[q]);          // one step ahead
 
         const bool valid = (cur_A.y & CELL_VALID) != 0;
         // waves whose 64 entries are all padding skip the arithmetic (wave-uniform branch)
@@ -394,10 +439,13 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
 #else
         const bool wave_has_work = true;
 #endif
-        bool rated = false;
-        double cd_in = 0.0, cd_out = 0.0, vol_nhi = 1.0;
-        unsigned dst_idx = 0;
+        bool rated[NSRC];
+        double cd_in[NSRC], cd_out[NSRC], vol_nhi[NSRC];
+        unsigned dst_idx[NSRC];
+#pragma unroll
+        for (int q = 0; q < NSRC; ++q) { rated[q] = false; cd_in[q] = 0.0; cd_out[q] = 0.0; vol_nhi[q] = 1.0; dst_idx[q] = 0; }
         if (wave_has_work) {
+        // ---- what the table entry alone determines: once per lane-step, whatever NSRC -------------------------------
         const unsigned abc = cur_A.x;
         const int a = abc & 1023, b = (abc >> 10) & 1023, c = (abc >> 20) & 1023;
         const unsigned face = abc >> 30;                 // 2: dk = s, 1: dj = s, 0: di = s
@@ -414,49 +462,62 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
         //  in shell s-1 and reads the zero slot, so only the denominator moves, below rounding)
         const double fu = (double)U * is, fv = (double)V * is;
         const double gu = 1.0 - fu, gv = 1.0 - fv;
-        // w_n = s_n / max(0.6, c_n*sig) (raytracing.cu:33,422-425) and
-        // cdensi = sum(c_n w_n)/sum(w_n) (raytracing.cu:428), with numerator and denominator
-        // multiplied through by the four max() terms: one division instead of five.
-        const double x1 = prev[cur_B.x], x2 = prev[cur_B.y], x3 = prev[cur_B.z], x4 = prev[cur_B.w];
-        const double m1 = fmax(0.6, x1 * sig), m2 = fmax(0.6, x2 * sig);
-        const double m3 = fmax(0.6, x3 * sig), m4 = fmax(0.6, x4 * sig);
-        const double m12 = m1 * m2, m34 = m3 * m4;
-        const double q1 = (fu * fv) * (m2 * m34), q2 = (fv * gu) * (m1 * m34);
-        const double q3 = (fu * gv) * (m12 * m4), q4 = (gu * gv) * (m12 * m3);
-#ifdef ASORA_DIAG_NO_DIVISION        // diagnostic build only (wrong values): what the two divisions of a cell cost
-        cd_in = (x1 * q1 + x2 * q2 + x3 * q3 + x4 * q4) * __builtin_amdgcn_rcp(q1 + q2 + q3 + q4);
-#else
-        cd_in = ASORA_DIV(x1 * q1 + x2 * q2 + x3 * q3 + x4 * q4, q1 + q2 + q3 + q4);     // (the weights sum to 1, each max() is >= 0.6)
-#endif
-        if (s == 1) {                                    // diagonal neighbours of the source, cu:431-441
-            const int nz = (a == 0) + (b == 0) + (c == 0);
-            const double r3 = p.fortran_consts ? (double)1.7320507764816284 : 1.73205080757; // f90:608 / cu:435
-            const double r2 = p.fortran_consts ? (double)1.4142135381698608 : 1.41421356237; // f90:609 / cu:439
-            if (nz < 2) cd_in = (nz == 0 ? r3 : r2) * cd_in;
-        }
+        const double w1 = fu * fv, w2 = fv * gu, w3 = fu * gv, w4 = gu * gv;
         const double path = __hiloint2double((int)cur_A.w, (int)cur_A.z) * dr;
-
-        // ---- the cell itself, raytracing.cu:270-276,311-328 -----------------------------
-        const double nHI = cur_nhi;
-        cd_out = fma(nHI, path, cd_in);
-        if (valid) cur[cur_A.y & CELL_SLOT_MASK] = cd_out;
-        n_eval += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid));
         // a cell on an octant-boundary plane is rated by the octant with the + sign there
         const unsigned zmask = (cur_A.y >> CELL_ZERO_SHIFT) & 7u;        // (a == 0) | (b == 0) << 1 | (c == 0) << 2, tabulated
         const double maxcd = p.fortran_consts ? (double)2e30f : 2e30;                    // raytracing.cu:15
         const bool owner = valid && (cur_A.y & CELL_RATE) && (zmask & negmask) == 0;
-        if (DUMP) {
-            if (owner) {
-                const bool neg = (cur_A.y & CELL_NEG) != 0;
-                const unsigned di = (neg && merge_axis == 0) ? wm[a] : wi[a], dk = (neg && merge_axis == 2) ? wm[c] : wk[c];
-                p.dump[(di * N + wj[b]) * N + dk] = cd_out;
-            }
-        }
-        rated = owner && cd_in <= maxcd && !ASORA_ABLATED(2);
-        n_gamma += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(owner && cd_in <= maxcd));
         const double n2 = (double)(a * a + b * b + c * c);
-        vol_nhi = n2 * (dr * dr * FOURPI) * path * nHI;                     // raytracing.cu:302-307
-        dst_idx = cur_idx;
+        const double volfac = n2 * (dr * dr * FOURPI) * path;                              // raytracing.cu:302-307 without nHI
+        const unsigned own_slot = cur_A.y & CELL_SLOT_MASK;
+        n_eval += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid)) * nreal;
+
+        // ---- per source: the medium-dependent arithmetic ----------------------------------------------------------------
+#pragma unroll
+        for (int q = 0; q < NSRC; ++q) {
+            const double *pq = prev + q * src_stride;
+            // w_n = s_n / max(0.6, c_n*sig) (raytracing.cu:33,422-425) and
+            // cdensi = sum(c_n w_n)/sum(w_n) (raytracing.cu:428), with numerator and denominator
+            // multiplied through by the four max() terms: one division instead of five.
+            const double x1 = pq[cur_B.x], x2 = pq[cur_B.y], x3 = pq[cur_B.z], x4 = pq[cur_B.w];
+            const double m1 = fmax(0.6, x1 * sig), m2 = fmax(0.6, x2 * sig);
+            const double m3 = fmax(0.6, x3 * sig), m4 = fmax(0.6, x4 * sig);
+            const double m12 = m1 * m2, m34 = m3 * m4;
+            const double q1 = w1 * (m2 * m34), q2 = w2 * (m1 * m34);
+            const double q3 = w3 * (m12 * m4), q4 = w4 * (m12 * m3);
+#ifdef ASORA_DIAG_NO_DIVISION        // diagnostic build only (wrong values): what the two divisions of a cell cost
+            double cdi = (x1 * q1 + x2 * q2 + x3 * q3 + x4 * q4) * __builtin_amdgcn_rcp(q1 + q2 + q3 + q4);
+#else
+            double cdi = ASORA_DIV(x1 * q1 + x2 * q2 + x3 * q3 + x4 * q4, q1 + q2 + q3 + q4);     // (the weights sum to 1, each max() is >= 0.6)
+#endif
+            if (s == 1) {                                    // diagonal neighbours of the source, cu:431-441
+                const int nz = (a == 0) + (b == 0) + (c == 0);
+                const double r3 = p.fortran_consts ? (double)1.7320507764816284 : 1.73205080757; // f90:608 / cu:435
+                const double r2 = p.fortran_consts ? (double)1.4142135381698608 : 1.41421356237; // f90:609 / cu:439
+                if (nz < 2) cdi = (nz == 0 ? r3 : r2) * cdi;
+            }
+            cd_in[q] = cdi;
+
+            // ---- the cell itself, raytracing.cu:270-276,311-328 -----------------------------
+            const double nHI = cur_nhi[q];
+            cd_out[q] = fma(nHI, path, cdi);
+            if (valid) cur[q * src_stride + own_slot] = cd_out[q];
+            if (DUMP) {
+                if (owner) {
+                    const int *w = wtab + q * 6 * TABCAP;
+                    const unsigned nb = cur_A.y >> CELL_NEG_SHIFT;
+                    const unsigned di = w[a + (nb & 1u) * TABCAP], dj = w[2 * TABCAP + b + ((nb >> 1) & 1u) * TABCAP];
+                    const unsigned dk = w[4 * TABCAP + c + ((nb >> 2) & 1u) * TABCAP];
+                    p.dump[(di * N + dj) * N + dk] = cd_out[q];
+                }
+            }
+            const bool ok = owner && cdi <= maxcd && (NSRC == 1 || have[q]);
+            rated[q] = ok && !ASORA_ABLATED(2);
+            n_gamma += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ok));
+            vol_nhi[q] = volfac * nHI;
+            dst_idx[q] = cur_idx[q];
+        }
         }
 
         if (__builtin_amdgcn_readfirstlane(cur_A.y) & CELL_LAST) {   // shell finished: publish it
@@ -466,87 +527,112 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
 
         // ---- rates, raytracing.cu:315-328 + rates.cu:16-41 ---------------------------------------
         if (grey) {
-            add_phi(rated, dst_idx, grey_rate_per_atom(flux, cd_in, cd_out, vol_nhi, p));
+#pragma unroll
+            for (int q = 0; q < NSRC; ++q)
+                add_phi(rated[q], dst_idx[q], grey_rate_per_atom(flux[q], cd_in[q], cd_out[q], vol_nhi[q], p));
         } else if (wave_has_work || ASORA_SKIP_EMPTY_WAVES == 2) {
             // (lanes without a rate run the lookups on whatever they hold: the index is clamped for any input)
-            const double tau_in = mul_unfused(cd_in, sig), tau_out = mul_unfused(cd_out, sig);   // un-fused, see rate_issue
             // TAU_PHOTO_LIMIT: rates.cu:7 (double 1e-7) or photorates.f90:69 (single 1e-7 promoted)
             const double limit = p.fortran_consts ? (double)1.0e-7f : 1.0e-7;
-            const double dtau = tau_out - tau_in;
-            const bool thick = fabs(dtau) > limit;
-            // one code path for both kinds of cell: per-lane table offset and arguments.  A thin cell looks its tau_thin up
-            // twice: tau_in with the Fortran's constants (photorates.f90:121), tau_out with the CUDA library's (rates.cu:37)
             const double2 *tab = p.tables;
-            const int toff = thick ? 0 : p.table_len;
-            const double arg_A = (thick || p.fortran_consts) ? tau_in : tau_out;
-            const double arg_B = (thick || !p.fortran_consts) ? tau_out : tau_in;
+            bool thick[NSRC];
+            double dtau[NSRC], arg_A[NSRC], arg_B[NSRC];
+            int toff[NSRC];
+#pragma unroll
+            for (int q = 0; q < NSRC; ++q) {
+                const double tau_in = mul_unfused(cd_in[q], sig), tau_out = mul_unfused(cd_out[q], sig);   // un-fused, see rate_issue
+                dtau[q] = tau_out - tau_in;
+                thick[q] = fabs(dtau[q]) > limit;
+                // one code path for both kinds of cell: per-lane table offset and arguments.  A thin cell looks its tau_thin up
+                // twice: tau_in with the Fortran's constants (photorates.f90:121), tau_out with the CUDA library's (rates.cu:37)
+                toff[q] = thick[q] ? 0 : p.table_len;
+                arg_A[q] = (thick[q] || p.fortran_consts) ? tau_in : tau_out;
+                arg_B[q] = (thick[q] || !p.fortran_consts) ? tau_out : tau_in;
+            }
 #if ASORA_LATE_LOOKUP
             // SKIP_ZERO (ASORA_OPT_SKIP_ZERO_RATES): a thick cell whose tau_in lies beyond the last table entry gets
             // pref * (T_last - T_last) = exactly +0; adding it changes nothing, so the atomic is not issued -- and when no
             // lane of the wave has anything to add, neither are the division, the logarithms and the lookups.  (pref must
             // be finite for the product to be 0 and not NaN: vol_nhi is checked instead of forming pref first.)  A kernel
             // variant of its own: the test and the branch cost 4.5 % where nothing can be left out.
-            bool add = rated;
+            bool add[NSRC];
             bool wave_adds = true;
+#pragma unroll
+            for (int q = 0; q < NSRC; ++q) add[q] = rated[q];
             if (SKIP_ZERO) {
-                const bool zero_rate = thick && tau_in >= p.tau_zero && fabs(vol_nhi) > 1e-250 && (vol_nhi - vol_nhi == 0.0);
-                add = rated && !zero_rate;
-                wave_adds = __builtin_amdgcn_readfirstlane((int)__any(add)) != 0;
+                const double tau_in0 = mul_unfused(cd_in[0], sig);
+                const bool zero_rate = thick[0] && tau_in0 >= p.tau_zero && fabs(vol_nhi[0]) > 1e-250 && (vol_nhi[0] - vol_nhi[0] == 0.0);
+                add[0] = rated[0] && !zero_rate;
+                wave_adds = __builtin_amdgcn_readfirstlane((int)__any(add[0])) != 0;
             }
-            {   // the previous step's lookups have had a whole step to arrive: form its rate now, issue this step's
-                // lookups, then add the rate behind them
-                const double ta = lookup_value(pend_A), tb = lookup_value(pend_B);
-                const double v_prev = pend_thick ? pend_pref * (ta - tb) : pend_pref * pend_dtau * ta;
-                double h_prev = 0.0;
-                if (HEAT) {
-                    const double ha = lookup_heat(pend_A), hb = lookup_heat(pend_B);
-                    h_prev = pend_thick ? pend_pref * (ha - hb) : pend_pref * pend_dtau * ha;
+            {   // the previous step's lookups have had a whole step to arrive: form its rates now, issue this step's
+                // lookups, then add the rates behind them
+                double v_prev[NSRC], h_prev[NSRC], pref[NSRC];
+                Lookup A2[NSRC], B2[NSRC];
+#pragma unroll
+                for (int q = 0; q < NSRC; ++q) {
+                    const double ta = lookup_value(pend_A[q]), tb = lookup_value(pend_B[q]);
+                    v_prev[q] = pend_thick[q] ? pend_pref[q] * (ta - tb) : pend_pref[q] * pend_dtau[q] * ta;
+                    h_prev[q] = 0.0;
+                    if (HEAT) {
+                        const double ha = lookup_heat(pend_A[q]), hb = lookup_heat(pend_B[q]);
+                        h_prev[q] = pend_thick[q] ? pend_pref[q] * (ha - hb) : pend_pref[q] * pend_dtau[q] * ha;
+                    }
+                    A2[q] = pend_A[q]; B2[q] = pend_B[q];
+                    pref[q] = 0.0;
                 }
-                Lookup A2 = pend_A, B2 = pend_B;
-                double pref = 0.0;
                 if (wave_adds) {
+#pragma unroll
+                    for (int q = 0; q < NSRC; ++q) {
 #ifdef ASORA_DIAG_NO_DIVISION
-                    pref = flux * __builtin_amdgcn_rcp(vol_nhi);
+                        pref[q] = flux[q] * __builtin_amdgcn_rcp(vol_nhi[q]);
 #else
-                    // (nHI = 0 -- a fully ionised or empty cell: the reference divides by zero; flux / +0 = flux * inf)
-                    pref = vol_nhi == 0.0 ? flux * INFINITY : ASORA_DIV(flux, vol_nhi);
+                        // (nHI = 0 -- a fully ionised or empty cell: the reference divides by zero; flux / +0 = flux * inf)
+                        pref[q] = vol_nhi[q] == 0.0 ? flux[q] * INFINITY : ASORA_DIV(flux[q], vol_nhi[q]);
 #endif
-                    A2 = lookup_issue<HEAT>(tab, arg_A, p, logtab, toff);
-                    B2 = lookup_issue<HEAT>(tab, arg_B, p, logtab, toff);
+                        A2[q] = lookup_issue<HEAT>(tab, arg_A[q], p, logtab, toff[q]);
+                        B2[q] = lookup_issue<HEAT>(tab, arg_B[q], p, logtab, toff[q]);
+                    }
                 }
-                add_phi(late_ok, late_idx, v_prev);
-                if (HEAT) add_heat(late_ok, late_idx, h_prev);
-                pend_A = A2; pend_B = B2; pend_thick = thick; pend_pref = pref; pend_dtau = dtau;
-                late_idx = dst_idx;
-                late_ok = add;
+#pragma unroll
+                for (int q = 0; q < NSRC; ++q) {
+                    add_phi(late_ok[q], late_idx[q], v_prev[q]);
+                    if (HEAT) add_heat(late_ok[q], late_idx[q], h_prev[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < NSRC; ++q) {
+                    pend_A[q] = A2[q]; pend_B[q] = B2[q]; pend_thick[q] = thick[q]; pend_pref[q] = pref[q]; pend_dtau[q] = dtau[q];
+                    late_idx[q] = dst_idx[q];
+                    late_ok[q] = add[q];
+                }
             }
 #elif ASORA_LATE_ATOMIC
-            const double pref = flux / vol_nhi;
-            const Lookup A = lookup_issue<HEAT>(tab, arg_A, p, logtab, toff);
-            const Lookup B = lookup_issue<HEAT>(tab, arg_B, p, logtab, toff);
+            const double pref = flux[0] / vol_nhi[0];
+            const Lookup A = lookup_issue<HEAT>(tab, arg_A[0], p, logtab, toff[0]);
+            const Lookup B = lookup_issue<HEAT>(tab, arg_B[0], p, logtab, toff[0]);
             // the previous step's rate, behind this step's lookups in the memory pipeline
-            add_phi(late_ok, late_idx, late_v);
-            if (HEAT) add_heat(late_ok, late_idx, late_h);
+            add_phi(late_ok[0], late_idx[0], late_v[0]);
+            if (HEAT) add_heat(late_ok[0], late_idx[0], late_h[0]);
             {
                 const double ta = lookup_value(A), tb = lookup_value(B);
-                late_v = thick ? pref * (ta - tb) : pref * dtau * ta;     // see rate_value on the form of the difference
+                late_v[0] = thick[0] ? pref * (ta - tb) : pref * dtau[0] * ta;     // see rate_value on the form of the difference
                 if (HEAT) {      // photorates.f90:118,124 with the same table index and residual
                     const double ha = lookup_heat(A), hb = lookup_heat(B);
-                    late_h = thick ? pref * (ha - hb) : pref * dtau * ha;
+                    late_h[0] = thick[0] ? pref * (ha - hb) : pref * dtau[0] * ha;
                 }
-                late_idx = dst_idx;
-                late_ok = rated;
+                late_idx[0] = dst_idx[0];
+                late_ok[0] = rated[0];
             }
 #else
-            const double pref = flux / vol_nhi;
-            const Lookup A = lookup_issue<HEAT>(tab, arg_A, p, logtab, toff);
-            const Lookup B = lookup_issue<HEAT>(tab, arg_B, p, logtab, toff);
+            const double pref = flux[0] / vol_nhi[0];
+            const Lookup A = lookup_issue<HEAT>(tab, arg_A[0], p, logtab, toff[0]);
+            const Lookup B = lookup_issue<HEAT>(tab, arg_B[0], p, logtab, toff[0]);
             {
                 const double ta = lookup_value(A), tb = lookup_value(B);
-                add_phi(rated, dst_idx, thick ? pref * (ta - tb) : pref * dtau * ta);
+                add_phi(rated[0], dst_idx[0], thick[0] ? pref * (ta - tb) : pref * dtau[0] * ta);
                 if (HEAT) {      // photorates.f90:118,124 with the same table index and residual
                     const double ha = lookup_heat(A), hb = lookup_heat(B);
-                    add_heat(rated, dst_idx, thick ? pref * (ha - hb) : pref * dtau * ha);
+                    add_heat(rated[0], dst_idx[0], thick[0] ? pref * (ha - hb) : pref * dtau[0] * ha);
                 }
             }
 #endif
@@ -557,8 +643,13 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
     uint4 A0 = cellA[e], B0 = cellB[e];
     uint4 A1 = cellA[e + RT_THREADS], B1 = cellB[e + RT_THREADS];
     uint4 A2, B2;
-    unsigned idx0, idx1 = 0, idx2 = 0;
-    double nhi0 = *nhi_address(A0.x, A0.y, idx0), nhi1 = 0.0, nhi2 = 0.0;
+    unsigned idx0[NSRC], idx1[NSRC], idx2[NSRC];
+    double nhi0[NSRC], nhi1[NSRC], nhi2[NSRC];
+#pragma unroll
+    for (int q = 0; q < NSRC; ++q) {
+        idx1[q] = idx2[q] = 0; nhi1[q] = nhi2[q] = 0.0;
+        nhi0[q] = *nhi_address(q, A0.x, A0.y, idx0[q]);
+    }
 #if ASORA_LATE_LOOKUP && ASORA_PRIME_PIPELINE
     // The loop is entered with the loads in flight that a step leaves behind, in the same order (tables, nHI, two lookups):
     // the compiler merges the counts of outstanding operations of the loop entry with those of the back edge and waits as
@@ -567,14 +658,21 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
     if (!GREY) {
         __builtin_amdgcn_sched_barrier(0);          // behind the nHI load, as in a step
         const double2 *__restrict__ prime = p.tables + (threadIdx.x & 1);
-        pend_A.t = prime[0];
-        if (HEAT) pend_A.h = prime[2 * p.table_len];
-        pend_B.t = prime[p.table_len];
-        if (HEAT) pend_B.h = prime[3 * p.table_len - 1];
-        if (BUFATOM) {                              // ... and the (dropped) atomic that follows them
+#pragma unroll
+        for (int q = 0; q < NSRC; ++q) {
+            // (distinct addresses, or the loads would be merged; a further source's come from the 128-entry log table)
+            pend_A[q].t = q == 0 ? prime[0] : p.logtab[(threadIdx.x & 1) + 4 * q];
+            if (HEAT) pend_A[q].h = prime[2 * p.table_len];
+            pend_B[q].t = q == 0 ? prime[p.table_len] : p.logtab[(threadIdx.x & 1) + 4 * q + 2];
+            if (HEAT) pend_B[q].h = prime[3 * p.table_len - 1];
+        }
+        if (BUFATOM) {                              // ... and the (dropped) atomics that follow them
             __builtin_amdgcn_sched_barrier(0);
-            (void)asora_buffer_atomic_fadd_f64(0.0, rs_phi, ASORA_OOB_OFFSET, 0, 0);
-            if (HEAT) (void)asora_buffer_atomic_fadd_f64(0.0, rs_heat, ASORA_OOB_OFFSET, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NSRC; ++q) {
+                (void)asora_buffer_atomic_fadd_f64(0.0, rs_phi, ASORA_OOB_OFFSET, 0, 0);
+                if (HEAT) (void)asora_buffer_atomic_fadd_f64(0.0, rs_heat, ASORA_OOB_OFFSET, 0, 0);
+            }
         }
     }
 #endif
@@ -586,19 +684,20 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? ASORA_MIN_WAV
         step(e + 3 * RT_THREADS, A1, B1, nhi1, idx1, A2, nhi2, idx2, A0, B0);
         step(e + 4 * RT_THREADS, A2, B2, nhi2, idx2, A0, nhi0, idx0, A1, B1);
     }
+#pragma unroll
+    for (int q = 0; q < NSRC; ++q) {
 #if ASORA_LATE_LOOKUP
-    {
-        const double ta = lookup_value(pend_A), tb = lookup_value(pend_B);
-        add_phi(late_ok, late_idx, pend_thick ? pend_pref * (ta - tb) : pend_pref * pend_dtau * ta);
+        const double ta = lookup_value(pend_A[q]), tb = lookup_value(pend_B[q]);
+        add_phi(late_ok[q], late_idx[q], pend_thick[q] ? pend_pref[q] * (ta - tb) : pend_pref[q] * pend_dtau[q] * ta);
         if (HEAT) {
-            const double ha = lookup_heat(pend_A), hb = lookup_heat(pend_B);
-            add_heat(late_ok, late_idx, pend_thick ? pend_pref * (ha - hb) : pend_pref * pend_dtau * ha);
+            const double ha = lookup_heat(pend_A[q]), hb = lookup_heat(pend_B[q]);
+            add_heat(late_ok[q], late_idx[q], pend_thick[q] ? pend_pref[q] * (ha - hb) : pend_pref[q] * pend_dtau[q] * ha);
         }
-    }
 #else
-    add_phi(late_ok, late_idx, late_v);
-    if (HEAT) add_heat(late_ok, late_idx, late_h);
+        add_phi(late_ok[q], late_idx[q], late_v[q]);
+        if (HEAT) add_heat(late_ok[q], late_idx[q], late_h[q]);
 #endif
+    }
 
     // work accounting: one atomic per wave and counter
     if ((threadIdx.x & 63) == 0) {
@@ -652,16 +751,17 @@ inline bool inside_radius_reference(int a, int b, int c, double dr, double R2)
 //   face =  0 : the x-sector = the di = s cells plus the planes {|di| = |dk|} (z-sector) and {|di| = |dj|}
 //               (y-sector) they read (each of which only reads itself and the main diagonal, which is in
 //               {|di| = |dk|}).
-//   merge_axis = 0 or 2 : the unit covers BOTH signs of that axis (two mirrored sectors in one workgroup, the
-//               plane between them evaluated once), so that its rows along that axis -- the memory-contiguous
-//               one for the unit's faces -- are full chords of the sphere: fewer 64-B atomic requests per cell.
+//   merge_mask bit ax : the unit covers BOTH signs of axis ax (mirrored octants / sectors in one workgroup, the plane
+//               between them evaluated once), so that its rows along that axis -- when it is the memory-contiguous one for
+//               a face -- are full chords of the sphere: fewer 64-B atomic requests per cell; and fewer, larger shells:
+//               fewer lanes of padding.  All three axes merged: the whole sphere in one workgroup, nothing evaluated twice.
 // A cell is RATED by its home unit only (its own face's sector); the copies a sector keeps of another
 // sector's plane are evaluated for their column density but not rated.
 struct UnitSpec {
     int face = -1;
-    int merge_axis = -1;
+    int merge_mask = 0;       // bit ax: the unit covers BOTH signs of axis ax (its own side + the mirrored one)
     int ext[3] = {0, 0, 0};   // periodic-window extent of each axis on the side this unit looks at
-    int ext_neg = 0;          // extent on the mirrored side of merge_axis
+    int ext_neg = 0;          // extent on the mirrored side of a merged axis
     int wedge = -1;           // 0..3: a quarter of the sector (restrict_to_wedge), -1: the whole unit
 };
 
@@ -671,7 +771,7 @@ void build_unit_geometry(HostGeom &h, const UnitSpec &us, double R, double dr, i
     const double R2 = R * R;
     const double R2hi = R2 * (1.0 + 1e-9) + 1e-9;
     int Emax = std::max(us.ext[0], std::max(us.ext[1], us.ext[2]));
-    if (us.merge_axis >= 0) Emax = std::max(Emax, us.ext_neg);
+    if (us.merge_mask) Emax = std::max(Emax, us.ext_neg);
     int S = Emax;
     if (std::isfinite(R2hi)) S = (int)std::min((double)Emax, std::floor(std::sqrt(R2hi)));
     h.S = S;
@@ -743,10 +843,11 @@ void build_unit_geometry(HostGeom &h, const UnitSpec &us, double R, double dr, i
             const double path = std::sqrt((u * u + v * v) / (sd * sd) + 1.0);  // raytracing.cu:444
             uint64_t pbits;
             std::memcpy(&pbits, &path, sizeof pbits);
-            const bool neg = us.merge_axis >= 0 && x[us.merge_axis] < 0;
+            uint32_t negbits = 0;
+            for (int ax = 0; ax < 3; ++ax) if (((us.merge_mask >> ax) & 1) && x[ax] < 0) negbits |= 1u << ax;
             uint4 ca;
             ca.x = (uint32_t)a | ((uint32_t)b << 10) | ((uint32_t)c << 20) | ((uint32_t)face << 30);
-            ca.y = count | CELL_VALID | (rate ? CELL_RATE : 0u) | (neg ? CELL_NEG : 0u) |
+            ca.y = count | CELL_VALID | (rate ? CELL_RATE : 0u) | (negbits << CELL_NEG_SHIFT) |
                    (((a == 0 ? 1u : 0u) | (b == 0 ? 2u : 0u) | (c == 0 ? 4u : 0u)) << CELL_ZERO_SHIFT);
             ca.z = (uint32_t)(pbits & 0xffffffffu);
             ca.w = (uint32_t)(pbits >> 32);
@@ -755,7 +856,7 @@ void build_unit_geometry(HostGeom &h, const UnitSpec &us, double R, double dr, i
             slot_cur[key_of(x)] = count++;
         };
         // signed range of a transverse axis whose magnitude may reach `maxmag`
-        auto lo_of = [&](int axis, int maxmag) { return us.merge_axis == axis ? -std::min(maxmag, us.ext_neg) : 0; };
+        auto lo_of = [&](int axis, int maxmag) { return ((us.merge_mask >> axis) & 1) ? -std::min(maxmag, us.ext_neg) : 0; };
         auto hi_of = [&](int axis, int maxmag) { return std::min(maxmag, us.ext[axis]); };
         for (int face = 2; face >= 0; --face) {
             if (us.face == 2 && face != 2) continue;          // the z-sector holds z-face cells only
@@ -767,7 +868,7 @@ void build_unit_geometry(HostGeom &h, const UnitSpec &us, double R, double dr, i
             const int max_fast = (face == 2) ? s : s - 1;                     // y/x-face: |dk| < s
             const int max_slow = (face == 0) ? s - 1 : s;                     // x-face: |dj| < s
             for (int dsgn = 1; dsgn >= -1; dsgn -= 2) {
-                if (dsgn < 0 && us.merge_axis != d) break;
+                if (dsgn < 0 && !((us.merge_mask >> d) & 1)) break;
                 const int ext_d = dsgn > 0 ? us.ext[d] : us.ext_neg;
                 if (s > ext_d) continue;
                 for (int sl = lo_of(slow, max_slow); sl <= hi_of(slow, max_slow); ++sl)
@@ -843,7 +944,7 @@ HostGeom restrict_to_wedge(const HostGeom &full, int wedge, int RT_THREADS, uint
         for (size_t q = 0; q < shells[si].size(); ++q) {
             if (!keep[si][q]) continue;
             Entry e = shells[si][q];
-            const uint32_t flags = e.a.y & (CELL_NEG | (7u << CELL_ZERO_SHIFT));
+            const uint32_t flags = e.a.y & ((7u << CELL_NEG_SHIFT) | (7u << CELL_ZERO_SHIFT));
             e.a.y = count | CELL_VALID | flags | (in_wedge(e.a) ? CELL_RATE : 0u);
             if (si > 0) {       // corners of shell 1 point into shell 0 (the source cell, slot 0): unchanged
                 auto remap = [&](uint32_t slot) -> uint32_t {
@@ -930,6 +1031,10 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
     //    4: unit = q, two whole octants mirrored in x  (q = sign bits of (y,z))
     //   12: unit = sector*4 + q, two mirrored sectors  (z-sector mirrored in x: q = sign bits of (y,z);
     //                                                   y- and x-sector mirrored in z: q = sign bits of (x,y))
+    //    1: the whole sphere                           (all three axes merged: no cell is evaluated twice, every row a full chord)
+    //    2: unit = sign of y, a half sphere            (x and z merged: the rows of every face are full chords)
+    //    3: unit = sector, all signs                   (a third of the LDS of the whole sphere)
+    //    6: unit = sector*2 + sign of the dominant offset, both transverse axes merged
     // Units with the same sector and the same periodic window share one table; when the sphere does not reach
     // the window on any axis all of a sector's units are identical.
     const double R2hi_all = p.R * p.R * (1.0 + 1e-9) + 1e-9;
@@ -943,34 +1048,48 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
         if (units == 96) {
             us.wedge = u / 24;
             us.face = (u % 24) >> 3;
-            us.merge_axis = -1;
+            us.merge_mask = 0;
             for (int ax = 0; ax < 3; ++ax) neg[ax] = ((u & 7) >> ax) & 1;
         } else if (units == 4) {                      // two whole octants mirrored in x: q = sign bits of (y,z)
             us.face = -1;
-            us.merge_axis = 0;
+            us.merge_mask = 1;
             neg[1] = u & 1; neg[2] = (u >> 1) & 1;
         } else if (units == 12) {
             us.face = u >> 2;
-            us.merge_axis = us.face == 2 ? 0 : 2;
+            us.merge_mask = us.face == 2 ? 1 : 4;
             const int q = u & 3;
             if (us.face == 2) { neg[1] = q & 1; neg[2] = (q >> 1) & 1; }
             else              { neg[0] = q & 1; neg[1] = (q >> 1) & 1; }
+        } else if (units == 1) {
+            us.face = -1;
+            us.merge_mask = 7;
+        } else if (units == 2) {
+            us.face = -1;
+            us.merge_mask = 5;
+            neg[1] = u & 1;
+        } else if (units == 3) {
+            us.face = u;
+            us.merge_mask = 7;
+        } else if (units == 6) {                      // a sector with both signs of its two transverse axes: unit = sector*2 + sign of the dominant offset
+            us.face = u >> 1;
+            us.merge_mask = 7 & ~(1 << us.face);      // (face code = dominant axis: 0 x, 1 y, 2 z)
+            neg[us.face] = u & 1;
         } else {
             us.face = units == 24 ? (u >> 3) : -1;
-            us.merge_axis = -1;
+            us.merge_mask = 0;
             for (int ax = 0; ax < 3; ++ax) neg[ax] = ((u & 7) >> ax) & 1;
         }
         for (int ax = 0; ax < 3; ++ax) us.ext[ax] = neg[ax] ? ext_neg : ext_pos;
         us.ext_neg = ext_neg;
         // exactly one unit rates the source cell: the all-positive one (of the z-sector when there are sectors)
         const bool rates_source = !neg[0] && !neg[1] && !neg[2] && (us.face == -1 || us.face == 2) && us.wedge <= 0;
-        info[u] = neg[0] | (neg[1] << 1) | (neg[2] << 2) | ((us.merge_axis + 1) << 3) | (rates_source ? 32 : 0);
+        info[u] = neg[0] | (neg[1] << 1) | (neg[2] << 2) | (us.merge_mask << 3) | (rates_source ? 64 : 0);
     }
     int owner[MAX_UNITS];
     for (int u = 0; u < units; ++u) {
         owner[u] = u;
         for (int u2 = 0; u2 < u; ++u2) {
-            if (spec[u2].face != spec[u].face || spec[u2].merge_axis != spec[u].merge_axis || spec[u2].wedge != spec[u].wedge) continue;
+            if (spec[u2].face != spec[u].face || spec[u2].merge_mask != spec[u].merge_mask || spec[u2].wedge != spec[u].wedge) continue;
             if (unclipped || (spec[u].ext[0] == spec[u2].ext[0] && spec[u].ext[1] == spec[u2].ext[1] &&
                               spec[u].ext[2] == spec[u2].ext[2])) {
                 owner[u] = owner[u2];
@@ -1232,13 +1351,21 @@ int launch_transpose(State &st, const double *src, double *dst, int N)
 static const size_t LDS_LIMIT_BYTES = 160 * 1024;
 
 // Decomposition and workgroup size.  Shells of a small trace do not fill 256 lanes (R=16: <= 310 cells per
-// octant shell); a large one needs so much LDS per octant that few workgroups fit a CU.  From about R = 20 on,
-// one workgroup per pair of mirrored sectors wins: its rows are full chords of the sphere, which lowers the
-// number of 64-B atomic requests per rated cell by ~15 %.
-// Thresholds from sweeps on MI355X (1000 sources, 256^3; tools/sweep_threads.sh, re-done once the work counters no longer
-// serialised the launch: profiles/r02_ab_work_counters.txt):
-//   R <= 12: octant pairs x 64 threads | 13..14: octant pairs x 128 | 15..19: octants x 64 | 20..22: sector pairs x 64 |
-//   23..28: octant pairs x 256 | 29..35: sector pairs x 128 | 36..54: x 256 | >= 55: x 512
+// octant shell); a large one needs so much LDS per octant that few workgroups fit a CU.  Three things pull:
+//   * padding: every shell of every unit is padded to whole waves, so FEWER, LARGER units waste fewer lanes (R = 16:
+//     1.41 lane-steps per rated cell with 8 octants, 1.04 with the whole sphere in one workgroup; R = 32: 1.17 with 12
+//     sector pairs, 1.10 with 6 sectors whose transverse axes are both mirrored), and units that cover both signs of an
+//     axis do not evaluate the plane between them twice;
+//   * the rate atomics want long contiguous rows: units that mirror the memory-contiguous axis of a face sweep full
+//     chords of the sphere (~15 % fewer 64-B atomic requests per rated cell than octants);
+//   * LDS: a unit's two shell buffers must leave room for enough workgroups per CU, which is what stops the merging --
+//     the whole sphere needs 39 KB at R = 16 and 157 KB at R = 32.
+// Thresholds from sweeps on MI355X (1000 sources, 256^3; tools/sweep_units.sh, profiles/r03_sweep_units_run*.txt):
+//   R < 11.5: whole sphere x 128 threads | < 15.5: x 256 | < 21.5: x 512 | < 23.5: half spheres x 256 | < 25.5: x 512 |
+//   < 36.5: 6 sectors by sign of the dominant offset x 256 | < 52.5: 12 mirrored sector pairs x 256 | else x 512
+// (round 2, without the merged kinds: R <= 12 octant pairs x 64 | 13..14 x 128 | 15..19 octants x 64 | 20..22 sector pairs
+//  x 64 | 23..28 octant pairs x 256 | 29..35 sector pairs x 128 | 36..54 x 256 | >= 55 x 512 -- still what is used when the
+//  merged kinds would leave CUs without a workgroup)
 static void pick_launch_shape(const State &st, double R, int N, int src_count, bool dump, int &units, int &threads)
 {
     const double r = std::min(R, 0.87 * N);                 // the window cuts the trace at ~sqrt(3)/2 N
@@ -1251,6 +1378,17 @@ static void pick_launch_shape(const State &st, double R, int N, int src_count, b
     else if (est_cells <= 1500.0) { units = 12; threads = 128; }     // r <= 35.3
     else if (est_cells <= 3500.0) { units = 12; threads = 256; }     // r <= 54
     else { units = 12; threads = 512; }
+    {   // the merged kinds, when they still give every CU a couple of workgroups
+        int mu = 0, mt = 0;
+        if (r < 11.5) { mu = 1; mt = 128; }
+        else if (r < 15.5) { mu = 1; mt = 256; }
+        else if (r < 21.5) { mu = 1; mt = 512; }
+        else if (r < 23.5) { mu = 2; mt = 256; }
+        else if (r < 25.5) { mu = 2; mt = 512; }
+        else if (r < 36.5) { mu = 6; mt = 256; }
+        else if (r < 52.5) { mu = 12; mt = 256; }
+        if (mu && (long)src_count * mu >= 2L * st.cu_count && !dump) { units = mu; threads = mt; }
+    }
     // Few sources (fewer workgroups than CUs): the time of the call is the time of ONE workgroup, so cut a source
     // into more (24 sectors) and wider pieces.  One source, 128^3, R = 64: 0.235 -> 0.146 ms (tools/sweep_single_source.sh)
     // A few dozen sources (workgroups for half the CUs' slots at most): still one round, wider workgroups finish it sooner
@@ -1275,12 +1413,40 @@ static void pick_launch_shape(const State &st, double R, int N, int src_count, b
     if (want_sectors == 3) units = 12;
     if (want_sectors == 4) units = 96;
     if (want_sectors == 5) units = 4;
+    if (want_sectors == 6) units = 1;
+    if (want_sectors == 7) units = 2;
+    if (want_sectors == 8) units = 3;
+    if (want_sectors == 9) units = 6;
     const int forced = st.opt[ASORA_OPT_BLOCK_THREADS];
     if (forced == 64 || forced == 128 || forced == 256 || forced == 512 || forced == 1024) threads = forced;
     if (dump) threads = 256;                                // the column-density dump variant is built for 256 only
 }
 
-constexpr size_t lds_table_bytes(int tabcap) { return LOG_TABLE_SIZE * sizeof(double2) + (size_t)tabcap * (sizeof(double) + 4 * sizeof(int)); }
+// Does sweeping two sources per workgroup pay?  (auto mode of ASORA_OPT_PAIR_SOURCES; from A/B runs on MI355X, 1000 sources,
+// 256^3: profiles/r03_ab_two_sources.txt -- R = 16 -4 %, 20 -2 %, 26 -10 %, 28 -12 %, 32 -7 %, 40 -8 %, 48 -5 %, 56 and 64 0 %;
+// nothing below R ~ 15, where the whole sphere is swept by few waves)
+static bool pair_sources_pays(const State &st, double R, int N, int src_count, int units, int threads)
+{
+    const double r = std::min(R, 0.87 * N);
+    if (!(r >= 15.5 && r < 52.5)) return false;
+    // enough waves must be left to fill the chip (two per SIMD)
+    return (long)(src_count / 2) * units * (threads / 64) >= 8L * st.cu_count;
+}
+
+constexpr size_t lds_table_bytes(int tabcap, int nsrc = 1) { return LOG_TABLE_SIZE * sizeof(double2) + (size_t)tabcap * (sizeof(double) + (size_t)nsrc * 6 * sizeof(int)); }
+
+// the paired-sources variant (NSRC = 2) exists for the production path only: table rates, no heating, no dump, shell
+// buffers in LDS, buffer atomics
+template <int T, int TABCAP>
+static int launch_variant_pairs(State &st, const RtParams &q, unsigned grid, size_t lds_bytes, hipStream_t stream)
+{
+    ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, false, TABCAP, false, false, true, 2>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, false, TABCAP, false, false, true, 2>), dim3(grid), dim3(T),
+                       lds_bytes, stream, q);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
 
 template <int T, int TABCAP>
 static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t lds_bytes, bool use_lds, bool dump, bool heat,
@@ -1337,9 +1503,25 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
     const bool big_tables = p.S + 1 > 256;
     const bool small_tables = p.S + 1 <= 64 && threads <= 128;
     if (p.S + 1 > 1024) return fail(4, "raytrace: more than 1023 shells (mesh too large for this build)");
-    const size_t fixed_bytes = lds_table_bytes(big_tables ? 1024 : small_tables ? 64 : 256);
-    const size_t shell_bytes = 2 * slots * sizeof(double);
+    size_t fixed_bytes = lds_table_bytes(big_tables ? 1024 : small_tables ? 64 : 256);
+    size_t shell_bytes = 2 * slots * sizeof(double);
     const bool use_lds = shell_bytes + fixed_bytes <= LDS_LIMIT_BYTES;
+    // Two sources per workgroup (see the kernel's NSRC): the variant exists for table rates without heating, column-density
+    // dump or exact-zero skipping, with the shell buffers in LDS and the rates through buffer atomics, for 64..512 threads
+    // and the two smaller LDS table capacities
+    bool pairs = false;
+    {
+        const int want = st.opt[ASORA_OPT_PAIR_SOURCES];
+        const bool possible = use_lds && !dump && !heat && !p.grey && !std::isfinite(p.tau_zero) && !big_tables && threads <= 512 &&
+                              16ull * p.ncell <= 0x80000000ull && !st.opt[ASORA_OPT_GLOBAL_ATOMICS] && p.src_count >= 2 &&
+                              2 * shell_bytes + lds_table_bytes((p.S + 1 <= 64 && threads <= 256) ? 64 : 256, 2) <= LDS_LIMIT_BYTES;
+        pairs = possible && (want == 2 || (want == 0 && pair_sources_pays(st, p.R, p.N, p.shape_src_count > 0 ? p.shape_src_count : p.src_count, units, threads)));
+    }
+    const bool pairs_small = p.S + 1 <= 64 && threads <= 256;      // the paired variant has the 64-entry tables for 256 threads too
+    if (pairs) {
+        fixed_bytes = lds_table_bytes(pairs_small ? 64 : 256, 2);
+        shell_bytes *= 2;
+    }
     size_t lds_bytes = (use_lds ? shell_bytes : 0) + fixed_bytes;
 #ifdef ASORA_ENABLE_ABLATION        // diagnostic builds only: unused LDS per workgroup, to lower the occupancy (ASORA_DIAG_EXTRA_LDS bytes)
     if (const char *e = getenv("ASORA_DIAG_EXTRA_LDS")) lds_bytes = std::min<size_t>(LDS_LIMIT_BYTES, lds_bytes + (size_t)atol(e));
@@ -1374,12 +1556,24 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
         q.src_begin = p.src_begin + done;
         q.src_count = batch;
         q.shell_scratch = use_lds ? nullptr : st.shell_scratch;
-        q.spread = (long)batch * units <= 2L * st.cu_count ? 1 : 0;      // few workgroups: spread a source's units over the XCDs
-        const unsigned grid = q.spread ? (unsigned)units * (unsigned)batch : 8u * (unsigned)units * (unsigned)((batch + 7) / 8);
+        const int groups = pairs ? (batch + 1) / 2 : batch;              // workgroups per unit
+        q.spread = (long)groups * units <= 2L * st.cu_count ? 1 : 0;     // few workgroups: spread a source's units over the XCDs
+        const unsigned grid = q.spread ? (unsigned)units * (unsigned)groups : 8u * (unsigned)units * (unsigned)((groups + 7) / 8);
         {
             KernelTimer kt(ASORA_KERNEL_RAYTRACE, stream);
             int rc = 0;
-            if (big_tables) {
+            if (pairs) {
+                if (pairs_small) {
+                    if (threads == 64)       rc = launch_variant_pairs<64, 64>(st, q, grid, lds_bytes, stream);
+                    else if (threads == 128) rc = launch_variant_pairs<128, 64>(st, q, grid, lds_bytes, stream);
+                    else                     rc = launch_variant_pairs<256, 64>(st, q, grid, lds_bytes, stream);
+                } else switch (threads) {
+                    case 64:  rc = launch_variant_pairs<64, 256>(st, q, grid, lds_bytes, stream); break;
+                    case 128: rc = launch_variant_pairs<128, 256>(st, q, grid, lds_bytes, stream); break;
+                    case 512: rc = launch_variant_pairs<512, 256>(st, q, grid, lds_bytes, stream); break;
+                    default:  rc = launch_variant_pairs<256, 256>(st, q, grid, lds_bytes, stream); break;
+                }
+            } else if (big_tables) {
                 if (threads == 1024)     rc = launch_variant<1024, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat, stream);
                 else if (threads == 512) rc = launch_variant<512, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat, stream);
                 else                rc = launch_variant<256, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat, stream);

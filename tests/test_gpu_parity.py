@@ -157,7 +157,7 @@ def test_decomposition_and_workgroup_size_do_not_change_results(asora, name, thr
     out = {}
     try:
         lib.set_option(capi.OPT_BLOCK_THREADS, threads)
-        for mode in (1, 2, 3, 4, 5):
+        for mode in (1, 2, 3, 4, 5, 6, 7, 8, 9):
             lib.set_option(capi.OPT_SECTORS, mode)
             phi = _asora_call(lib, c, N, numtau)
             np.testing.assert_allclose(phi, ref, rtol=GAMMA_RTOL, atol=0)
@@ -169,7 +169,11 @@ def test_decomposition_and_workgroup_size_do_not_change_results(asora, name, thr
     np.testing.assert_allclose(out[1][0], out[3][0], rtol=1e-12, atol=0)
     np.testing.assert_allclose(out[1][0], out[4][0], rtol=1e-12, atol=0)
     np.testing.assert_allclose(out[1][0], out[5][0], rtol=1e-12, atol=0)
-    assert out[1][1][0] == out[2][1][0] == out[3][1][0] == out[4][1][0] == out[5][1][0]    # rated pairs
+    for mode in (6, 7, 8, 9):                         # whole sphere, half spheres, all-sign sectors, sectors by dominant sign
+        np.testing.assert_allclose(out[1][0], out[mode][0], rtol=1e-12, atol=0)
+    assert len({out[mode][1][0] for mode in out}) == 1                                     # rated pairs
+    assert out[6][1][1] == out[6][1][0]               # the whole sphere in one workgroup: nothing is evaluated twice
+    assert out[6][1][1] <= out[7][1][1] <= out[5][1][1] <= out[1][1][1]
     assert out[2][1][1] >= out[1][1][1]               # evaluations (re-derived planes)
     assert out[4][1][1] >= out[2][1][1]               # quarter sectors re-derive the inner part of their sector
 
@@ -1104,6 +1108,69 @@ def test_leaving_out_exactly_zero_rates_changes_nothing(asora):
             np.testing.assert_allclose(out[0][w], ref[w], rtol=GAMMA_RTOL, atol=0)
         zeros = float((out[0] == 0).mean())
         assert (zeros > 0.5) if tau_cell == 3000.0 else (zeros < 0.5)
+
+
+def test_two_sources_per_workgroup_give_the_same_rates(asora):
+    """ASORA_OPT_PAIR_SOURCES: one workgroup sweeps its unit for two consecutive sources at once.  Sources whose spheres do
+    not overlap (no summation-order freedom) -> grids IDENTICAL to the one-source-per-workgroup kernel, for every
+    decomposition and workgroup size the paired variant exists for, for even and ODD source counts (the last workgroup then
+    carries a dummy second source whose rates must be dropped) and with the Fortran constants; overlapping sources against
+    the oracle; and the pair counts the library reports do not change."""
+    p, lib, capi = asora
+    N = 96
+    thin, thick, dlog = cases.soft_tables(400)
+    nd, xh, dr = cases.grid(N, "lognormal", 12, 0.4, xlo=1e-4, xhi=1e-2)
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 8)
+    p.photo_table_to_device(thin, thick)
+    lib.grid_to_device(capi.GRID_NDENS, nd)
+    lib.grid_to_device(capi.GRID_XH_AV, xh)
+    lattice = np.array([(i, j, k) for i in range(1, N, 12) for j in range(1, N, 12) for k in range(1, N, 12)]).T     # spacing 12 > 2 R
+    rng = np.random.RandomState(5)
+    pick = rng.permutation(lattice.shape[1])[:81]
+    pos = lattice[:, pick].copy()
+    pos[:, 0] = [1, 1, 1]                                       # a corner: the periodic wrap is in play
+    pos[:, 1] = [N, 37, 1]
+    flux = rng.uniform(1.0, 5.0, 81)
+    p0, f0 = cases.flat_sources(pos, flux)
+
+    def trace(R, n, pairs, **opts):
+        lib.source_data_to_device(p0[:3 * n], f0[:n], n)
+        lib.set_option(capi.OPT_PAIR_SOURCES, pairs)
+        for k, v in opts.items():
+            lib.set_option(getattr(capi, k), v)
+        try:
+            lib.raytrace_device(R, cases.SIG, dr, 0, n, cases.MINLOGTAU, dlog, thin.shape[0])
+            phi = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+            counts = lib.last_raytrace_counts()
+        finally:
+            lib.set_option(capi.OPT_PAIR_SOURCES, 0)
+            for k in opts:
+                lib.set_option(getattr(capi, k), 0)
+        return phi, counts
+
+    for R in (4.0, 5.5):
+        for n in (80, 81, 2, 3):
+            for opts in ({}, {"OPT_SECTORS": 1}, {"OPT_SECTORS": 2}, {"OPT_SECTORS": 3}, {"OPT_SECTORS": 5}, {"OPT_SECTORS": 6},
+                         {"OPT_SECTORS": 7, "OPT_BLOCK_THREADS": 256}, {"OPT_SECTORS": 8}, {"OPT_SECTORS": 9},
+                         {"OPT_SECTORS": 3, "OPT_BLOCK_THREADS": 128}, {"OPT_SECTORS": 3, "OPT_BLOCK_THREADS": 256},
+                         {"OPT_SECTORS": 1, "OPT_BLOCK_THREADS": 512}, {"OPT_FORTRAN_CONSTANTS": 1}):
+                one, c1 = trace(R, n, 1, **opts)
+                two, c2 = trace(R, n, 2, **opts)
+                assert np.array_equal(one, two), (R, n, opts)
+                assert c1[0] == c2[0] == n * int(((np.add.outer(np.add.outer(np.arange(-6, 7) ** 2, np.arange(-6, 7) ** 2),
+                                                                np.arange(-6, 7) ** 2)) <= R * R).sum())
+                assert one.max() > 0
+    # overlapping spheres (R = 9 > half the spacing) against the oracle, odd count
+    ref = O.asora_do_all_sources(9.0, cases.SIG, dr, nd, xh, p0, f0, thin, thick, cases.MINLOGTAU, dlog,
+                                 NumTau=thin.shape[0], flags=O.ASORA_MODE)["phi_ion"]
+    w = ref != 0
+    for mode in (1, 3, 5):
+        phi, _ = trace(9.0, 81, 2, OPT_SECTORS=mode)
+        assert np.array_equal(phi != 0, w)
+        np.testing.assert_allclose(phi[w], ref[w], rtol=GAMMA_RTOL, atol=0)
+    p.device_close()
 
 
 def test_buffer_and_global_rate_atomics_give_the_same_rates(asora):
