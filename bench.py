@@ -50,8 +50,8 @@ TEMPH0 = 13.598 / 8.617e-05                        # eth0*ev2k                  
 HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: 8 TB/s spec
 RT_BYTES_PER_UPDATE = 32                           # 8 ndens + 8 xh_av + 16 Gamma RMW
 CHEM_BYTES_PER_UPDATE = 56                         # 5 loads + 2 stores
-CHEM_FUSED_BYTES_PER_UPDATE = 96                   # the fused pass on a uniform-temperature grid (both workloads here): 5 loads
-                                                   # + 7 stores; 104 with a temperature grid that has to be read
+CHEM_FUSED_BYTES_PER_UPDATE = 88                   # the fused pass on a uniform-temperature grid (both workloads here): 5 loads
+                                                   # + 6 stores; 96 with a temperature grid that has to be read
 
 
 def make_tables():
@@ -561,7 +561,7 @@ def main():
              "bytes_moved_per_unit": CHEM_FUSED_BYTES_PER_UPDATE if comm is None else CHEM_BYTES_PER_UPDATE,
              "moved_GBs": ch_actual,
              "note": "the fused pass also folds the two rate accumulators, writes nHI in both layouts for the next raytrace and "
-                     "zeroes the accumulators: 96 B per cell move through HBM (uniform temperature: that grid is not read), of which 56 B are "
+                     "zeroes the accumulators: 88 B per cell move through HBM (uniform temperature: that grid is not read; the folded rates are not stored), of which 56 B are "
                      "the chemistry's own algorithmic traffic"},
         ],
         "kernels_ms_per_step": {

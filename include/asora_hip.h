@@ -215,8 +215,11 @@ int asora_chemistry_finish(int *conv_flag, double *sum_xh1, double *sum_xh0);
  *   asora_evolve_enqueue  enqueues `iterations` (1..32) outer iterations; asynchronous.
  *   asora_evolve_poll     waits for what was enqueued; returns the iterations carried out so far, whether the test has
  *                         passed, and one row {conv_flag, sum(xh_intermed), sum(1-xh_intermed), rel_change_xh1,
- *                         rel_change_xh0} per iteration not reported yet (at most history_rows rows).
- * Results: ASORA_GRID_XH_INTERMED (xh_new), ASORA_GRID_XH_AV, ASORA_GRID_PHI_ION. */
+ *                         rel_change_xh0} per iteration not reported yet (at most history_rows rows; history = NULL: the
+ *                         rows are given up).  At most 64 iterations may be enqueued between two polls.  The pass does
+ *                         not store the folded rates (the accumulators alternate between two pairs instead, so the last
+ *                         iteration's survive): the poll folds them into ASORA_GRID_PHI_ION, which is valid from then on.
+ * Results: ASORA_GRID_XH_INTERMED (xh_new), ASORA_GRID_XH_AV, and -- after a poll -- ASORA_GRID_PHI_ION. */
 int asora_evolve_begin(double dt, double bh00, double albpow, double colh0, double temph0, double abu_c,
                        double R, double sig, double dr, double minlogtau, double dlogtau, int NumTau,
                        int src_begin, int src_count, double conv_criterion, double convergence_fraction);

@@ -142,7 +142,7 @@ static int release_all()
     State &st = g_state;
     auto drop = [](auto *&ptr) { if (ptr) { (void)hipFree(ptr); ptr = nullptr; } };
     for (int g = 0; g < ASORA_GRID_COUNT; ++g) { drop(st.grid[g]); st.grid_valid[g] = false; }
-    drop(st.nhi); drop(st.staging); drop(st.acc); st.ev_acc_clean = false;
+    drop(st.nhi); drop(st.staging); drop(st.acc); st.ev_clean[0] = st.ev_clean[1] = false; st.ev_sets_known = false;
     st.ev_open = false;
     st.temp_probe_valid = false;
     st.nhi_t = st.phi_t = st.heat_t = nullptr;    // second halves of nhi / phi_ion / phi_heat
@@ -1238,10 +1238,17 @@ int asora_evolve_begin(double dt, double bh00, double albpow, double colh0, doub
 
     if (int rc = ensure_temp_probe(bh00, albpow, colh0, temph0)) return rc;
     const size_t bytes = st.ncell * sizeof(double);
-    // the accumulators are zeroed once: every fused pass leaves them zero behind it, iterations beyond convergence do
-    // not touch them, so they are zero again whenever a new time step begins
-    bool acc_is_zero = st.acc != nullptr;
-    if (!st.acc) ASORA_HIP_TRY(hipMalloc(&st.acc, 2 * bytes));
+    // two accumulator pairs (State::acc): the first trace needs a zeroed pair; every fused pass zeroes the pair the next
+    // trace adds into, iterations beyond convergence touch nothing
+    if (!st.acc) { ASORA_HIP_TRY(hipMalloc(&st.acc, 4 * bytes)); st.ev_sets_known = false; }
+    if (!st.ev_sets_known) {          // iterations were enqueued and never polled: which pair holds what is not known
+        ASORA_HIP_TRY(hipMemsetAsync(st.acc, 0, 4 * bytes, st.stream));                      // raytracing.cu:113
+        st.ev_clean[0] = st.ev_clean[1] = true;
+        st.ev_sets_known = true;
+    }
+    if (!st.ev_clean[0] && !st.ev_clean[1]) return fail(11, "evolve_begin: no clean accumulator pair (internal error)");
+    st.ev_base = st.ev_clean[0] ? 0 : 1;
+    st.ev_folded_iter = 0;
     if (!st.ev_status) {
         ASORA_HIP_TRY(hipMalloc(&st.ev_status, sizeof(EvolveStatus)));
         ASORA_HIP_TRY(hipHostMalloc(&st.ev_host, sizeof(EvolveStatus), hipHostMallocDefault));
@@ -1253,15 +1260,13 @@ int asora_evolve_begin(double dt, double bh00, double albpow, double colh0, doub
     st.ev_host->conv_criterion = conv_criterion;
     st.ev_host->conv_fraction = convergence_fraction;
     ASORA_HIP_TRY(hipMemcpyAsync(st.ev_status, st.ev_host, sizeof(EvolveStatus), hipMemcpyHostToDevice, st.stream));
-    if (!acc_is_zero || !st.ev_acc_clean) ASORA_HIP_TRY(hipMemsetAsync(st.acc, 0, 2 * bytes, st.stream));   // raytracing.cu:113
-    st.ev_acc_clean = true;
     ASORA_HIP_TRY(hipMemsetAsync(st.counters, 0, sizeof(unsigned long long) * 2 * COUNTER_SLOTS, st.stream));
     // xh_av = copy(xh) (evolve.py:136) is not materialised: nHI of the first trace is formed from xh and the first
     // chemistry pass takes xh as its starting xh_av; xh_intermed (evolve.py:137) is only ever written
     if (int rc = launch_prepare_nhi_from(st, st.grid[ASORA_GRID_XH], st.opt[ASORA_OPT_Z_TRANSPOSED] != 0)) return rc;
 
     fill_rt_params(st.ev_rt, R, sig, dr, minlogtau, dlogtau, NumTau);
-    st.ev_rt.phi = st.acc;
+    st.ev_rt.phi = st.acc + (size_t)st.ev_base * 2 * st.ncell;       // (each iteration sets its own pair, asora_evolve_enqueue)
     st.ev_rt.done_flag = &st.ev_status->done;
     st.ev_rt.src_begin = src_begin; st.ev_rt.src_count = src_count; st.ev_rt.shape_src_count = src_count;
     if (src_begin == 0 && src_count == st.num_src && st.src_pos_sorted) { st.ev_rt.src_pos = st.src_pos_sorted; st.ev_rt.src_flux = st.src_flux_sorted; }
@@ -1287,10 +1292,14 @@ int asora_evolve_enqueue(int iterations)
     if (st.ev_enqueued - st.ev_reported + iterations > EVOLVE_HIST)
         return fail(4, "evolve_enqueue: " + std::to_string(st.ev_enqueued - st.ev_reported) + " iterations enqueued since the last "
                            "asora_evolve_poll; the history ring holds " + std::to_string(EVOLVE_HIST) + " (poll first)");
+    st.ev_sets_known = false;                        // until the next poll tells how many of these were carried out
     for (int it = 0; it < iterations; ++it) {
+        // iteration k = ev_enqueued + it + 1 of the step (as long as the step has not converged: then nothing runs anyway)
+        const int set = (st.ev_base + st.ev_enqueued + it) & 1;
+        double *acc_cur = st.acc + (size_t)set * 2 * st.ncell, *acc_next = st.acc + (size_t)(set ^ 1) * 2 * st.ncell;
         if (st.ev_src_count > 0) {
             RtParams p = st.ev_rt;
-            st.ev_acc_clean = false;                 // until the fused pass behind this trace has been enqueued
+            p.phi = acc_cur;
             if (int rc = launch_raytrace(st, p, false, false)) return rc;
         }
         ChemTileParams c;
@@ -1299,7 +1308,12 @@ int asora_evolve_enqueue(int iterations)
         c.temph0 = st.ev_chem[4]; c.abu_c = st.ev_chem[5];
         c.ndens = st.grid[ASORA_GRID_NDENS]; c.temp = st.grid[ASORA_GRID_TEMP]; c.xh = st.grid[ASORA_GRID_XH];
         c.xh_av_in = st.ev_first ? st.grid[ASORA_GRID_XH] : st.grid[ASORA_GRID_XH_AV];
-        c.gamma = st.acc; c.gamma_t = st.acc + st.ncell; c.phi_out = st.grid[ASORA_GRID_PHI_ION];
+        c.gamma = acc_cur; c.gamma_t = acc_cur + st.ncell; c.phi_out = nullptr;
+        {   // A/B only (tools/ab_chem_store.sh): also store the folded rates every iteration, as round 2 did
+            static const bool store_always = getenv("ASORA_DIAG_STORE_PHI") != nullptr;
+            if (store_always) c.phi_out = st.grid[ASORA_GRID_PHI_ION];
+        }
+        c.zero_a = acc_next; c.zero_t = acc_next + st.ncell;
         c.xh_av = st.grid[ASORA_GRID_XH_AV]; c.xh_intermed = st.grid[ASORA_GRID_XH_INTERMED];
         c.nhi = st.nhi; c.nhi_t = st.nhi_t;
         c.red_partial = st.red_partial; c.red_final = st.red_final;
@@ -1307,11 +1321,11 @@ int asora_evolve_enqueue(int iterations)
         c.fold = true; c.emit = true;
         set_uniform_temperature(c);
         if (int rc = launch_chemistry_tiles(st, c, st.stream)) return rc;
-        st.ev_acc_clean = true;
         st.ev_first = false;
     }
     st.ev_enqueued += iterations;
-    st.grid_valid[ASORA_GRID_XH_AV] = st.grid_valid[ASORA_GRID_XH_INTERMED] = st.grid_valid[ASORA_GRID_PHI_ION] = true;
+    st.grid_valid[ASORA_GRID_XH_AV] = st.grid_valid[ASORA_GRID_XH_INTERMED] = true;
+    st.grid_valid[ASORA_GRID_PHI_ION] = false;       // until asora_evolve_poll folds the last iteration's accumulators
     return 0;
 }
 
@@ -1324,6 +1338,19 @@ int asora_evolve_poll(int *niter, int *converged, double *history, int history_r
     ASORA_HIP_TRY(hipMemcpyAsync(st.ev_host, st.ev_status, sizeof(EvolveStatus), hipMemcpyDeviceToHost, st.stream));
     ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
     const EvolveStatus &h = *st.ev_host;
+    // The rates of the last iteration carried out sit, unfolded, in its accumulator pair; the other pair is zero (the pass
+    // of that iteration zeroed it; iterations enqueued beyond convergence did nothing).  Fold them into PHI_ION now.
+    if (h.niter > 0) {
+        const int set = (st.ev_base + h.niter - 1) & 1;
+        if (st.ev_folded_iter != h.niter) {
+            const double *a = st.acc + (size_t)set * 2 * st.ncell;
+            if (int rc = launch_fold_sum(st, a, a + st.ncell, st.grid[ASORA_GRID_PHI_ION])) return rc;
+            st.ev_folded_iter = h.niter;
+        }
+        st.grid_valid[ASORA_GRID_PHI_ION] = true;
+        st.ev_clean[set] = false; st.ev_clean[set ^ 1] = true;
+    }
+    st.ev_sets_known = true;
     int rows = 0;
     for (int it = st.ev_reported; it < h.niter && history && rows < history_rows; ++it, ++rows)
         for (int q = 0; q < 5; ++q) history[5 * rows + q] = h.hist[it % EVOLVE_HIST][q];

@@ -113,7 +113,13 @@ struct State {
     int geom_units = 0;
     double2 *logtab_dev = nullptr;          // log2 table (ensure_logtab), lives until the runtime is torn down
     bool geom_valid = false;
-    bool geom_dr_matters = true;
+    // table entries of cells that sit (to rounding) exactly ON the sphere: whether such a cell gets a rate is decided by
+    // the reference's floating-point distance test, whose outcome depends on dr.  They are always tabulated (evaluated);
+    // their RATE bit is re-decided in place when dr changes (a cosmological run: every time step) -- no rebuild.
+    struct SphereCell { uint32_t *dev_word; uint32_t word_without_rate; int a, b, c; };
+    std::vector<SphereCell> geom_sphere;
+    void *geom_patch_dev = nullptr;         // staging for the patch kernel: {address, value} pairs
+    size_t geom_patch_cap = 0;
     int geom_N = 0, geom_S = 0, geom_max_cells = 0, geom_threads = 0;
     double geom_R = 0.0, geom_dr = 0.0;
 
@@ -149,11 +155,18 @@ struct State {
 
     // fused evolve loop (asora_evolve_*): raytrace accumulators of their own ([i][j][k] then [k][j][i]; the chemistry
     // kernel folds them into PHI_ION and zeroes them), device-side convergence bookkeeping
-    double *acc = nullptr;                  // 2 N^3, allocated on first use
+    // TWO sets of accumulators, each [i][j][k] then [k][j][i] (4 N^3 doubles, allocated on first use).  Iteration k of a
+    // time step traces into set (ev_base + k - 1) & 1; its fused pass reads that set WITHOUT destroying it and zeroes the
+    // other one for iteration k + 1.  The rates of the last iteration carried out therefore survive in their set until the
+    // host asks for them (asora_evolve_poll folds them into PHI_ION): the pass writes no rate grid (88 instead of 96 B per cell).
+    double *acc = nullptr;
+    int ev_base = 0;                        // set of the first iteration of the current time step
+    bool ev_clean[2] = {false, false};      // set known to be all zero (when nothing is enqueued)
+    bool ev_sets_known = false;             // the bookkeeping above is valid (a poll has happened since the last enqueue)
+    int ev_folded_iter = -1;                // PHI_ION holds the rates of this iteration of the current step (0: none yet)
     EvolveStatus *ev_status = nullptr;      // device
     EvolveStatus *ev_host = nullptr;        // pinned
     bool ev_open = false, ev_first = true;
-    bool ev_acc_clean = false;              // both accumulators are known to be zero
     // temperature probe of the TEMP grid: valid for the upload `temp_generation` and the constants in temp_consts
     double *temp_probe_dev = nullptr;       // [8] device: the probe's five results, [5] = asora_grid_sum's
     double temp_probe[5] = {0, 0, 0, 0, 0}; // host copy: uniform?, T, brech0, acolh0, t_ok
@@ -207,6 +220,7 @@ int launch_prepare_nhi(State &st, bool need_transposed);
 int launch_finish_phi(State &st);
 int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t side = nullptr);   // side: stream to launch on when no shared scratch is needed
 int launch_fold_transposed(State &st, const double *src_t, double *dst);   // dst[i][j][k] += src_t[k][j][i]
+int launch_fold_sum(State &st, const double *a, const double *b_t, double *dst);   // dst[i][j][k] = a[i][j][k] + b_t[k][j][i]
 int launch_transpose(State &st, const double *src, double *dst, int N);   // dst[k][j][i] = src[i][j][k]
 
 // ---------------------------------------------------------------------------------------------
@@ -266,7 +280,8 @@ struct ChemTileParams {
     double dt = 0, bh00 = 0, albpow = 0, colh0 = 0, temph0 = 0, abu_c = 0;
     const double *ndens = nullptr, *temp = nullptr, *xh = nullptr, *xh_av_in = nullptr;
     double *gamma = nullptr, *gamma_t = nullptr;     // rates [i][j][k] (+ [k][j][i] accumulator when fold)
-    double *phi_out = nullptr;                       // fold: folded rates
+    double *phi_out = nullptr;                       // fold: folded rates go here as well (nullptr: nowhere)
+    double *zero_a = nullptr, *zero_t = nullptr;     // emit: the accumulator pair to zero for the next raytrace
     double *xh_av = nullptr, *xh_intermed = nullptr;
     double *nhi = nullptr, *nhi_t = nullptr;         // emit
     double *red_partial = nullptr, *red_final = nullptr;

@@ -185,8 +185,10 @@ __global__ void __launch_bounds__(RED_THREADS) chemistry_reduce_kernel(const dou
 // What the host of the reference does between the raytrace and the next raytrace (pyc2ray/evolve.py:200-240:
 // reshape phi_ion, global_pass, the two sums, ravel xh_av for the next upload) plus this build's own helper
 // passes (fold of the z-face accumulator, nHI in both layouts, zeroing of the accumulators) in ONE sweep over
-// the grids: per cell 6 loads (ndens, temp, xh, xh_av, two accumulators) and 7 stores (xh_av, xh_intermed,
-// phi_ion, nHI twice, two zeros) = 104 B, against 56 + 32 + 24 + 16 B of the four separate passes.
+// the grids: per cell 6 loads (ndens, temp, xh, xh_av, two accumulators) and 6 stores (xh_av, xh_intermed,
+// nHI twice, two zeros) = 96 B (88 without the temperature), against 56 + 32 + 24 + 16 B of the four separate passes.
+// The folded rate itself is NOT stored: the pass leaves the accumulators it read intact and zeroes the OTHER pair for the
+// next raytrace (ChemTileParams.zero_a / zero_t), so the rates of the last iteration can be folded when someone asks.
 // The [k][j][i] twins are read and written through LDS tiles so that their rows are contiguous as well.
 // waves per SIMD the register allocation of the tiled pass must leave room for (a streaming pass: more waves, more
 // bytes in flight)
@@ -222,7 +224,7 @@ __global__ void __launch_bounds__(CH_THREADS, ASORA_CHEM_MIN_WAVES) chemistry_ti
                 if (k < N && i < p.i_end) {
                     const size_t o = ((size_t)k * N + j) * N + i;
                     tile_g[r][tx] = p.gamma_t[o];
-                    if (EMIT) p.gamma_t[o] = 0.0;
+                    if (EMIT) p.zero_t[o] = 0.0;
                 }
             }
             __syncthreads();
@@ -232,8 +234,8 @@ __global__ void __launch_bounds__(CH_THREADS, ASORA_CHEM_MIN_WAVES) chemistry_ti
             if (i < p.i_end && k < N) {
                 const size_t idx = ((size_t)i * N + j) * N + k;
                 double g = p.gamma[idx];
-                if (FOLD) { g += tile_g[tx][r]; p.phi_out[idx] = g; }
-                if (EMIT) p.gamma[idx] = 0.0;
+                if (FOLD) { g += tile_g[tx][r]; if (p.phi_out) p.phi_out[idx] = g; }
+                if (EMIT) p.zero_a[idx] = 0.0;
                 const double n = p.ndens[idx];
                 double xav = p.xh_av_in[idx], xint;
                 if (!UNIFORM_T) temperature_factors(cp, p.temp[idx], tf);

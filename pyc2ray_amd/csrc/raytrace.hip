@@ -218,6 +218,7 @@ extern "C" __device__ double asora_buffer_atomic_fadd_f64(double, __amdgpu_buffe
 #endif
 
 constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_RATE = 1u << 29,
+                   CELL_SPHERE = 1u << 28,            // host bookkeeping: the cell sits on the sphere, RATE depends on dr (the kernel ignores it)
                    CELL_ZERO_SHIFT = 25,              // bits 25..27: which of the offsets (a, b, c) are zero
                    CELL_NEG_SHIFT = 22,               // bits 22..24: the cell lies on the mirrored side of axis 0 / 1 / 2 (axes the unit merges)
                    CELL_SLOT_MASK = (1u << 22) - 1;
@@ -725,7 +726,7 @@ struct HostGeom {
     int nsteps = 0;
     uint32_t max_cells = 1;
     bool inconsistent = false;   // a corner of non-zero weight was not found in the unit
-    bool on_sphere = false;      // some cell needed the floating-point distance test (its result depends on dr)
+    bool on_sphere = false;      // some cell needed the floating-point distance test (its result depends on dr): flagged CELL_SPHERE
 };
 
 inline bool inside_radius_reference(int a, int b, int c, double dr, double R2)
@@ -794,13 +795,15 @@ void build_unit_geometry(HostGeom &h, const UnitSpec &us, double R, double dr, i
     {   const int origin[3] = {0, 0, 0};
         slot_prev[key_of(origin)] = 0;       // the source cell sits in slot 0 of shell 0
     }
-    auto in_sphere = [&](int a, int b, int c) -> bool {
-        if (a + b + c > q_max) return false;                                   // raytracing.cu:101,198
+    // 0: outside, 1: inside, 2: ON the sphere to rounding -- tabulated and evaluated whatever the floating-point test says
+    // (nothing that is kept reads it: its readers lie strictly further out), rated as inside_radius_reference decides for
+    // the current dr; ensure_geometry re-decides these cells in place when dr changes
+    auto in_sphere = [&](int a, int b, int c) -> int {
+        if (a + b + c > q_max) return 0;                                       // raytracing.cu:101,198
         const double n2 = (double)a * a + (double)b * b + (double)c * c;
-        if (n2 > R2hi) return false;
-        if (n2 < R2 * (1.0 - 1e-9) - 1e-9) return true;
-        h.on_sphere = true;
-        return inside_radius_reference(a, b, c, dr, R2);
+        if (n2 > R2hi) return 0;
+        if (n2 < R2 * (1.0 - 1e-9) - 1e-9) return 1;
+        return 2;
     };
     const uint4 pad_a = {0u, 0u, 0u, 0u};
     const uint4 pad_b = {zero_slot_marker, zero_slot_marker, zero_slot_marker, zero_slot_marker};
@@ -810,15 +813,19 @@ void build_unit_geometry(HostGeom &h, const UnitSpec &us, double R, double dr, i
         uint32_t count = 0;
         auto emit = [&](const int x[3], int face) {
             const int a = std::abs(x[0]), b = std::abs(x[1]), c = std::abs(x[2]);
-            if (!in_sphere(a, b, c)) return;
-            bool rate = true;
+            const int where = in_sphere(a, b, c);
+            if (!where) return;
+            bool rate = where == 1 || inside_radius_reference(a, b, c, dr, R2);
+            bool sphere = where == 2;
             if (us.face >= 0 && face != us.face) {
                 // a foreign cell: kept only if this sector reads it
                 const bool keep = (us.face == 1) ? (face == 2 && b == c)
                                                  : (us.face == 0) ? ((face == 2 && a == c) || (face == 1 && a == b)) : false;
                 if (!keep) return;
                 rate = false;
+                sphere = false;
             }
+            if (sphere) h.on_sphere = true;
             const int d = DOM[face], e = TE[face], f = TF[face];
             const int U = std::abs(x[e]), V = std::abs(x[f]);
             const int sgd = x[d] < 0 ? -1 : 1, sge = x[e] < 0 ? -1 : 1, sgf = x[f] < 0 ? -1 : 1;
@@ -847,7 +854,7 @@ void build_unit_geometry(HostGeom &h, const UnitSpec &us, double R, double dr, i
             for (int ax = 0; ax < 3; ++ax) if (((us.merge_mask >> ax) & 1) && x[ax] < 0) negbits |= 1u << ax;
             uint4 ca;
             ca.x = (uint32_t)a | ((uint32_t)b << 10) | ((uint32_t)c << 20) | ((uint32_t)face << 30);
-            ca.y = count | CELL_VALID | (rate ? CELL_RATE : 0u) | (negbits << CELL_NEG_SHIFT) |
+            ca.y = count | CELL_VALID | (rate ? CELL_RATE : 0u) | (sphere ? CELL_SPHERE : 0u) | (negbits << CELL_NEG_SHIFT) |
                    (((a == 0 ? 1u : 0u) | (b == 0 ? 2u : 0u) | (c == 0 ? 4u : 0u)) << CELL_ZERO_SHIFT);
             ca.z = (uint32_t)(pbits & 0xffffffffu);
             ca.w = (uint32_t)(pbits >> 32);
@@ -914,8 +921,8 @@ HostGeom restrict_to_wedge(const HostGeom &full, int wedge, int RT_THREADS, uint
             if (full.cellA[st0].y & CELL_LAST) { shells.push_back(cur); cur.clear(); }
         }
     }
-    auto in_wedge = [wedge](const uint4 &a) -> bool {
-        if (!(a.y & CELL_RATE)) return false;
+    auto in_wedge = [wedge](const uint4 &a) -> bool {           // (own-face cells: rated, or on the sphere and possibly rated later)
+        if (!(a.y & (CELL_RATE | CELL_SPHERE))) return false;
         const int ca = a.x & 1023, cb = (a.x >> 10) & 1023, cc = (a.x >> 20) & 1023, face = a.x >> 30;
         const int s = std::max(ca, std::max(cb, cc));
         const int U = face == 0 ? cb : ca, V = face == 2 ? cb : cc;
@@ -945,7 +952,9 @@ HostGeom restrict_to_wedge(const HostGeom &full, int wedge, int RT_THREADS, uint
             if (!keep[si][q]) continue;
             Entry e = shells[si][q];
             const uint32_t flags = e.a.y & ((7u << CELL_NEG_SHIFT) | (7u << CELL_ZERO_SHIFT));
-            e.a.y = count | CELL_VALID | flags | (in_wedge(e.a) ? CELL_RATE : 0u);
+            const bool mine = in_wedge(e.a);
+            e.a.y = count | CELL_VALID | flags | ((mine && (e.a.y & CELL_RATE)) ? CELL_RATE : 0u) |
+                    ((mine && (e.a.y & CELL_SPHERE)) ? CELL_SPHERE : 0u);
             if (si > 0) {       // corners of shell 1 point into shell 0 (the source cell, slot 0): unchanged
                 auto remap = [&](uint32_t slot) -> uint32_t {
                     if (slot == zero_slot_marker) return slot;
@@ -1004,7 +1013,40 @@ void release_geometry(State &st)
 {
     for (void *q : st.geom_owned) (void)hipFree(q);
     st.geom_owned.clear();
+    st.geom_sphere.clear();
     st.geom_valid = false;
+}
+
+// dr has changed: re-decide the RATE bit of the cells on the sphere (a handful: the lattice points with |d|^2 = R^2) and
+// write the words in place, behind whatever the library's stream is still running with the old ones
+__global__ void patch_words_kernel(const unsigned long long *__restrict__ pairs, int n)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) *reinterpret_cast<uint32_t *>(pairs[2 * q]) = (uint32_t)pairs[2 * q + 1];
+}
+
+static int patch_sphere_cells(State &st, double R, double dr)
+{
+    const size_t n = st.geom_sphere.size();
+    std::vector<unsigned long long> pairs(2 * n);
+    for (size_t q = 0; q < n; ++q) {
+        const State::SphereCell &c = st.geom_sphere[q];
+        pairs[2 * q] = (unsigned long long)reinterpret_cast<uintptr_t>(c.dev_word);
+        pairs[2 * q + 1] = c.word_without_rate | (inside_radius_reference(c.a, c.b, c.c, dr, R * R) ? CELL_RATE : 0u);
+    }
+    if (n > st.geom_patch_cap) {
+        if (st.geom_patch_dev) (void)hipFree(st.geom_patch_dev);
+        st.geom_patch_dev = nullptr; st.geom_patch_cap = 0;
+        ASORA_HIP_TRY(hipMalloc(&st.geom_patch_dev, 2 * n * sizeof(unsigned long long)));
+        st.geom_patch_cap = n;
+    }
+    // (a blocking copy from pageable memory: `pairs` may go out of scope right after; the kernel is stream-ordered)
+    ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    ASORA_HIP_TRY(hipMemcpy(st.geom_patch_dev, pairs.data(), 2 * n * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(patch_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st.stream,
+                       (const unsigned long long *)st.geom_patch_dev, (int)n);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 // Build (or reuse) the geometry tables for this (N, R, dr).  dr only enters through the
@@ -1015,9 +1057,13 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
     const int q_max = (int)std::ceil(1.73205080757 * std::min(p.R, 1.73205080757 * N / 2.0));   // raytracing.cu:14,101
     const int ext_pos = N / 2 - 1 + (N % 2);                                                      // raytracing.cu:122
     const int ext_neg = N / 2;                                                                    // raytracing.cu:123
-    // dr only matters when some cell sits exactly on the sphere (a cosmological run changes dr every step)
-    if (st.geom_valid && st.geom_N == N && st.geom_R == p.R && (st.geom_dr == p.dr || !st.geom_dr_matters) &&
-        st.geom_threads == threads && st.geom_units == units) {
+    // dr only matters for the cells that sit exactly on the sphere (a cosmological run changes dr every step): their RATE
+    // bits are re-decided in place
+    if (st.geom_valid && st.geom_N == N && st.geom_R == p.R && st.geom_threads == threads && st.geom_units == units) {
+        if (st.geom_dr != p.dr && !st.geom_sphere.empty()) {
+            if (int rc = patch_sphere_cells(st, p.R, p.dr)) return rc;
+        }
+        st.geom_dr = p.dr;
         for (int o = 0; o < units; ++o) p.geom[o] = st.geom_host[o];
         p.units = units;
         p.logtab = st.logtab_dev; p.S = st.geom_S; p.max_cells = st.geom_max_cells;
@@ -1106,7 +1152,6 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
     int Smax = 0;
     uint32_t max_cells = 1;
     const uint32_t MARK = 0xffffffffu;
-    bool dr_matters = false;
     {   // the tables of the distinct units are independent: one host thread each (a whole-box trace tabulates N^3
         // cells per unit set -- ~1 s on one core at 320^3)
         std::vector<std::thread> workers;
@@ -1149,7 +1194,6 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
             return fail(11, "raytrace geometry: a cell of a unit reads a corner outside the unit (internal error)");
         Smax = std::max(Smax, hg[u].S);
         max_cells = std::max(max_cells, hg[u].max_cells);
-        dr_matters = dr_matters || hg[u].on_sphere;
     }
     const double t_built = now_s();
     // zero-slot marker -> max_cells (the slot that holds 0.0), then upload
@@ -1168,6 +1212,13 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
         if (int rc = upload(h.cellA, d.cellA, st.geom_owned)) return rc;
         if (int rc = upload(h.cellB, d.cellB, st.geom_owned)) return rc;
         od[u] = d;
+        if (h.on_sphere)         // where the on-sphere cells of this table live on the device (see patch_sphere_cells)
+            for (size_t e = 0; e < h.cellA.size(); ++e)
+                if (h.cellA[e].y & CELL_SPHERE) {
+                    const uint32_t x = h.cellA[e].x;
+                    st.geom_sphere.push_back({reinterpret_cast<uint32_t *>(const_cast<uint4 *>(d.cellA) + e) + 1,
+                                              h.cellA[e].y & ~CELL_RATE, (int)(x & 1023), (int)((x >> 10) & 1023), (int)((x >> 20) & 1023)});
+                }
     }
     for (int u = 0; u < units; ++u) { od[u] = od[owner[u]]; od[u].info = info[u]; }
     if (geom_timing) {
@@ -1184,7 +1235,6 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
     st.geom_units = units;
     st.geom_N = N; st.geom_R = p.R; st.geom_dr = p.dr; st.geom_S = Smax; st.geom_max_cells = (int)max_cells;
     st.geom_threads = threads;
-    st.geom_dr_matters = dr_matters;
     st.geom_valid = true;
     for (int o = 0; o < units; ++o) p.geom[o] = od[o];
     p.units = units;
@@ -1333,6 +1383,32 @@ int launch_fold_range(State &st, const double *src_t, double *dst, int i_begin, 
     const unsigned tk = (st.N + 31) / 32, ti = (i_count + 31) / 32;
     hipLaunchKernelGGL(fold_range_kernel, dim3(ti, st.N, tk), dim3(32, 8), 0, st.stream, src_t, dst, st.N, i_begin,
                        i_begin + i_count);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// dst[i][j][k] = a[i][j][k] + b_t[k][j][i] (the two accumulators of the device loop, left intact, into the rate grid)
+__global__ void __launch_bounds__(256) fold_sum_kernel(const double *__restrict__ a, const double *__restrict__ b_t,
+                                                       double *__restrict__ dst, int N)
+{
+    __shared__ double tile[32][33];
+    const int j = blockIdx.y;
+    const int kb = blockIdx.z * 32, ib = blockIdx.x * 32;       // b_t tile: rows k, columns i
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int k = kb + r, i = ib + threadIdx.x;
+        if (k < N && i < N) tile[r][threadIdx.x] = b_t[((size_t)k * N + j) * N + i];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int i = ib + r, k = kb + threadIdx.x;
+        if (i < N && k < N) { const size_t o = ((size_t)i * N + j) * N + k; dst[o] = a[o] + tile[threadIdx.x][r]; }
+    }
+}
+
+int launch_fold_sum(State &st, const double *a, const double *b_t, double *dst)
+{
+    KernelTimer kt(ASORA_KERNEL_FINISH);
+    hipLaunchKernelGGL(fold_sum_kernel, tile_grid(st.N), dim3(32, 8), 0, st.stream, a, b_t, dst, st.N);
     ASORA_HIP_TRY(hipGetLastError());
     return 0;
 }
