@@ -291,7 +291,12 @@ enum {
      * number of sources (default), 1 = never, 2 = whenever the variant exists (table rates, no heating, shell buffers
      * in LDS, buffer atomics).  Same rates either way, up to the order in which the atomics add them up. */
     ASORA_OPT_PAIR_SOURCES = 13,
-    ASORA_OPT_COUNT = 14
+    /* c2ray_do_all_sources / asora_subbox_raytrace_device: sweep the sub-boxes on the tabulated geometry of the ASORA
+     * kernel (cells within R_max_LLS only: what is rated or lost) instead of generating the cube's geometry on the fly.
+     * 0 = the library decides (radius inside the traversal range, enough sources), 1 = never, 2 = whenever the variant
+     * exists (table rates, N <= 512).  The source whose column densities are returned always takes the on-the-fly kernel. */
+    ASORA_OPT_SUBBOX_TABLES = 14,
+    ASORA_OPT_COUNT = 15
 };
 int asora_set_option(int option, int value);
 int asora_get_option(int option);

@@ -150,6 +150,7 @@ static int release_all()
     drop(st.tables); st.table_len = 0;
     drop(st.src_pos); drop(st.src_flux); drop(st.src_pos_sorted); drop(st.src_flux_sorted); st.src_i0_sorted.clear(); st.num_src = 0;
     drop(st.shell_scratch); st.shell_scratch_bytes = 0;
+    drop(st.sb_trail); st.sb_trail_bytes = 0;
     drop(st.sb_active); drop(st.sb_nbox); drop(st.sb_loss); drop(st.sb_loss_final); st.subbox_cap = 0;
     release_geometry(st);
     st.init = false; st.N = 0; st.ncell = 0;
@@ -383,9 +384,32 @@ static int subbox_core(const SubboxCall &c, long long &total_nbox, double &total
     std::vector<int> h_nbox((size_t)cap);
     std::vector<double> h_loss((size_t)cap);
 
+    // Round 3: the sources whose column densities do not go back to the caller are swept on the ASORA kernel's tabulated
+    // geometry (cells within R_max_LLS only; raytrace.hip, SUBBOX) when that applies; the dumped source -- it needs the
+    // whole cube -- and everything else stay with the on-the-fly kernel of subbox.hip
+    RtParams tp;
+    fill_rt_params(tp, c.R, c.sig, c.dr, c.minlogtau, c.dlogtau, c.NumTau);
+    tp.numtau_f = p.numtau_f; tp.lut_k1 = p.lut_k1; tp.lut_k0 = p.lut_k0; tp.tau_zero = INFINITY;
+    tp.table_len = c.table_len; tp.tables = c.tables;
+    tp.fortran_consts = 1; tp.grey = grey ? 1 : 0; tp.z_transposed = 1;
+    tp.logtab = st.logtab_dev;
+    tp.src_pos = c.src_pos; tp.src_flux = c.src_flux;
+    tp.flux_src = p.flux_src;
+    const bool has_dump = c.dump != nullptr;
+    SubboxTables tab;
+    {
+        const int table_sources = c.src_count - (has_dump ? 1 : 0);
+        if (range_open && table_sources > 0)
+            if (int rc = subbox_tables_prepare(st, tp, ext_r, ext_l, c.subboxsize, std::min(table_sources, max_batch), c.heat, tab)) return rc;
+    }
+
     for (int done = 0; done < c.src_count;) {
         const int batch = std::min(c.src_count - done, max_batch);
-        const size_t need = (size_t)8 * ((batch + 7) / 8) * per_src;
+        // with the tables, the on-the-fly kernel only sweeps the dumped source (the last one of the call)
+        const bool dump_here = has_dump && done + batch == c.src_count;
+        const int fly_count = tab.ok ? (dump_here ? 1 : 0) : batch;
+        const int fly_first = tab.ok ? batch - fly_count : 0;          // batch-local index of the first source swept on the fly
+        const size_t need = (size_t)8 * ((std::max(fly_count, 1) + 7) / 8) * per_src;
         if (need > st.shell_scratch_bytes) {
             if (st.shell_scratch) ASORA_HIP_TRY(hipFree(st.shell_scratch));
             st.shell_scratch = nullptr; st.shell_scratch_bytes = 0;
@@ -394,8 +418,10 @@ static int subbox_core(const SubboxCall &c, long long &total_nbox, double &total
         }
         const int first = c.src_begin + done;
         p.scratch = st.shell_scratch;
-        p.src_begin = first; p.src_count = batch;
-        p.active = st.sb_active; p.loss = st.sb_loss;
+        p.src_begin = first + fly_first; p.src_count = fly_count;
+        p.active = st.sb_active + fly_first; p.loss = st.sb_loss + fly_first;
+        tp.src_begin = first; tp.src_count = batch - fly_count;
+        tp.sb_active = st.sb_active; tp.sb_loss = st.sb_loss;
         int n_active = 0;
         if (int rc = launch_subbox_decide(st, 0, batch, c.src_flux, first, (double)c.loss_fraction, range_open ? 1 : 0,
                                           st.sb_active, st.sb_loss, st.sb_loss_final, st.sb_nbox, st.sb_nactive)) return rc;
@@ -409,7 +435,11 @@ static int subbox_core(const SubboxCall &c, long long &total_nbox, double &total
             p.s_end = (int)std::min<long long>(box, S_all);
             p.edge_r = (int)std::min<long long>(box, ext_r);
             p.edge_l = (int)std::min<long long>(box, ext_l);
-            if (int rc = launch_subbox_sweep(st, p)) return rc;
+            if (fly_count > 0) { if (int rc = launch_subbox_sweep(st, p)) return rc; }
+            if (tab.ok && tp.src_count > 0) {
+                tp.sb_edge_r = p.edge_r; tp.sb_edge_l = p.edge_l;
+                if (int rc = subbox_tables_sweep(st, tp, tab, p.s_begin, p.s_end, c.heat)) return rc;
+            }
             const int more_range = (box < ext_r && box < ext_l) ? 1 : 0;          // f90:194-195
             if (int rc = launch_subbox_decide(st, 1, batch, c.src_flux, first, (double)c.loss_fraction, more_range,
                                               st.sb_active, st.sb_loss, st.sb_loss_final, st.sb_nbox, st.sb_nactive)) return rc;

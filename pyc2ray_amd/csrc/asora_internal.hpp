@@ -57,6 +57,14 @@ struct RtParams {
     double *shell_scratch;      // global shell buffers when they do not fit LDS, else nullptr
     unsigned long long *counters;
     const int *done_flag;       // evolve loop: device flag "the step has converged" -> the launch does nothing; or nullptr
+    // ---- SUBBOX kernels only (the reference's CPU semantics on the tabulated geometry, raytrace.hip / subbox.hip) ----
+    int sb_k0[12], sb_k1[12];   // per unit: this launch sweeps the table steps [k0, k1) = the shells of one sub-box (multiples of 3)
+    int sb_first;               // 1: the launch starts at the source cell; 0: it continues from the trailing shell in sb_trail
+    int sb_edge_r, sb_edge_l;   // faces of the current sub-box on the + / - side of every axis (raytracing.f90:199-200)
+    int flux_src;               // >= 0: every source shines with the flux of this one (f90:500,503); -1: its own
+    const int *sb_active;       // per source of the batch: still growing?
+    double *sb_loss;            // per source of the batch: photons through the faces of the current sub-box
+    double *sb_trail;           // per (source, unit): the last shell swept, handed to the next sub-box's launch
 };
 
 // Device-side bookkeeping of the evolve loop (asora_evolve_begin / _enqueue / _poll): the convergence test of
@@ -121,6 +129,10 @@ struct State {
     void *geom_patch_dev = nullptr;         // staging for the patch kernel: {address, value} pairs
     size_t geom_patch_cap = 0;
     int geom_N = 0, geom_S = 0, geom_max_cells = 0, geom_threads = 0;
+    // sub-box tables (subbox_tables_prepare): traversal range instead of the periodic window, no octahedron bound, every
+    // sub-box boundary padded to whole triples of steps; step_after_shell[u][s] = first table step behind shell s of unit u
+    int geom_subbox = 0, geom_ext_r = 0, geom_ext_l = 0, geom_boxsize = 0;
+    std::vector<int> geom_step_after_shell[12];
     double geom_R = 0.0, geom_dr = 0.0;
 
     // a raytrace call in progress (asora_raytrace_begin ... _range ... _fold)
@@ -138,6 +150,9 @@ struct State {
     int *sb_active = nullptr, *sb_nbox = nullptr, *sb_nactive = nullptr;
     double *sb_loss = nullptr, *sb_loss_final = nullptr;
     size_t subbox_cap = 0;
+
+    double *sb_trail = nullptr;             // per (source, unit): the trailing shell between two sub-box launches (table path)
+    size_t sb_trail_bytes = 0;
 
     // shell scratch for traces whose shell buffers exceed LDS
     double *shell_scratch = nullptr;
@@ -182,7 +197,7 @@ struct State {
     struct PendingTimer { int which; hipEvent_t e0, e1; };
     std::vector<PendingTimer> pending_timers;     // recorded, not yet resolved
     std::vector<hipEvent_t> free_events;
-    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0};
+    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0};
     double k_ms[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
     long k_n[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
 };
@@ -219,6 +234,11 @@ int ensure_logtab(State &st);
 int launch_prepare_nhi(State &st, bool need_transposed);
 int launch_finish_phi(State &st);
 int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t side = nullptr);   // side: stream to launch on when no shared scratch is needed
+// The sub-box sweep on tabulated geometry (raytrace.hip): prepare -> tables for (N, R, range, box size), then one launch per
+// sub-box.  `shells` = (s_begin, s_end] of the box; returns without launching when the tables hold nothing there.
+struct SubboxTables { int units = 0, threads = 0, S = 0; bool ok = false; };
+int subbox_tables_prepare(State &st, RtParams &p, int ext_r, int ext_l, int subboxsize, int src_count, bool heat, SubboxTables &out);
+int subbox_tables_sweep(State &st, const RtParams &p, const SubboxTables &tab, int s_begin, int s_end, bool heat);
 int launch_fold_transposed(State &st, const double *src_t, double *dst);   // dst[i][j][k] += src_t[k][j][i]
 int launch_fold_sum(State &st, const double *a, const double *b_t, double *dst);   // dst[i][j][k] = a[i][j][k] + b_t[k][j][i]
 int launch_transpose(State &st, const double *src, double *dst, int N);   // dst[k][j][i] = src[i][j][k]

@@ -238,12 +238,18 @@ constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_RATE = 1u <
 // two independent dependency chains (LDS reads -> interpolation -> LDS write) that interleave.  What stays per source:
 // the shell buffers and wrapped-coordinate tables in LDS, nHI, the interpolation, the lookups and the atomic.  An odd
 // source count leaves the last workgroup with a copy of its first source whose rates are dropped (`have`).
+// SUBBOX: the semantics of the reference's CPU function (src/c2ray/raytracing.f90:52-567, see subbox.hip) on this kernel's
+// machinery.  A launch sweeps ONE sub-box = a range of shells = the table steps [sb_k0, sb_k1) of its unit, for the sources
+// that are still growing; it starts from the trailing shell the previous sub-box's launch left in global memory and leaves
+// its own there; cells on the faces of the box add what passes through them (phi_out, photorates.f90:120-125) to the
+// source's photon loss; every source is rated with the flux of `flux_src` (f90:500,503).  Fortran-flavoured constants.
 template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP, bool HEAT, int TABCAP, bool SKIP_ZERO = false, bool GREY = false,
-          bool BUFATOM = false, int NSRC = 1>
+          bool BUFATOM = false, int NSRC = 1, bool SUBBOX = false>
 __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? ASORA_PAIR_MIN_WAVES : ASORA_MIN_WAVES) : 1)) raytrace_octant_kernel(const RtParams p)
 {
     extern __shared__ double lds_raw[];
     static_assert(NSRC == 1 || (ASORA_LATE_LOOKUP && !GLOBAL_SCRATCH && !DUMP && !SKIP_ZERO), "paired sources: production variant only");
+    static_assert(!SUBBOX || (NSRC == 1 && ASORA_LATE_LOOKUP && !GLOBAL_SCRATCH && !DUMP && !SKIP_ZERO && !GREY), "sub-box sweep: table rates, shells in LDS");
 
     if (p.done_flag && *p.done_flag) return;   // evolve loop: an iteration enqueued beyond convergence does nothing
     const int blk = blockIdx.x;
@@ -264,6 +270,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     unit = p.units - 1 - unit;   // sector units: z (most cells) first, x (fewest) last in dispatch order
 #endif
     if (src_local * NSRC >= p.src_count) return;
+    if (SUBBOX) { if (!p.sb_active[src_local]) return; }            // this source stopped growing after an earlier box
 
     const uint4 *__restrict__ cellA = p.geom[unit].cellA;
     const uint4 *__restrict__ cellB = p.geom[unit].cellB;
@@ -281,7 +288,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
         i0[q] = p.src_pos[3 * ns + 0];
         j0[q] = p.src_pos[3 * ns + 1];
         k0[q] = p.src_pos[3 * ns + 2];
-        flux[q] = p.src_flux[ns];
+        flux[q] = p.src_flux[(SUBBOX && p.flux_src >= 0) ? p.flux_src : ns];
         nreal += have[q] ? 1u : 0u;
     }
     const int sa = (uinfo & 1) ? -1 : 1, sb = (uinfo & 2) ? -1 : 1, sc = (uinfo & 4) ? -1 : 1;
@@ -347,8 +354,14 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
         else if (ok) unsafeAtomicAdd(p.heat + idx, v);
     };
 
+    // ---- SUBBOX, a later box of the source: continue from the trailing shell of the box before ------------
+    const bool continues = SUBBOX && !p.sb_first;
+    double *trail = SUBBOX ? p.sb_trail + ((size_t)src_local * p.units + unit) * (size_t)slots : nullptr;
+    if (continues) {
+        for (int t = threadIdx.x; t < p.max_cells; t += RT_THREADS) prev[t] = trail[t];
+    }
     // ---- shell 0: the source cell (raytracing.cu:285-294) -----------------------------------
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && !continues) {
 #pragma unroll
         for (int q = 0; q < NSRC; ++q) {
             const unsigned idx = ((unsigned)i0[q] * N + j0[q]) * N + k0[q];
@@ -417,6 +430,14 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
 #endif
     }
 
+    // SUBBOX: photons through the faces of the current sub-box (f90:541-543), per lane; the faces on the unit's own side
+    // and on the mirrored side of each axis
+    double loss = 0.0;
+    bool pend_edge = false, cur_edge = false;
+    double pend_pv = 0.0;                 // flux / volume of the pending cell (pref without the division by nHI)
+    const int edge_own[3] = {sa > 0 ? p.sb_edge_r : p.sb_edge_l, sb > 0 ? p.sb_edge_r : p.sb_edge_l, sc > 0 ? p.sb_edge_r : p.sb_edge_l};
+    const int edge_mir[3] = {sa > 0 ? p.sb_edge_l : p.sb_edge_r, sb > 0 ? p.sb_edge_l : p.sb_edge_r, sc > 0 ? p.sb_edge_l : p.sb_edge_r};
+
     auto step = [&](unsigned e_pf, const uint4 &cur_A, const uint4 &cur_B, const double (&cur_nhi)[NSRC], const unsigned (&cur_idx)[NSRC],
                     const uint4 &nxt_A, double (&nxt_nhi)[NSRC], unsigned (&nxt_idx)[NSRC], uint4 &pf_A, uint4 &pf_B) {
 #if ASORA_STEP_SCHED_BARRIER
@@ -472,6 +493,11 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
         const double n2 = (double)(a * a + b * b + c * c);
         const double volfac = n2 * (dr * dr * FOURPI) * path;                              // raytracing.cu:302-307 without nHI
         const unsigned own_slot = cur_A.y & CELL_SLOT_MASK;
+        if (SUBBOX) {       // is the cell on a face of the current sub-box?
+            const unsigned nb = cur_A.y >> CELL_NEG_SHIFT;
+            cur_edge = a == ((nb & 1u) ? edge_mir[0] : edge_own[0]) || b == ((nb & 2u) ? edge_mir[1] : edge_own[1]) ||
+                       c == ((nb & 4u) ? edge_mir[2] : edge_own[2]);
+        }
         n_eval += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid)) * nreal;
 
         // ---- per source: the medium-dependent arithmetic ----------------------------------------------------------------
@@ -550,6 +576,8 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
                 arg_A[q] = (thick[q] || p.fortran_consts) ? tau_in : tau_out;
                 arg_B[q] = (thick[q] || !p.fortran_consts) ? tau_out : tau_in;
             }
+            // SUBBOX: the second lookup of a THIN cell is the THICK table at tau_in: phi_in = pref T_thick(tau_in), which
+            // the photon loss needs (phi_out = phi_in - phi, photorates.f90:120-125); its rate only uses the first
 #if ASORA_LATE_LOOKUP
             // SKIP_ZERO (ASORA_OPT_SKIP_ZERO_RATES): a thick cell whose tau_in lies beyond the last table entry gets
             // pref * (T_last - T_last) = exactly +0; adding it changes nothing, so the atomic is not issued -- and when no
@@ -592,8 +620,24 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
                         pref[q] = vol_nhi[q] == 0.0 ? flux[q] * INFINITY : ASORA_DIV(flux[q], vol_nhi[q]);
 #endif
                         A2[q] = lookup_issue<HEAT>(tab, arg_A[q], p, logtab, toff[q]);
-                        B2[q] = lookup_issue<HEAT>(tab, arg_B[q], p, logtab, toff[q]);
+                        B2[q] = lookup_issue<HEAT>(tab, arg_B[q], p, logtab, SUBBOX ? 0 : toff[q]);
                     }
+                }
+                if (SUBBOX) {
+                    // what leaves the PREVIOUS step's cell through the far side, if that cell lies on a face of the box
+                    const double ta = lookup_value(pend_A[0]), tb = lookup_value(pend_B[0]);
+                    const double po = pend_thick[0] ? pend_pv * tb : pend_pv * (tb - pend_dtau[0] * ta);
+                    if (late_ok[0] && pend_edge) loss += po;
+                    // flux / volume of this step's cell: pref * nHI, or the quotient itself where nHI = 0 (pref = inf)
+                    double pv = pref[0] * cur_nhi[0];
+                    if (__builtin_amdgcn_ballot_w64(cur_nhi[0] == 0.0) != 0ull) {
+                        const double n2s = (double)((cur_A.x & 1023) * (cur_A.x & 1023) + ((cur_A.x >> 10) & 1023) * ((cur_A.x >> 10) & 1023) +
+                                                    ((cur_A.x >> 20) & 1023) * ((cur_A.x >> 20) & 1023));
+                        const double vol = n2s * (dr * dr * FOURPI) * (__hiloint2double((int)cur_A.w, (int)cur_A.z) * dr);
+                        if (cur_nhi[0] == 0.0) pv = flux[0] / vol;
+                    }
+                    pend_pv = pv;
+                    pend_edge = cur_edge;
                 }
 #pragma unroll
                 for (int q = 0; q < NSRC; ++q) {
@@ -640,7 +684,9 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
         }
     };
 
-    unsigned e = threadIdx.x;
+    // SUBBOX: the steps of this launch's sub-box only (whole triples: the tables are padded at every box boundary)
+    const int k_first = SUBBOX ? p.sb_k0[unit] : 0, k_last = SUBBOX ? p.sb_k1[unit] : nsteps;
+    unsigned e = (unsigned)k_first * RT_THREADS + threadIdx.x;
     uint4 A0 = cellA[e], B0 = cellB[e];
     uint4 A1 = cellA[e + RT_THREADS], B1 = cellB[e + RT_THREADS];
     uint4 A2, B2;
@@ -680,7 +726,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
 
     // nsteps is a multiple of 3 (the tables are padded to it) and is followed by two more
     // all-invalid steps, so every look-ahead stays inside the tables.
-    for (int k = 0; k < nsteps; k += 3, e += 3 * RT_THREADS) {
+    for (int k = k_first; k < k_last; k += 3, e += 3 * RT_THREADS) {
         step(e + 2 * RT_THREADS, A0, B0, nhi0, idx0, A1, nhi1, idx1, A2, B2);
         step(e + 3 * RT_THREADS, A1, B1, nhi1, idx1, A2, nhi2, idx2, A0, B0);
         step(e + 4 * RT_THREADS, A2, B2, nhi2, idx2, A0, nhi0, idx0, A1, B1);
@@ -698,6 +744,20 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
         add_phi(late_ok[q], late_idx[q], late_v[q]);
         if (HEAT) add_heat(late_ok[q], late_idx[q], late_h[q]);
 #endif
+    }
+
+    if (SUBBOX) {
+        // the pending cell of the last step
+        {
+            const double ta = lookup_value(pend_A[0]), tb = lookup_value(pend_B[0]);
+            const double po = pend_thick[0] ? pend_pv * tb : pend_pv * (tb - pend_dtau[0] * ta);
+            if (late_ok[0] && pend_edge) loss += po;
+        }
+        // hand the last shell swept to the next sub-box's launch (the step that closed it ended with the barrier and the
+        // swap: it is `prev`, complete)
+        for (int t = threadIdx.x; t < p.max_cells; t += RT_THREADS) trail[t] = prev[t];
+        for (int o = 32; o > 0; o >>= 1) loss += __shfl_down(loss, o);
+        if ((threadIdx.x & 63) == 0 && loss != 0.0) unsafeAtomicAdd(p.sb_loss + src_local, loss * (dr * dr * dr));
     }
 
     // work accounting: one atomic per wave and counter
@@ -727,6 +787,7 @@ struct HostGeom {
     uint32_t max_cells = 1;
     bool inconsistent = false;   // a corner of non-zero weight was not found in the unit
     bool on_sphere = false;      // some cell needed the floating-point distance test (its result depends on dr): flagged CELL_SPHERE
+    std::vector<int> step_after_shell;   // [s]: number of table steps up to and including shell s ([0] = 0)
 };
 
 inline bool inside_radius_reference(int a, int b, int c, double dr, double R2)
@@ -766,8 +827,10 @@ struct UnitSpec {
     int wedge = -1;           // 0..3: a quarter of the sector (restrict_to_wedge), -1: the whole unit
 };
 
+// boxsize > 0 (sub-box tables): every shell that closes a sub-box (a multiple of boxsize) is followed by all-invalid steps
+// up to a whole triple of steps, so that a launch can sweep exactly one sub-box with the three-step pipeline
 void build_unit_geometry(HostGeom &h, const UnitSpec &us, double R, double dr, int q_max, uint32_t zero_slot_marker,
-                         int RT_THREADS)
+                         int RT_THREADS, int boxsize = 0)
 {
     const double R2 = R * R;
     const double R2hi = R2 * (1.0 + 1e-9) + 1e-9;
@@ -890,13 +953,19 @@ void build_unit_geometry(HostGeom &h, const UnitSpec &us, double R, double dr, i
         // pad the shell to whole steps and flag every entry of its last step
         while (h.cellA.size() % RT_THREADS) { h.cellA.push_back(pad_a); h.cellB.push_back(pad_b); }
         for (size_t q = h.cellA.size() - RT_THREADS; q < h.cellA.size(); ++q) h.cellA[q].y |= CELL_LAST;
+        if (boxsize > 0 && s % boxsize == 0)
+            while ((h.cellA.size() / (size_t)RT_THREADS) % 3) for (int q = 0; q < RT_THREADS; ++q) { h.cellA.push_back(pad_a); h.cellB.push_back(pad_b); }
         h.max_cells = std::max(h.max_cells, count);
         slot_prev.swap(slot_cur);
+        h.step_after_shell.resize((size_t)s + 1, 0);
+        h.step_after_shell[(size_t)s] = (int)(h.cellA.size() / (size_t)RT_THREADS);
     }
     // the kernel walks the steps three at a time and looks two steps ahead: pad to a multiple of
     // three steps and append four all-invalid steps so that every load stays inside the tables
     while ((h.cellA.size() / (size_t)RT_THREADS) % 3) for (int q = 0; q < RT_THREADS; ++q) { h.cellA.push_back(pad_a); h.cellB.push_back(pad_b); }
     h.nsteps = (int)(h.cellA.size() / (size_t)RT_THREADS);
+    if (h.step_after_shell.empty()) h.step_after_shell.push_back(0);
+    h.step_after_shell.back() = h.nsteps;         // (the last shell's count includes the closing padding)
     for (int q = 0; q < 4 * RT_THREADS; ++q) { h.cellA.push_back(pad_a); h.cellB.push_back(pad_b); }
 }
 
@@ -1051,15 +1120,19 @@ static int patch_sphere_cells(State &st, double R, double dr)
 
 // Build (or reuse) the geometry tables for this (N, R, dr).  dr only enters through the
 // classification of cells sitting exactly on the sphere (see inside_radius_reference).
-static int ensure_geometry(State &st, RtParams &p, int threads, int units)
+struct SubboxGeometry { int ext_r, ext_l, boxsize; };     // sub-box tables: the traversal range of raytracing.f90:174-175, the box size
+static int ensure_geometry(State &st, RtParams &p, int threads, int units, const SubboxGeometry *sbg = nullptr)
 {
     const int N = p.N;
-    const int q_max = (int)std::ceil(1.73205080757 * std::min(p.R, 1.73205080757 * N / 2.0));   // raytracing.cu:14,101
-    const int ext_pos = N / 2 - 1 + (N % 2);                                                      // raytracing.cu:122
-    const int ext_neg = N / 2;                                                                    // raytracing.cu:123
+    // (the Fortran path has no octahedron bound and its own range instead of the ASORA window)
+    const int q_max = sbg ? (1 << 28) : (int)std::ceil(1.73205080757 * std::min(p.R, 1.73205080757 * N / 2.0));   // raytracing.cu:14,101
+    const int ext_pos = sbg ? sbg->ext_r : N / 2 - 1 + (N % 2);                                  // raytracing.cu:122
+    const int ext_neg = sbg ? sbg->ext_l : N / 2;                                                // raytracing.cu:123
+    const int boxsize = sbg ? sbg->boxsize : 0;
     // dr only matters for the cells that sit exactly on the sphere (a cosmological run changes dr every step): their RATE
     // bits are re-decided in place
-    if (st.geom_valid && st.geom_N == N && st.geom_R == p.R && st.geom_threads == threads && st.geom_units == units) {
+    if (st.geom_valid && st.geom_N == N && st.geom_R == p.R && st.geom_threads == threads && st.geom_units == units &&
+        st.geom_subbox == (sbg ? 1 : 0) && (!sbg || (st.geom_ext_r == ext_pos && st.geom_ext_l == ext_neg && st.geom_boxsize == boxsize))) {
         if (st.geom_dr != p.dr && !st.geom_sphere.empty()) {
             if (int rc = patch_sphere_cells(st, p.R, p.dr)) return rc;
         }
@@ -1159,8 +1232,8 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
         if (units != 96) {
             for (int u = 0; u < units; ++u) {
                 if (owner[u] != u) continue;
-                workers.emplace_back([&hg, &spec, u, R_all, dr_all, q_max, threads]() {
-                    build_unit_geometry(hg[u], spec[u], R_all, dr_all, q_max, MARK, threads);
+                workers.emplace_back([&hg, &spec, u, R_all, dr_all, q_max, threads, boxsize]() {
+                    build_unit_geometry(hg[u], spec[u], R_all, dr_all, q_max, MARK, threads, boxsize);
                 });
             }
             for (auto &w : workers) w.join();
@@ -1235,6 +1308,8 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units)
     st.geom_units = units;
     st.geom_N = N; st.geom_R = p.R; st.geom_dr = p.dr; st.geom_S = Smax; st.geom_max_cells = (int)max_cells;
     st.geom_threads = threads;
+    st.geom_subbox = sbg ? 1 : 0; st.geom_ext_r = ext_pos; st.geom_ext_l = ext_neg; st.geom_boxsize = boxsize;
+    for (int u = 0; u < units && u < 12; ++u) st.geom_step_after_shell[u] = hg[owner[u]].step_after_shell;
     st.geom_valid = true;
     for (int o = 0; o < units; ++o) p.geom[o] = od[o];
     p.units = units;
@@ -1668,6 +1743,89 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
         done += batch;
     }
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The sub-box sweep of the reference's CPU function on this file's tabulated geometry (see the kernel's SUBBOX and
+// subbox.hip for the semantics).  The tables hold the cells within R_max_LLS inside the traversal range -- the only ones
+// that are rated or add to the photon loss; a source whose column densities go back to the caller needs the whole cube and
+// stays with the on-the-fly kernel of subbox.hip.
+// ---------------------------------------------------------------------------------------------
+template <int T, bool HT>
+static int launch_subbox_tables_variant(const RtParams &q, unsigned grid, size_t lds_bytes, hipStream_t stream)
+{
+    ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, HT, 256, false, false, true, 1, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, HT, 256, false, false, true, 1, true>), dim3(grid), dim3(T), lds_bytes,
+                       stream, q);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int subbox_tables_prepare(State &st, RtParams &p, int ext_r, int ext_l, int subboxsize, int src_count, bool heat, SubboxTables &out)
+{
+    (void)heat;
+    out = SubboxTables();
+    const int want = st.opt[ASORA_OPT_SUBBOX_TABLES];
+    if (want == 1 || p.grey || ext_r <= 0 || ext_l <= 0 || src_count < 1) return 0;
+    if (16ull * p.ncell > 0x80000000ull || st.opt[ASORA_OPT_GLOBAL_ATOMICS] || !p.z_transposed) return 0;   // the rates go through buffer atomics
+    const double R2hi = p.R * p.R * (1.0 + 1e-9) + 1e-9;
+    const int range = std::max(ext_r, ext_l);
+    const int S_tab = std::isfinite(R2hi) ? (int)std::min((double)range, std::floor(std::sqrt(R2hi))) : range;
+    if (S_tab + 1 > 256) return 0;                                    // the variant is built with the 256-entry LDS tables
+    // auto: when the radius, not the range, bounds the work (else the tables would hold the whole cube), and not beyond
+    // what a table of a few tens of MB covers
+    if (want == 0 && !(S_tab < std::min(ext_r, ext_l) && S_tab <= 96)) return 0;
+    int units, threads;
+    const double r = (double)S_tab;
+    if (r < 15.5) { units = 1; threads = 256; }
+    else if (r < 21.5) { units = 1; threads = 512; }
+    else if (r < 23.5) { units = 2; threads = 256; }
+    else if (r < 25.5) { units = 2; threads = 512; }
+    else if (r < 36.5) { units = 6; threads = 256; }
+    else if (r < 52.5) { units = 12; threads = 256; }
+    else { units = 12; threads = 512; }
+    if (want == 0 && (long)src_count * units < 2L * st.cu_count) return 0;     // a handful of sources: subbox.hip's wide workgroups
+    const SubboxGeometry sbg{ext_r, ext_l, subboxsize};
+    if (int rc = ensure_geometry(st, p, threads, units, &sbg)) return rc;
+    const size_t slots = ((size_t)p.max_cells + 2) & ~(size_t)1;
+    if (2 * slots * sizeof(double) + lds_table_bytes(256) > LDS_LIMIT_BYTES) return 0;
+    const size_t need = (size_t)src_count * units * slots * sizeof(double);
+    if (need > st.sb_trail_bytes) {
+        if (st.sb_trail) ASORA_HIP_TRY(hipFree(st.sb_trail));
+        st.sb_trail = nullptr; st.sb_trail_bytes = 0;
+        ASORA_HIP_TRY(hipMalloc(&st.sb_trail, need));
+        st.sb_trail_bytes = need;
+    }
+    p.sb_trail = st.sb_trail;
+    out.units = units; out.threads = threads; out.S = p.S; out.ok = true;
+    return 0;
+}
+
+int subbox_tables_sweep(State &st, const RtParams &p, const SubboxTables &tab, int s_begin, int s_end, bool heat)
+{
+    RtParams q = p;
+    bool any = false;
+    for (int u = 0; u < tab.units; ++u) {
+        const std::vector<int> &after = st.geom_step_after_shell[u];
+        auto at = [&](int s) { return after[(size_t)std::min<long>(std::max(s, 0), (long)after.size() - 1)]; };
+        q.sb_k0[u] = at(s_begin);
+        q.sb_k1[u] = at(s_end);
+        if (q.sb_k0[u] % 3 || q.sb_k1[u] % 3) return fail(11, "sub-box tables: a box boundary is not on a triple of steps (internal error)");
+        any = any || q.sb_k1[u] > q.sb_k0[u];
+    }
+    if (!any) return 0;                       // the box lies beyond the radius: nothing is rated, nothing is lost
+    q.sb_first = s_begin == 0 ? 1 : 0;
+    const size_t slots = ((size_t)p.max_cells + 2) & ~(size_t)1;
+    const size_t lds_bytes = 2 * slots * sizeof(double) + lds_table_bytes(256);
+    const int groups = q.src_count;
+    q.spread = (long)groups * tab.units <= 2L * st.cu_count ? 1 : 0;
+    const unsigned grid = q.spread ? (unsigned)tab.units * (unsigned)groups : 8u * (unsigned)tab.units * (unsigned)((groups + 7) / 8);
+    KernelTimer kt(ASORA_KERNEL_RAYTRACE);
+    if (tab.threads == 512) return heat ? launch_subbox_tables_variant<512, true>(q, grid, lds_bytes, st.stream)
+                                        : launch_subbox_tables_variant<512, false>(q, grid, lds_bytes, st.stream);
+    return heat ? launch_subbox_tables_variant<256, true>(q, grid, lds_bytes, st.stream)
+                : launch_subbox_tables_variant<256, false>(q, grid, lds_bytes, st.stream);
 }
 
 } // namespace asora

@@ -338,3 +338,83 @@ def test_shell_buffers_in_lds_and_in_global_memory_give_the_same(libs, name, hea
     if heat:
         _close(phi1, g[name + "__phi"], RATE_RTOL)
         assert nbox1 == int(g[name + "__stats"][0])
+
+
+# ---- the sweep on tabulated geometry (round 3: raytrace.hip SUBBOX) -----------------------------------------------------
+@pytest.mark.parametrize("name", list(cases.SUBBOX_CASES))
+def test_tabulated_sweep_matches_the_reference(libs, name):
+    """ASORA_OPT_SUBBOX_TABLES = 2: every source but the last (whose column densities go back to the caller) is swept on
+    the tabulated geometry of the ASORA kernel -- launch per sub-box, trailing shell through global memory, photon loss
+    from the cells on the box faces.  Same fixtures of the reference Fortran as the on-the-fly kernel: box counts exact,
+    rates, heating, loss and column densities."""
+    p, c2ray, asora, capi = libs
+    c = cases.subbox_case(name)
+    _fresh(p, c["N"])
+    g = np.load(os.path.join(G, "subbox.npz"))
+    asora.set_option(capi.OPT_SUBBOX_TABLES, 2)
+    try:
+        phi, heat, cd, nbox, loss = _call(c2ray, c, c["max_subbox"], c["subboxsize"], c["loss_fraction"], c["R"])
+    finally:
+        asora.set_option(capi.OPT_SUBBOX_TABLES, 0)
+    assert nbox == int(g[name + "__stats"][0])
+    _close(phi, g[name + "__phi"], RATE_RTOL)
+    _close(heat, g[name + "__heat"], RATE_RTOL)
+    np.testing.assert_allclose(cd, g[name + "__cd"], rtol=1e-11)
+    np.testing.assert_allclose(loss, g[name + "__stats"][1], rtol=RATE_RTOL)
+
+
+def test_tabulated_sweep_randomised_against_oracle_and_on_the_fly_kernel(libs):
+    """Seeded sweep: mesh sizes, source counts (corners included), ranges, box sizes, loss fractions, opacities, and radii
+    both beyond the range (loss defined everywhere: against the oracle) and INSIDE it (the tables then hold the sphere
+    only; cells on box faces beyond the radius add nothing on either GPU path: the two paths against each other, rates
+    against the oracle)."""
+    p, c2ray, asora, capi = libs
+    rng = np.random.default_rng(2031)
+    thin, thick, dlog = cases.soft_tables(400)
+    ht, hk = 1e-11 * thin[::-1].copy(), 3e-12 * thick
+    seen_multi_box = 0
+    for trial in range(28):
+        N = int(rng.choice([12, 16, 20, 33]))
+        ns = int(rng.integers(2, 7))
+        tau_cell = float(10 ** rng.uniform(-2.0, 0.5))
+        nd, xh, dr = cases.grid(N, "lognormal", 300 + trial, tau_cell)
+        pos = 1 + rng.integers(0, N, size=(3, ns))
+        if trial % 4 == 0:
+            pos[:, 0] = [1, N, 1]
+        flux = rng.uniform(0.5, 4.0, size=ns)
+        max_subbox = int(rng.choice([3, N // 2 - 1, N // 2, 1000]))
+        subboxsize = int(rng.integers(1, 6))
+        lf = float(rng.choice([0.0, 1e-3, 0.05, 0.3]))
+        R = float(rng.choice([1000.0, 1000.0, 2.5, 4.0, 5.0, N / 3.0]))
+        use_heat = bool(trial % 2)
+        zeros = np.zeros(thin.shape[0])
+        _fresh(p, N)
+        out = {}
+        for tables in (1, 2):
+            phi = np.zeros((N, N, N), order="F"); heat = np.zeros((N, N, N), order="F"); cd = np.zeros((N, N, N), order="F")
+            asora.set_option(capi.OPT_SUBBOX_TABLES, tables)
+            try:
+                nbox, loss = c2ray.raytracing.do_all_sources(flux, pos, max_subbox, subboxsize, cd, cases.SIG, dr, nd, xh, phi, heat,
+                                                             lf, thin, thick, ht if use_heat else zeros, hk if use_heat else zeros,
+                                                             cases.MINLOGTAU, dlog, R)
+            finally:
+                asora.set_option(capi.OPT_SUBBOX_TABLES, 0)
+            out[tables] = (phi, heat, cd, nbox, loss)
+        tag = f"trial {trial}: N={N} ns={ns} max_subbox={max_subbox} subboxsize={subboxsize} lf={lf} tau={tau_cell:.3g} R={R} heat={use_heat}"
+        (phi1, heat1, cd1, nbox1, loss1), (phi2, heat2, cd2, nbox2, loss2) = out[1], out[2]
+        assert nbox1 == nbox2, tag
+        np.testing.assert_allclose(loss2, loss1, rtol=RATE_RTOL, err_msg=tag)
+        assert np.array_equal(cd1, cd2), tag                       # the dumped source takes the same kernel on both paths
+        _close(phi2, phi1, RATE_RTOL)
+        _close(heat2, heat1, RATE_RTOL)
+        ref = O.do_all_sources(flux, pos, max_subbox, subboxsize, cases.SIG, dr, nd, xh, lf, thin, thick, cases.MINLOGTAU,
+                               dlog, R, heat_thin=ht if use_heat else None, heat_thick=hk if use_heat else None)
+        if R >= 1000.0:
+            assert nbox2 == ref["nsubbox"], tag
+            np.testing.assert_allclose(loss2, ref["photon_loss"], rtol=RATE_RTOL, err_msg=tag)
+            _close(phi2, ref["phi_ion"], RATE_RTOL)
+            _close(heat2, ref["phi_heat"], RATE_RTOL)
+        elif nbox2 == ref["nsubbox"]:       # same boxes swept: same rates (the oracle's loss beyond the radius is the reference's undefined one)
+            _close(phi2, ref["phi_ion"], RATE_RTOL)
+        seen_multi_box += nbox2 > ns
+    assert seen_multi_box >= 8

@@ -25,6 +25,7 @@ ap.add_argument("--workload", default="uniform")
 ap.add_argument("--loss-fraction", type=float, default=1e-2)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--global-shells", type=int, default=0, help="1: ASORA_OPT_SUBBOX_GLOBAL_SHELLS (shell buffers in global memory)")
+ap.add_argument("--tables", type=int, default=0, help="ASORA_OPT_SUBBOX_TABLES: 0 auto, 1 on-the-fly geometry only (round 2), 2 tabulated whenever possible")
 a = ap.parse_args()
 
 N, ns = a.N, a.nsrc
@@ -36,6 +37,7 @@ nd_f, xh_f = np.asfortranarray(ndens), np.asfortranarray(xh)
 zeros = np.zeros(thin.shape[0])
 
 asora.set_option(9, a.global_shells)      # ASORA_OPT_SUBBOX_GLOBAL_SHELLS
+asora.set_option(14, a.tables)            # ASORA_OPT_SUBBOX_TABLES
 for R in a.R:
     sub = int(R)
     phi = np.zeros((N, N, N), order="F")
@@ -63,6 +65,7 @@ for R in a.R:
            "roofline_sweep_kernel": {"bound": "hbm", "algorithmic_bytes_per_call": algo_bytes, "rated_cells": rated, "swept_cells": swept,
                                      "achieved_GBs": algo_bytes / (k_ms / a.reps * 1e-3) / 1e9, "peak_GBs": 8000.0,
                                      "frac": algo_bytes / (k_ms / a.reps * 1e-3) / 1e9 / 8000.0}, "shell_buffers": "global memory" if a.global_shells else "LDS when they fit",
+           "geometry": {0: "auto", 1: "on the fly (subbox.hip)", 2: "tabulated (raytrace.hip SUBBOX) + on the fly for the dumped source"}[a.tables],
            "sources": ns, "R": R, "subboxsize": sub, "loss_fraction": a.loss_fraction, "s_per_call": t_gpu,
            "sweep_kernels_ms_per_call": k_ms / a.reps, "sweep_launches_per_call": k_n / a.reps,
            "nsubbox": nbox, "photon_loss": loss}
