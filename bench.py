@@ -238,8 +238,12 @@ def main():
     ap.add_argument("--nsrc", type=int, default=1000, help="sources: in total (strong scaling) or per GPU (weak scaling)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N>1: strong = --nsrc sources in total sharded over the ranks (the metric), weak = --nsrc per rank")
-    ap.add_argument("--exchange", choices=["slab", "allreduce"], default="slab",
-                    help="N>1: how the per-rank rates are summed (see the module docstring)")
+    ap.add_argument("--exchange", choices=["auto", "slab", "allreduce"], default="auto",
+                    help="N>1: how the per-rank rates are summed (see the module docstring); auto = whichever the byte model "
+                         "of pyc2ray_amd/dist.py makes cheaper for this (ranks, mesh, radius, sources), printed in config")
+    ap.add_argument("--slab-chunks", type=int, default=0,
+                    help="N>1, slab exchange: trace chunks per step; planes final after a chunk travel while the next is traced "
+                         "(1 = no overlap; 0 = TorchComm's default: 2 with two ranks, else 1)")
     ap.add_argument("--R", type=float, default=32.0)
     ap.add_argument("--workload", choices=["uniform", "cosmo"], default=None,
                     help="default: uniform (configs[2]) on one GPU, cosmo (configs[3]) on several")
@@ -306,6 +310,7 @@ def main():
         # (rehearsal of the multi-rank logic on a box with ONE GPU: PYC2RAY_AMD_BENCH_BACKEND=gloo puts every rank on
         #  device PYC2RAY_AMD_BENCH_DEVICE and stages the sums through the host; never the measured configuration)
         backend = os.environ.get("PYC2RAY_AMD_BENCH_BACKEND", "nccl")
+        os.environ.setdefault("PYC2RAY_AMD_DIST_TIMEOUT_S", "180")     # a collective that never completes ends the run after 3 minutes
         init_process_group_from_env(backend)
         comm = TorchComm()
 
@@ -317,7 +322,8 @@ def main():
 
     ndens, xh, temp, dr, pos, flux = make_workload(args.workload, N, nsrc_total)
     overlap = comm is not None and (args.overlap == 1 or (args.overlap < 0 and comm.overlap))
-    slab = comm is not None and args.exchange == "slab" and not overlap
+    slab = comm is not None and args.exchange in ("slab", "auto") and not overlap
+    exchange_model = None
     src_i0 = None
     plan = None
     if slab:
@@ -329,6 +335,34 @@ def main():
             bounds = [r * args.nsrc for r in range(world + 1)]
         lo, hi = bounds[rank], bounds[rank + 1]
         plan = SlabPlan(N, world, args.R, [pos[0, bounds[r]:bounds[r + 1]] - 1 for r in range(world)])
+        if args.slab_chunks > 0:
+            comm.slab_chunks = args.slab_chunks
+        # what each scheme moves per step over its busiest link, and what that costs at two assumed link rates (the build box
+        # has one GPU: no rate was ever measured); ring all-reduce: 2 (P-1) steps of N^3/P doubles over one link each
+        K = plan.common_chunks(comm.slab_chunks)
+        link = plan.largest_transfer()
+        sched = [plan.send_schedule(r, K) for r in range(world)]
+        early = [sum((b - a) for pieces in sc[:-1] for _, a, b in pieces) for sc in sched]
+        total = [sum((b - a) for pieces in sc for _, a, b in pieces) for sc in sched]
+        hidden = min((e / t) if t else 1.0 for e, t in zip(early, total))          # share of exchange 1 that leaves before the last chunk
+        ring = 2.0 * (world - 1) / world * 8.0 * N ** 3
+        exchange_model = {
+            "slab_bytes_per_link_and_exchange": link, "slab_exchanges_per_step": 2, "slab_trace_chunks": K,
+            "slab_share_of_rate_exchange_sent_before_the_last_chunk": hidden,
+            "allreduce_ring_bytes_per_link_per_step": ring,
+            "assumed_link_GBs": [50.0, 100.0],
+            "slab_comm_ms": [2.0 * link / (g * 1e6) for g in (50.0, 100.0)],
+            "slab_comm_ms_with_overlap": [(2.0 - hidden) * link / (g * 1e6) for g in (50.0, 100.0)],
+            "allreduce_comm_ms": [ring / (g * 1e6) for g in (50.0, 100.0)],
+            "note": "bytes are exact (SlabPlan); the rates are assumptions; the slab scheme also runs 1/P of the chemistry per rank",
+        }
+        if args.exchange == "auto" and 2.0 * link > ring:
+            slab = False                         # (every rank reaches nearly every plane: the exchange moves no less than the ring)
+        exchange_model["choice"] = "slab" if slab else "allreduce"
+    if comm is not None and not slab:
+        comm.exchange = "allreduce"
+    if slab:
+        pass
     elif strong:
         per = nsrc_total // world                                    # evolve.py:362-367
         lo, hi = rank * per, ((rank + 1) * per if rank != world - 1 else nsrc_total)
@@ -383,24 +417,39 @@ def main():
             comm.Barrier()
             torch.cuda.synchronize()
 
+    fell_back = None
     if comm is not None and state["slab"]:
-        # The point-to-point exchange has never run between real GPUs (the build box has one).  If it raises on any rank
-        # in its first step, every rank falls back to the full-grid all-reduce (any partition of the sources is fine for
-        # it) instead of losing the run; which path ran is in the JSON (`config.parallelism`).
-        ok = 1.0
-        try:
-            begin_time_step(); step(); fence()
-        except Exception as e:
-            print(f"bench: slab exchange failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
-            ok = 0.0
+        # The point-to-point exchange has never run between real GPUs (the build box has one).  Two gates, each followed by
+        # a vote (MIN over the ranks): a one-plane ring of sends and receives through the same torch call, then the first
+        # full step.  If either raises or delivers a wrong payload on ANY rank, every rank takes the full-grid all-reduce
+        # (any partition of the sources is fine for it) instead of losing the run; which path ran, and why, is in the JSON
+        # (`config.parallelism`, `config.exchange_fallback`).  Nothing is re-executed: the process keeps its GPU context.
         import torch
         import torch.distributed as dist
-        flag = torch.tensor([ok], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if float(flag.item()) == 0.0:
-            state["slab"] = False
-            slab = False
-            comm.exchange = "allreduce"
+
+        def all_ranks_ok(ok):
+            flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return float(flag.item()) != 0.0
+
+        for gate in ("point-to-point preflight", "first slab step"):
+            ok = True
+            try:
+                if gate == "point-to-point preflight":
+                    ok = comm.preflight_p2p(N * N)
+                else:
+                    begin_time_step(); step(); fence()
+            except Exception as e:
+                print(f"bench: {gate} failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
+                ok = False
+            if not all_ranks_ok(ok):
+                state["slab"] = False
+                slab = False
+                comm.exchange = "allreduce"
+                fell_back = gate
+                if exchange_model is not None:
+                    exchange_model["choice"] = "allreduce (fallback)"
+                break
     # the FIRST iteration of a time step additionally forms nHI from xh and zeroes the accumulators on the whole grid
     begin_time_step(); step(); fence()
     t0 = time.perf_counter()
@@ -518,10 +567,14 @@ def main():
             "ranks_agree_on_rates_and_ionised_fraction": ranks_agree,
             "parallelism": ("single GPU" if world == 1 else
                             f"sources sharded over {world} ranks by slab of the first coordinate; rates sent plane-wise to the "
-                            "owners of the planes, slab chemistry, xh_av sent back (pyc2ray_amd/dist.py SlabPlan)" if slab else
+                            f"owners of the planes (trace in {plan.common_chunks(comm.slab_chunks)} chunks, final planes sent while the next "
+                            "chunk is traced), slab chemistry, xh_av sent back (pyc2ray_amd/dist.py SlabPlan)" if slab else
                             f"sources x{world}, rate-grid all-reduce " + ("pipelined with the trace" if overlap else "after the trace")
                             + ", chemistry on every rank"),
             "comm_bytes_per_rank_per_step": comm_bytes,
+            "exchange_requested": args.exchange if world > 1 else None,
+            "exchange_model": exchange_model,
+            "exchange_fallback": fell_back,
             "unit_definition": "rate-receiving (source,cell) pairs (|d|<=R) + N^3 chemistry cells per step",
             "raytrace_updates_per_step": tot_gamma,
             "chemistry_updates_per_step": N ** 3,

@@ -233,6 +233,7 @@ static int rt_begin(double R, double sig, double dr, double minlogtau, double dl
     p.dump = dump;
     st.rt_heat = heat;
     st.rt_pipelined = pipelined;
+    st.rt_by_planes = false;
     if (pipelined) {       // the side streams start behind the zeroed accumulators and nHI
         ASORA_HIP_TRY(hipEventRecord(st.main_ready, st.stream));
         for (int q = 0; q < 2; ++q) {
@@ -259,8 +260,9 @@ static int rt_range(int src_begin, int src_count)
     // the whole list: in the spatially ordered copy (a column-density dump is of the caller's LAST source: caller's order)
     if (src_begin == 0 && src_count == st.num_src && st.src_pos_sorted && !p.dump) { p.src_pos = st.src_pos_sorted; p.src_flux = st.src_flux_sorted; }
     p.src_begin = src_begin; p.src_count = src_count;
-    // one launch shape (one set of geometry tables) per call: a pipelined call is sized by all of the rank's sources
-    p.shape_src_count = st.rt_pipelined ? st.num_src : src_count;
+    // one launch shape (one set of geometry tables) per call: a call that traces its sources in several ranges (pipelined
+    // all-reduce, chunked slab exchange) is sized by all of the rank's sources
+    p.shape_src_count = (st.rt_pipelined || st.rt_by_planes) ? st.num_src : src_count;
     if (!st.rt_pipelined) return launch_raytrace(st, p, p.dump != nullptr, st.rt_heat);
     const int q = st.side_next;
     st.side_next ^= 1;
@@ -435,11 +437,20 @@ static int subbox_core(const SubboxCall &c, long long &total_nbox, double &total
             p.s_end = (int)std::min<long long>(box, S_all);
             p.edge_r = (int)std::min<long long>(box, ext_r);
             p.edge_l = (int)std::min<long long>(box, ext_l);
-            if (fly_count > 0) { if (int rc = launch_subbox_sweep(st, p)) return rc; }
+            // the dumped source's sweep (8 wide workgroups: as long as ONE workgroup lasts) runs beside the tabulated sweep of
+            // all the others, on a side stream; both add into the same rate grids
+            const bool beside = fly_count > 0 && tab.ok && tp.src_count > 0;
+            if (beside) {
+                ASORA_HIP_TRY(hipEventRecord(st.main_ready, st.stream));
+                ASORA_HIP_TRY(hipStreamWaitEvent(st.side[0], st.main_ready, 0));
+            }
+            if (fly_count > 0) { if (int rc = launch_subbox_sweep(st, p, beside ? st.side[0] : nullptr)) return rc; }
+            if (beside) ASORA_HIP_TRY(hipEventRecord(st.side_done[0], st.side[0]));
             if (tab.ok && tp.src_count > 0) {
                 tp.sb_edge_r = p.edge_r; tp.sb_edge_l = p.edge_l;
                 if (int rc = subbox_tables_sweep(st, tp, tab, p.s_begin, p.s_end, c.heat)) return rc;
             }
+            if (beside) ASORA_HIP_TRY(hipStreamWaitEvent(st.stream, st.side_done[0], 0));
             const int more_range = (box < ext_r && box < ext_l) ? 1 : 0;          // f90:194-195
             if (int rc = launch_subbox_decide(st, 1, batch, c.src_flux, first, (double)c.loss_fraction, more_range,
                                               st.sb_active, st.sb_loss, st.sb_loss_final, st.sb_nbox, st.sb_nactive)) return rc;
@@ -948,6 +959,7 @@ int asora_raytrace_begin_planes(double R, double sig, double dr, double minlogta
     fill_rt_params(st.rt_params, R, sig, dr, minlogtau, dlogtau, NumTau);
     st.rt_heat = false;
     st.rt_pipelined = false;
+    st.rt_by_planes = true;
     st.rt_open = true;
     return 0;
 }

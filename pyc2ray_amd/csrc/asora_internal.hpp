@@ -141,6 +141,7 @@ struct State {
     // pipelined calls put consecutive source ranges on two side streams, so that the tail of one range and the
     // head of the next overlap; folds (main stream) wait for the ranges issued before them
     bool rt_pipelined = false;
+    bool rt_by_planes = false;              // begun by asora_raytrace_begin_planes: ranges share one launch shape
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t side_done[2] = {nullptr, nullptr}, main_ready = nullptr;
     bool side_pending[2] = {false, false};
@@ -270,7 +271,7 @@ struct SubboxParams {
     const int *active;          // per source of the batch
     double *loss;               // per source of the batch: photons through the current box faces
 };
-int launch_subbox_sweep(State &st, const SubboxParams &p);
+int launch_subbox_sweep(State &st, const SubboxParams &p, hipStream_t side = nullptr);   // side: the stream to launch on (default: the library's)
 int launch_subbox_decide(State &st, int mode, int count, const double *src_flux, int src_begin, double loss_fraction,
                          int more_range, int *active, double *loss, double *loss_final, int *nbox, int *n_active);
 

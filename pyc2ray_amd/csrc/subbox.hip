@@ -289,13 +289,13 @@ __global__ void subbox_decide_kernel(int mode, int count, const double *src_flux
 #endif
 
 template <int T>
-static int launch_subbox_variant(State &st, const SubboxParams &p, unsigned grid, bool lds, size_t lds_bytes)
+static int launch_subbox_variant(State &st, const SubboxParams &p, unsigned grid, bool lds, size_t lds_bytes, hipStream_t stream)
 {
 #define ASORA_SB_LAUNCH(HT, LD)                                                                                          \
     do {                                                                                                                 \
         if (LD) ASORA_HIP_TRY(hipFuncSetAttribute((const void *)subbox_sweep_kernel<T, HT, LD>,                          \
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));          \
-        hipLaunchKernelGGL((subbox_sweep_kernel<T, HT, LD>), dim3(grid), dim3(T), LD ? lds_bytes : 0, st.stream, p);     \
+        hipLaunchKernelGGL((subbox_sweep_kernel<T, HT, LD>), dim3(grid), dim3(T), LD ? lds_bytes : 0, stream, p);        \
     } while (0)
     if (p.heat) { if (lds) ASORA_SB_LAUNCH(true, true); else ASORA_SB_LAUNCH(true, false); }
     else        { if (lds) ASORA_SB_LAUNCH(false, true); else ASORA_SB_LAUNCH(false, false); }
@@ -304,17 +304,18 @@ static int launch_subbox_variant(State &st, const SubboxParams &p, unsigned grid
     return 0;
 }
 
-int launch_subbox_sweep(State &st, const SubboxParams &p)
+int launch_subbox_sweep(State &st, const SubboxParams &p, hipStream_t side)
 {
     const unsigned grid = 64u * (unsigned)((p.src_count + 7) / 8);
-    KernelTimer kt(ASORA_KERNEL_RAYTRACE);
+    hipStream_t stream = side ? side : st.stream;
+    KernelTimer kt(ASORA_KERNEL_RAYTRACE, stream);
     // both shell buffers in LDS up to 56 KB per workgroup (W <= 34: a +-32 box, the benchmark's)
     const size_t lds_bytes = (size_t)6 * p.W * p.W * sizeof(double);
     const bool lds = lds_bytes <= 56 * 1024 && !st.opt[ASORA_OPT_SUBBOX_GLOBAL_SHELLS];
-    if ((long)p.src_count * 8 < (long)st.cu_count) return launch_subbox_variant<1024>(st, p, grid, lds, lds_bytes);
+    if ((long)p.src_count * 8 < (long)st.cu_count) return launch_subbox_variant<1024>(st, p, grid, lds, lds_bytes, stream);
     // small boxes: shells of a few hundred cells fill 128 threads better (+-16: 0.65 -> 0.59 ms per 1000 sources; +-32: 256)
-    if (ASORA_SB_THREADS == 256 && p.W <= 20) return launch_subbox_variant<128>(st, p, grid, lds, lds_bytes);
-    return launch_subbox_variant<ASORA_SB_THREADS>(st, p, grid, lds, lds_bytes);
+    if (ASORA_SB_THREADS == 256 && p.W <= 20) return launch_subbox_variant<128>(st, p, grid, lds, lds_bytes, stream);
+    return launch_subbox_variant<ASORA_SB_THREADS>(st, p, grid, lds, lds_bytes, stream);
 }
 
 int launch_subbox_decide(State &st, int mode, int count, const double *src_flux, int src_begin, double loss_fraction,

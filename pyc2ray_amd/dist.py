@@ -89,42 +89,105 @@ class SlabPlan:
         which needs it to form nHI for its next raytrace;
       * the three convergence scalars are summed over ranks in rank order (identical on every rank).
 
-    Planes travel as contiguous runs (plane i is N*N consecutive doubles of the [i][j][k] grid); the run for a pair
-    (r, q) is the shortest run inside own[q] that covers reach[r] & own[q] (zeros in between are harmless).  At 256^3,
-    R = 32, 8 ranks with evenly spread sources a rank sends and receives 2 x 32 planes per exchange (2 x 33.5 MiB
-    in, the same out, to and from its two neighbours over their direct xGMI links) instead of taking part in a
-    ring all-reduce of 128 MiB (224 MiB in and out per rank), and runs 1/8 of the chemistry.  With R >= N/2 every
-    rank reaches every plane and the scheme degenerates into reduce-scatter + all-gather by direct sends.
+    Planes travel as contiguous runs (plane i is N*N consecutive doubles of the [i][j][k] grid); for a pair (r, q)
+    these are the maximal runs of reach[r] inside own[q], runs closer than MERGE_GAP planes joined (zeros in between are
+    harmless, every run is a message) -- usually one, two when r's sources reach q's slab from both sides around the
+    periodic box (two ranks: always).  At 256^3, R = 32, 8 ranks with evenly spread sources a rank sends and receives
+    2 x 32 planes per exchange (2 x 16.8 MiB in, the same out, to and from its two neighbours over their direct xGMI
+    links) instead of taking part in a ring all-reduce of 128 MiB (224 MiB in and out per rank), and runs 1/8 of the
+    chemistry.  With R >= N/2 every rank reaches every plane and the scheme degenerates into reduce-scatter +
+    all-gather by direct sends.
+
+    Overlap (``send_schedule``): a rank traces its sources -- ordered by first coordinate -- in K chunks; a foreign plane
+    that no LATER chunk can reach is final, is folded and sent at once, while the next chunk is being traced.  Which
+    planes go after which chunk is again a function of the plan only, so the receiver posts the matching receives
+    without being told.
 
     Everything here is a function of (N, P, R, first coordinates of the sorted sources) only, so every rank derives
     the same plan without communicating."""
 
+    #: runs of reached planes closer than this are sent as one run
+    MERGE_GAP = 4
+
     def __init__(self, N, nprocs, R, shard_i0):
-        """shard_i0[r]: 0-based first coordinates of the sources of rank r."""
+        """shard_i0[r]: 0-based first coordinates of the sources of rank r, in the order they are uploaded (ascending
+        when the chunked schedule is used)."""
         self.N, self.P = int(N), int(nprocs)
         N, P = self.N, self.P
         self.own = [(q * N // P, (q + 1) * N // P) for q in range(P)]
         m = int(np.floor(R)) if np.isfinite(R) else N
-        lo, hi = min(m, N // 2), min(m, N // 2 - 1 + N % 2)          # the periodic window, raytracing.cu:122-123
-        self.reach = []
-        for r in range(P):
-            mask = np.zeros(N, dtype=bool)
-            i0 = np.unique(np.asarray(shard_i0[r], dtype=np.int64))
-            if i0.size:
-                if lo + hi + 1 >= N:
-                    mask[:] = True
-                else:
-                    for d in range(-lo, hi + 1):
-                        mask[(i0 + d) % N] = True
-            self.reach.append(mask)
-        # run[r][q]: planes rank r contributes to (and needs back from) the slab of rank q, or None
-        self.run = [[None] * P for _ in range(P)]
+        self._lo, self._hi = min(m, N // 2), min(m, N // 2 - 1 + N % 2)          # the periodic window, raytracing.cu:122-123
+        self.i0 = [np.asarray(shard_i0[r], dtype=np.int64) for r in range(P)]
+        self.reach = [self._reach_of(self.i0[r]) for r in range(P)]
+        # runs[r][q]: runs of planes rank r contributes to (and needs back from) the slab of rank q
+        self.runs = [[[] for _ in range(P)] for _ in range(P)]
         for r in range(P):
             for q in range(P):
                 a, b = self.own[q]
-                idx = np.flatnonzero(self.reach[r][a:b])
-                if idx.size:
-                    self.run[r][q] = (a + int(idx[0]), a + int(idx[-1]) + 1)
+                merged = []
+                for s0, s1 in _runs_of(self.reach[r][a:b]):
+                    if merged and s0 - merged[-1][1] < self.MERGE_GAP:
+                        merged[-1] = (merged[-1][0], s1)
+                    else:
+                        merged.append((s0, s1))
+                self.runs[r][q] = [(a + s0, a + s1) for s0, s1 in merged]
+
+    def _reach_of(self, i0):
+        """Planes the sources at first coordinates i0 can rate."""
+        mask = np.zeros(self.N, dtype=bool)
+        i0 = np.unique(np.asarray(i0, dtype=np.int64))
+        if i0.size:
+            if self._lo + self._hi + 1 >= self.N:
+                mask[:] = True
+            else:
+                for d in range(-self._lo, self._hi + 1):
+                    mask[(i0 + d) % self.N] = True
+        return mask
+
+    def common_chunks(self, K):
+        """The chunk count every rank uses: K when every rank's sources are in ascending order of their first coordinate
+        (a rank with fewer sources than chunks simply has empty chunks), else 1 -- nothing is final before the end then."""
+        if any(np.any(np.diff(i0) < 0) for i0 in self.i0):
+            return 1
+        return max(1, int(K))
+
+    @staticmethod
+    def chunk_bounds(n, K):
+        """Rank-local source ranges [b[c], b[c+1]) of the K trace chunks (equal counts, upload order)."""
+        return [c * n // K for c in range(K + 1)]
+
+    def send_schedule(self, r, K):
+        """sched[c] = [(q, a, b), ...]: the pieces of runs[r][q] (q != r) rank r sends once it has traced its chunks
+        0..c -- the planes no later chunk reaches, not sent before; the last chunk sends everything that is left.  Every
+        plane of every run is sent exactly once."""
+        K = max(1, int(K))
+        n = self.i0[r].size
+        b = self.chunk_bounds(n, K)
+        sent = np.zeros(self.N, dtype=bool)
+        sched = []
+        for c in range(K):
+            later = self._reach_of(self.i0[r][b[c + 1]:]) if c < K - 1 else np.zeros(self.N, dtype=bool)
+            pieces = []
+            for q in range(self.P):
+                if q == r:
+                    continue
+                for a0, a1 in self.runs[r][q]:
+                    ready = ~later[a0:a1] & ~sent[a0:a1]
+                    for s0, s1 in _runs_of(ready):
+                        pieces.append((q, a0 + s0, a0 + s1))
+                        sent[a0 + s0:a0 + s1] = True
+            sched.append(pieces)
+        return sched
+
+    def recv_schedule(self, q, K):
+        """rsched[c] = [(r, a, b), ...]: what the other ranks send to q after their chunk c (rank order)."""
+        out = [[] for _ in range(max(1, int(K)))]
+        for r in range(self.P):
+            if r == q:
+                continue
+            for c, pieces in enumerate(self.send_schedule(r, K)):
+                out[c] += [(r, a, b) for (dest, a, b) in pieces if dest == q]
+        return out
 
     def work_runs(self, r):
         """Planes rank r zeroes its accumulators on and forms nHI on: what its sources reach plus what it owns."""
@@ -139,9 +202,14 @@ class SlabPlan:
     def bytes_per_rank(self, r):
         """(sent, received) by rank r in ONE of the two exchanges of an iteration, in bytes."""
         plane = 8 * self.N * self.N
-        sent = sum((b - a) for q, run in enumerate(self.run[r]) if run and q != r for a, b in [run])
-        recv = sum((b - a) for q in range(self.P) if q != r and self.run[q][r] for a, b in [self.run[q][r]])
+        sent = sum((b - a) for q in range(self.P) if q != r for a, b in self.runs[r][q])
+        recv = sum((b - a) for q in range(self.P) if q != r for a, b in self.runs[q][r])
         return sent * plane, recv * plane
+
+    def largest_transfer(self):
+        """Bytes of the largest rank-to-rank transfer of one exchange (what a single xGMI link carries in one direction)."""
+        plane = 8 * self.N * self.N
+        return plane * max([sum(b - a for a, b in self.runs[r][q]) for r in range(self.P) for q in range(self.P) if q != r] or [0])
 
 
 class _DevicePointer:
@@ -176,6 +244,13 @@ class TorchComm:
         #: how the per-rank rate grids are summed: "slab" (SlabPlan: planes to their owners, slab chemistry, xh_av
         #: back) or "allreduce" (full-grid all-reduce, chemistry replicated on every rank)
         self.exchange = os.environ.get("PYC2RAY_AMD_EXCHANGE", "slab")
+        #: slab exchange: trace chunks per iteration; planes that are final after a chunk travel while the next is traced
+        # (measured per-rank compute + modelled links, tools/slab_compute_model.py, profiles/r03_slab_model_chunks.txt: splitting
+        #  the trace costs more than the early sends hide from four ranks on -- 125 sources per launch no longer fill the chip
+        #  -- and gains ~15 % with two ranks)
+        self.slab_chunks = int(os.environ.get("PYC2RAY_AMD_SLAB_CHUNKS", "2" if self._dist.get_world_size(group) == 2 else "1"))
+        #: every rank derives the convergence decision from the SAME all-reduced scalars (no broadcast of the decision needed)
+        self.identical_scalars = True
         # Bring the communicator up with a collective EVERY rank takes part in.  The slab exchange is point-to-point
         # and a rank with nothing to send or receive skips it; if that were the first operation on the process group,
         # the ranks that do take part would wait for the others in the communicator's set-up.
@@ -256,6 +331,27 @@ class TorchComm:
             libasora.grid_to_device(which, host)
 
 
+    def preflight_p2p(self, nelem=65536):
+        """One small point-to-point round (every rank sends to its right neighbour and receives from its left one) through
+        the same call the slab exchange uses.  The exchange has never run between real GPUs on the build box; a caller
+        that gets an exception here (or False from any rank, after a MIN-reduce of the results) takes the all-reduce path.
+        Returns True when the round went through on this rank and the payload arrived intact."""
+        import torch
+        dist = self._dist
+        P, me = self.Get_size(), self.Get_rank()
+        if P < 2:
+            return True
+        dev = "cuda" if self._backend() == "nccl" else "cpu"
+        out = torch.full((nelem,), float(me + 1), dtype=torch.float64, device=dev)
+        inc = torch.zeros((nelem,), dtype=torch.float64, device=dev)
+        ops = [dist.P2POp(dist.isend, out, (me + 1) % P, group=self._group),
+               dist.P2POp(dist.irecv, inc, (me - 1) % P, group=self._group)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if dev == "cuda":
+            torch.cuda.synchronize()
+        return bool((inc == float((me - 1) % P + 1)).all().item())
+
     # -- slab exchange: rates to the owners of the planes, ionised fraction back (see SlabPlan) -------------------
     @staticmethod
     def shard_sources_by_slab(src_pos, src_flux, nprocs):
@@ -273,89 +369,115 @@ class TorchComm:
         import torch
         return torch.as_tensor(_DevicePointer(libasora.device_ptr(which), N ** 3), device="cuda").view(N, N * N)
 
-    def _exchange(self, libasora, plan, which, N, direction):
-        """direction 'to_owner': rank r sends run[r][q] of grid `which` to q, q ADDS run[r][q] of every r (rank order).
-        direction 'from_owner': owner q sends run[r][q] to r, which stores it in place."""
+    def _post(self, libasora, which, N, sends, recvs, add, tag):
+        """Start one round of plane transfers of grid `which`: `sends` = [(peer, a, b)] planes [a, b) to peer, `recvs` =
+        [(peer, a, b)] planes from peer.  Returns a handle for ``_complete``.  With RCCL everything is ordered on the
+        library's stream: the sends start behind the kernels that produced the planes, and nothing waits on the host; the
+        transfers themselves run on RCCL's stream, beside whatever the library's stream does next.  add = True: what is
+        received is ADDED to the planes (in ``_complete``, in the order of `recvs`), else it replaces them."""
         import torch
         dist = self._dist
-        me, P = self.Get_rank(), plan.P
-        if direction == "to_owner":
-            sends = [(q, plan.run[me][q]) for q in range(P) if q != me and plan.run[me][q]]
-            recvs = [(q, plan.run[q][me]) for q in range(P) if q != me and plan.run[q][me]]
-        else:
-            sends = [(q, plan.run[q][me]) for q in range(P) if q != me and plan.run[q][me]]
-            recvs = [(q, plan.run[me][q]) for q in range(P) if q != me and plan.run[me][q]]
         if not sends and not recvs:
-            return
-        nccl = self._backend() == "nccl"
-        if nccl:
-            # everything is ordered on the library's stream: the collective starts behind the kernels that produced
-            # the planes and the kernels that consume them start behind it, without the host waiting for either
+            return None
+        if self._backend() == "nccl":
             lib_stream = torch.cuda.ExternalStream(libasora.stream_ptr())
             with torch.cuda.stream(lib_stream):
                 grid = self._planes_view(libasora, which, N)
-                if direction == "to_owner":
-                    key = ("stage", N, tuple(recvs))
-                    if getattr(self, "_stage_key", None) != key:       # staging kept between iterations
-                        self._stage = [torch.empty((b - a, N * N), dtype=torch.float64, device="cuda") for _, (a, b) in recvs]
-                        self._stage_key = key
-                    targets = self._stage
+                if add:
+                    key = (tag, N, tuple(recvs))
+                    cache = self.__dict__.setdefault("_stages", {})
+                    if key not in cache:                                   # staging kept between iterations
+                        cache[key] = [torch.empty((b - a, N * N), dtype=torch.float64, device="cuda") for _, a, b in recvs]
+                    targets = cache[key]
                 else:
-                    targets = [grid[a:b] for _, (a, b) in recvs]
-                ops = [dist.P2POp(dist.isend, grid[a:b], q, group=self._group) for q, (a, b) in sends]
-                ops += [dist.P2POp(dist.irecv, t, q, group=self._group) for (q, _), t in zip(recvs, targets)]
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
-                if direction == "to_owner":
-                    for (q, (a, b)), t in zip(recvs, targets):         # fixed (rank) order: same bits on every run
+                    targets = [grid[a:b] for _, a, b in recvs]
+                ops = [dist.P2POp(dist.isend, grid[a:b], q, group=self._group) for q, a, b in sends]
+                ops += [dist.P2POp(dist.irecv, t, q, group=self._group) for (q, _, _), t in zip(recvs, targets)]
+                works = dist.batch_isend_irecv(ops)
+            return ("nccl", works, recvs, targets, add)
+        # gloo (CPU tests, several ranks on one GPU): staged through the host
+        out = [torch.from_numpy(libasora.planes_to_host(which, a, b - a, N)) for _, a, b in sends]
+        inc = [torch.empty((b - a, N, N), dtype=torch.float64) for _, a, b in recvs]
+        ops = [dist.P2POp(dist.isend, t, q, group=self._group) for (q, _, _), t in zip(sends, out)]
+        ops += [dist.P2POp(dist.irecv, t, q, group=self._group) for (q, _, _), t in zip(recvs, inc)]
+        works = dist.batch_isend_irecv(ops)
+        return ("gloo", works, recvs, inc, add, out)
+
+    def _complete(self, libasora, which, N, handle):
+        """Wait for a round started by ``_post`` and put what was received in place (fixed order: same bits on every run)."""
+        import torch
+        if handle is None:
+            return
+        kind, works, recvs, targets, add = handle[:5]
+        if kind == "nccl":
+            lib_stream = torch.cuda.ExternalStream(libasora.stream_ptr())
+            with torch.cuda.stream(lib_stream):
+                for w in works:
+                    w.wait()                       # the library's stream waits, not the host
+                if add:
+                    grid = self._planes_view(libasora, which, N)
+                    for (q, a, b), t in zip(recvs, targets):
                         grid[a:b] += t
             return
-        # gloo (CPU tests, several ranks on one GPU): staged through the host
-        out = [torch.from_numpy(libasora.planes_to_host(which, a, b - a, N)) for _, (a, b) in sends]
-        inc = [torch.empty((b - a, N, N), dtype=torch.float64) for _, (a, b) in recvs]
-        ops = [dist.P2POp(dist.isend, t, q, group=self._group) for (q, _), t in zip(sends, out)]
-        ops += [dist.P2POp(dist.irecv, t, q, group=self._group) for (q, _), t in zip(recvs, inc)]
-        for w in dist.batch_isend_irecv(ops):
+        for w in works:
             w.wait()
-        for (q, (a, b)), t in zip(recvs, inc):
-            if direction == "to_owner":
+        for (q, a, b), t in zip(recvs, targets):
+            if add:
                 mine = libasora.planes_to_host(which, a, b - a, N)
                 libasora.planes_to_device(which, a, mine + t.numpy())
             else:
                 libasora.planes_to_device(which, a, t.numpy())
 
+    def _sum_scalars(self, part):
+        """Sum of (conv_flag, sum x, sum 1-x) over the ranks: ONE all-reduce of three doubles and one read-back (the result
+        of an all-reduce is the same on every rank, so every rank takes the same convergence decision)."""
+        import torch
+        t = torch.tensor([float(part[0]), float(part[1]), float(part[2])], dtype=torch.float64)
+        if self._backend() == "nccl":
+            t = t.cuda()
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
+        v = t.cpu().tolist()
+        return int(round(v[0])), v[1], v[2]
+
     def slab_iteration(self, libasora, plan, N, R, sig, dr, num_src_local, minlogtau, dlogtau, NumTau, chemistry, first):
         """One outer iteration with the rates summed slab-wise: raytrace this rank's sources, send the rates to the
         owners of the planes, chemistry on the own slab, send the new xh_av back to the ranks that trace through it.
         Returns (conv_flag, sum x, sum 1-x) over the WHOLE grid, identical on every rank.  `first`: the first
-        iteration of a time step (accumulators and nHI are set up on the whole grid)."""
-        import torch
+        iteration of a time step (accumulators and nHI are set up on the whole grid).
+
+        With self.slab_chunks = K > 1 (and the rank's sources uploaded in ascending order of their first coordinate, which
+        ``shard_sources_by_slab`` gives) the trace runs in K chunks and every foreign plane is sent as soon as no later
+        chunk can reach it (SlabPlan.send_schedule): the first exchange runs beside the trace."""
         from . import _capi
         me = self.Get_rank()
+        # every rank walks through the same number of rounds and derives every other rank's schedule: the chunk count is a
+        # function of the plan, never of this rank alone
+        K = plan.common_chunks(getattr(self, "slab_chunks", 1))
         if first:
             libasora.raytrace_begin_planes(R, sig, dr, minlogtau, dlogtau, NumTau, [(0, N)])
         else:
             libasora.raytrace_begin_planes(R, sig, dr, minlogtau, dlogtau, NumTau,
                                            [(a, b - a) for a, b in plan.work_runs(me)])
-        libasora.raytrace_range(0, num_src_local)
-        for a, b in plan.reach_runs(me):
-            libasora.raytrace_fold(a, b - a)
-        self._exchange(libasora, plan, _capi.GRID_PHI_ION, N, "to_owner")
+        sched, rsched = plan.send_schedule(me, K), plan.recv_schedule(me, K)
+        bounds = plan.chunk_bounds(num_src_local, K)
+        handles = []
+        for c in range(K):
+            libasora.raytrace_range(bounds[c], bounds[c + 1] - bounds[c])
+            for _, a, b in sched[c]:
+                libasora.raytrace_fold(a, b - a)                        # the z-face accumulator of the planes that leave now
+            handles.append(self._post(libasora, _capi.GRID_PHI_ION, N, sched[c], rsched[c], True, ("rates", c)))
         a, b = plan.own[me]
+        if b > a:
+            libasora.raytrace_fold(a, b - a)
+        for h in handles:                                               # chunk order, then rank order: a fixed order of additions
+            self._complete(libasora, _capi.GRID_PHI_ION, N, h)
         libasora.chemistry_range(*chemistry, a, b - a, True)
         part = libasora.chemistry_finish()
-        self._exchange(libasora, plan, _capi.GRID_XH_AV, N, "from_owner")
-        # the three scalars: gathered, then summed in rank order on the host
-        t = torch.tensor([float(part[0]), part[1], part[2]], dtype=torch.float64)
-        if self._backend() == "nccl":
-            t = t.cuda()
-        allp = [torch.empty_like(t) for _ in range(plan.P)]
-        self._dist.all_gather(allp, t, group=self._group)
-        tot = [0.0, 0.0, 0.0]
-        for q in range(plan.P):
-            v = allp[q].cpu().tolist()
-            tot = [tot[0] + v[0], tot[1] + v[1], tot[2] + v[2]]
-        return int(round(tot[0])), tot[1], tot[2]
+        # xh_av back: the owner q of a run sends it to the rank r that traces through it
+        sends = [(r, s0, s1) for r in range(plan.P) if r != me for s0, s1 in plan.runs[r][me]]
+        recvs = [(q, s0, s1) for q in range(plan.P) if q != me for s0, s1 in plan.runs[me][q]]
+        self._complete(libasora, _capi.GRID_XH_AV, N, self._post(libasora, _capi.GRID_XH_AV, N, sends, recvs, False, "xh_av"))
+        return self._sum_scalars(part)
 
     def slab_gather(self, libasora, plan, which, N):
         """Every rank gets every owner's slab of grid `which` (end of a time step: xh_intermed, phi_ion)."""

@@ -334,7 +334,9 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
 
         converged = (conv_flag < conv_criterion) or ((rel_change_xh1 < convergence_fraction) and
                                                      (rel_change_xh0 < convergence_fraction))
-        converged = _agree_on_convergence(comm, converged)            # evolve.py:484-489
+        if not (slab and getattr(comm, "identical_scalars", False)):
+            # (the slab path's three scalars come out of ONE all-reduce: the same bits, hence the same decision, on every rank)
+            converged = _agree_on_convergence(comm, converged)        # evolve.py:484-489
         prev_sum_xh1_int = sum_xh1_int
         prev_sum_xh0_int = sum_xh0_int
 

@@ -38,6 +38,9 @@ def main():
     assert (r, w) == (rank, world)
     comm = pd.TorchComm(overlap=overlap, chunks=4, pipeline_chemistry=overlap)
     comm.exchange = "slab" if slab else "allreduce"
+    for item in spec[1:]:
+        if item.startswith("k") and item[1:].isdigit():
+            comm.slab_chunks = int(item[1:])              # trace chunks of the overlapped slab exchange
     assert comm.Get_rank() == rank and comm.Get_size() == world
 
     # mpi4py-flavoured surface

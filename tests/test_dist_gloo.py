@@ -130,11 +130,46 @@ def test_slab_plan_covers_what_the_sources_reach():
             for q in range(P):
                 a, b = plan.own[q]
                 idx = np.flatnonzero(want[a:b])
+                runs = plan.runs[r][q]
                 if idx.size == 0:
-                    assert plan.run[r][q] is None
+                    assert runs == []
                 else:
-                    ra, rb = plan.run[r][q]
-                    assert a <= ra <= a + idx[0] and a + idx[-1] < rb <= b
+                    covered = np.zeros(N, dtype=bool)
+                    for ra, rb in runs:
+                        assert a <= ra < rb <= b and not covered[ra:rb].any()
+                        covered[ra:rb] = True
+                    assert covered[a:b][want[a:b]].all()                         # every reached plane travels
+                    assert want[[ra for ra, _ in runs]].all() and want[[rb - 1 for _, rb in runs]].all()   # runs start and end on reached planes
+                    assert len(runs) <= 1 + (want[a:b].size - int(want[a:b].sum())) // SlabPlan.MERGE_GAP
+            # the chunked schedule: every plane of every run leaves exactly once, and never while a later chunk can still reach it
+            for K in (1, 3, 4):
+                sched = plan.send_schedule(r, K)
+                assert len(sched) == K
+                bnd = plan.chunk_bounds(bounds[r + 1] - bounds[r], K)
+                mine = spos[0, bounds[r]:bounds[r + 1]] - 1
+                gone = np.zeros(N, dtype=int)
+                for c, pieces in enumerate(sched):
+                    later = np.zeros(N, dtype=bool)
+                    for i0 in mine[bnd[c + 1]:]:
+                        for d in range(-min(m, N // 2), min(m, N // 2 - 1 + N % 2) + 1):
+                            later[(i0 + d) % N] = True
+                    for q, pa, pb in pieces:
+                        assert q != r and plan.own[q][0] <= pa < pb <= plan.own[q][1]
+                        assert not later[pa:pb].any(), (trial, r, K, c)
+                        gone[pa:pb] += 1
+                want_gone = np.zeros(N, dtype=int)
+                for q in range(P):
+                    if q != r:
+                        for ra, rb in plan.runs[r][q]:
+                            want_gone[ra:rb] += 1
+                assert np.array_equal(gone, want_gone)
+                # what q expects from r is what r sends to q, chunk by chunk
+                for q in range(P):
+                    if q == r:
+                        continue
+                    rs = plan.recv_schedule(q, K)
+                    for c in range(K):
+                        assert [(pa, pb) for (src, pa, pb) in rs[c] if src == r] == [(pa, pb) for (dest, pa, pb) in sched[c] if dest == q]
             work = np.zeros(N, dtype=bool)
             for a, b in plan.work_runs(r):
                 work[a:b] = True
@@ -148,6 +183,11 @@ def test_slab_plan_covers_what_the_sources_reach():
     plan = SlabPlan(256, 8, 32.0, [spos[0, bounds[r]:bounds[r + 1]] - 1 for r in range(8)])
     per_exchange = max(plan.bytes_per_rank(r)[0] for r in range(8))
     assert per_exchange <= 70 * 256 * 256 * 8                       # ~2 x 32 planes of 512 KiB, against 2 x 7/8 x 128 MiB in a ring all-reduce
+    # two ranks: a rank reaches the other's slab from both sides around the periodic box -- two runs of ~32 planes, not the whole slab
+    spos, _, bounds = TorchComm.shard_sources_by_slab(pos, np.ones(1000), 2)
+    plan2 = SlabPlan(256, 2, 32.0, [spos[0, bounds[r]:bounds[r + 1]] - 1 for r in range(2)])
+    assert [len(plan2.runs[r][1 - r]) for r in range(2)] == [2, 2]
+    assert max(plan2.bytes_per_rank(r)[0] for r in range(2)) <= 68 * 256 * 256 * 8           # (64 MiB per exchange with one covering run)
 
 
 def _run_workers(tmp_path, world, mode, timeout=600):
@@ -171,6 +211,24 @@ def _slab_reference(N, ns, R):
     thin, thick, dlog = cases.soft_tables()
     return evolve3D_oracle(3.15576e13 * 5, dr, flux, pos, temp, nd, xh, thin, thick, cases.MINLOGTAU, dlog, R, 1e-4,
                            cases.SIG, cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C)
+
+
+@pytest.mark.parametrize("world,N,ns,R,chunks", [(2, 24, 13, 3.0, 3), (3, 33, 17, 4.0, 4), (4, 24, 21, 2.5, 2), (8, 32, 41, 2.0, 3),
+                                                 (2, 16, 9, 1000.0, 3), (4, 24, 5, 3.0, 4)])
+def test_overlapped_slab_exchange_matches_single_process(tmp_path, world, N, ns, R, chunks):
+    """The slab exchange with the trace in K chunks and every foreign plane sent as soon as no later chunk can reach it
+    (TorchComm.slab_chunks; SlabPlan.send_schedule).  A plane sent too early would miss the rates of a later chunk, a
+    plane folded twice trips the stand-in's assertion, a receive nobody sends hangs the job: same fields and iteration
+    count as the single-process oracle loop.  Includes a radius beyond the box (everything final only at the end) and
+    ranks with fewer sources than chunks (empty chunks)."""
+    res = _run_workers(tmp_path, world, f"slab:{N}:{ns}:{R}:k{chunks}")
+    for r in res[1:]:
+        assert np.array_equal(r["xh"], res[0]["xh"]) and np.array_equal(r["phi"], res[0]["phi"])
+        assert int(r["niter"]) == int(res[0]["niter"])
+    x_ref, phi_ref, niter_ref, _ = _slab_reference(N, ns, R)
+    assert int(res[0]["niter"]) == niter_ref and niter_ref >= 3
+    np.testing.assert_allclose(res[0]["xh"], x_ref, rtol=1e-10, atol=0)
+    np.testing.assert_allclose(res[0]["phi"], phi_ref, rtol=1e-10, atol=0)
 
 
 @pytest.mark.parametrize("world,N,ns,R", [(2, 16, 5, 6.0), (3, 17, 7, 2.5), (4, 24, 9, 3.0), (8, 16, 19, 2.0), (4, 16, 6, 1000.0)])
@@ -204,10 +262,11 @@ def test_mpi4py_shaped_communicator_takes_the_host_staged_branch(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,N,ns,R", [(2, 16, 5, 6.0), (4, 24, 9, 3.0)])
-def test_slab_exchange_with_the_hip_library(tmp_path, world, N, ns, R):
-    """The same with the HIP library under every rank (all on GPU 0, planes staged through the host by gloo)."""
-    res = _run_workers(tmp_path, world, f"slab:{N}:{ns}:{R}:real")
+@pytest.mark.parametrize("world,N,ns,R,chunks", [(2, 16, 5, 6.0, 1), (4, 24, 9, 3.0, 1), (2, 24, 13, 3.0, 3), (4, 32, 41, 2.5, 4)])
+def test_slab_exchange_with_the_hip_library(tmp_path, world, N, ns, R, chunks):
+    """The same with the HIP library under every rank (all on GPU 0, planes staged through the host by gloo), with and
+    without the chunked, overlapped first exchange."""
+    res = _run_workers(tmp_path, world, f"slab:{N}:{ns}:{R}:real:k{chunks}")
     for r in res[1:]:
         assert np.array_equal(r["xh"], res[0]["xh"]) and int(r["niter"]) == int(res[0]["niter"])
     x_ref, phi_ref, niter_ref, _ = _slab_reference(N, ns, R)

@@ -32,6 +32,7 @@ ap.add_argument("--nsrc", type=int, default=1000)
 ap.add_argument("--R", type=float, default=32.0)
 ap.add_argument("--link-GBs", type=float, default=50.0, help="assumed achieved point-to-point rate per direction and peer")
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--chunks", type=int, default=4, help="trace chunks of the overlapped slab exchange (TorchComm.slab_chunks)")
 a = ap.parse_args()
 N = a.N
 lib = load_asora()
@@ -59,36 +60,76 @@ for P in (1, 2, 4, 8):
         lib.raytrace_range(0, hi - lo)
         lib.synchronize()
         best = None
+        K = plan.common_chunks(a.chunks)
+        sched = plan.send_schedule(r, K)
+        cb = plan.chunk_bounds(hi - lo, K)
         for _ in range(a.reps):
             t0 = time.perf_counter()
             lib.raytrace_begin_planes(a.R, bench.SIG, dr, bench.MINLOGTAU, dlog, numtau, work)
-            lib.raytrace_range(0, hi - lo)
-            for x, y in plan.reach_runs(r):
-                lib.raytrace_fold(x, y - x)
+            for c in range(K):                       # exactly what TorchComm.slab_iteration issues between the exchanges
+                lib.raytrace_range(cb[c], cb[c + 1] - cb[c])
+                for _, x, y in sched[c]:
+                    lib.raytrace_fold(x, y - x)
+            x, y = plan.own[r]
+            lib.raytrace_fold(x, y - x)
             lib.synchronize()
             t1 = time.perf_counter()
-            x, y = plan.own[r]
             lib.chemistry_range(*chem, x, y - x, True)
             lib.chemistry_finish()
             t2 = time.perf_counter()
             cur = (t2 - t0, t1 - t0, t2 - t1)
             best = cur if best is None or cur[0] < best[0] else best
+        # when do the pieces of the rate exchange become available?  the same loop with a synchronisation after every chunk
+        ready = None
+        for _ in range(a.reps):
+            t0 = time.perf_counter()
+            lib.raytrace_begin_planes(a.R, bench.SIG, dr, bench.MINLOGTAU, dlog, numtau, work)
+            marks = []
+            for c in range(K):
+                lib.raytrace_range(cb[c], cb[c + 1] - cb[c])
+                for _, x, y in sched[c]:
+                    lib.raytrace_fold(x, y - x)
+                lib.synchronize()
+                marks.append(time.perf_counter() - t0)
+            ready = marks if ready is None or marks[-1] < ready[-1] else ready
+        # bytes per chunk on the busiest outgoing link of this rank
+        plane = 8 * N * N
+        per_peer = {}
+        for c in range(K):
+            for q, x, y in sched[c]:
+                per_peer.setdefault(q, [0] * K)[c] += (y - x) * plane
+        busiest = max(per_peer.values(), key=sum) if per_peer else [0] * K
         per_rank.append({"rank": r, "sources": hi - lo, "planes_worked_on": int(sum(c for _, c in work)), "own_planes": plan.own[r][1] - plan.own[r][0],
                          "compute_ms": best[0] * 1e3, "prepare_trace_fold_ms": best[1] * 1e3, "slab_chemistry_ms": best[2] * 1e3,
-                         "bytes_sent_per_exchange": plan.bytes_per_rank(r)[0], "bytes_received_per_exchange": plan.bytes_per_rank(r)[1]})
+                         "bytes_sent_per_exchange": plan.bytes_per_rank(r)[0], "bytes_received_per_exchange": plan.bytes_per_rank(r)[1],
+                         "chunk_ready_ms": [m * 1e3 for m in ready], "busiest_link_bytes_per_chunk": busiest})
     slow = max(per_rank, key=lambda q: q["compute_ms"])
-    peers = max(sum(1 for q in range(P) if q != r and (plan.run[r][q] or plan.run[q][r])) for r in range(P)) if P > 1 else 0
+    peers = max(sum(1 for q in range(P) if q != r and (plan.runs[r][q] or plan.runs[q][r])) for r in range(P)) if P > 1 else 0
     worst_bytes = max(max(q["bytes_sent_per_exchange"], q["bytes_received_per_exchange"]) for q in per_rank)
     # a rank's transfers to different peers use different links; the exchange lasts as long as its largest single transfer
-    largest_pair = max([(b - aa) * 8 * N * N for r in range(P) for q in range(P) if q != r and plan.run[r][q] for aa, b in [plan.run[r][q]]] or [0])
+    largest_pair = plan.largest_transfer()
     exch_ms = largest_pair / (a.link_GBs * 1e9) * 1e3
+    # the overlapped schedule: a link carries a rank's pieces one after the other, each from the moment its chunk is done;
+    # the chemistry of a slab starts when the slowest rank's last piece has arrived; the xh_av exchange is not overlapped
+    def overlapped_step_ms(link_GBs):
+        arrive = 0.0
+        for q in per_rank:
+            t = 0.0
+            for c, nbytes in enumerate(q["busiest_link_bytes_per_chunk"]):
+                if nbytes:
+                    t = max(t, q["chunk_ready_ms"][c]) + nbytes / (link_GBs * 1e9) * 1e3
+            arrive = max(arrive, t, q["prepare_trace_fold_ms"])
+        return arrive + max(q["slab_chemistry_ms"] for q in per_rank) + largest_pair / (link_GBs * 1e9) * 1e3
     rows.append({"ranks": P, "slowest_rank_compute_ms": slow["compute_ms"], "of_which_prepare_trace_fold_ms": slow["prepare_trace_fold_ms"],
+                 "trace_chunks": plan.common_chunks(a.chunks),
+                 "modelled_step_ms_overlapped": {f"{g:g} GB/s": (overlapped_step_ms(g) if P > 1 else slow["compute_ms"]) for g in (50.0, 100.0, 150.0)},
                  "of_which_slab_chemistry_ms": slow["slab_chemistry_ms"], "max_bytes_one_direction_per_exchange": worst_bytes,
                  "largest_single_transfer_bytes": largest_pair, "peers_of_the_busiest_rank": peers,
                  "modelled_exchange_ms_each_of_two": exch_ms, "modelled_step_ms": slow["compute_ms"] + 2 * exch_ms, "per_rank": per_rank})
 t1 = rows[0]["modelled_step_ms"]
 for r in rows:
     r["modelled_speedup_over_one_rank"] = t1 / r["modelled_step_ms"]
+    r["modelled_speedup_overlapped"] = {k: rows[0]["slowest_rank_compute_ms"] / v for k, v in r["modelled_step_ms_overlapped"].items()}
 print(json.dumps({"workload": f"{a.workload} {N}^3, {a.nsrc} sources in total, r_RT={a.R:g}",
                   "measured": "per-rank compute (library calls between the exchanges), one GPU, best of %d" % a.reps,
                   "modelled": f"exchange time = largest single rank-to-rank transfer / {a.link_GBs:g} GB/s (assumed), two exchanges per iteration; "
