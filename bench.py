@@ -108,7 +108,7 @@ def workload_label(kind, N, nsrc_total, R, world, strong):
             "raytrace + one chemistry pass per step")
 
 
-PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.txt")
+PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.txt")
 
 
 def pmc_counters(kernel):
@@ -598,9 +598,11 @@ def main():
             "algorithmic_bytes_per_launch": RT_BYTES_PER_UPDATE * gamma_cells,
             "avg_launch_ms": rt_ms / max(rt_n, 1),
             "launches_timed": rt_n,
-            "binding_resource": ("FP64/integer VALU issue (~225 wave-instructions per 64 cells: ~80 %% of the launch), then the memory-side "
-                                 "rate atomics (TCC_EA0_ATOMIC %.3g 64-B requests per launch, %s; ~10 %% of the launch); DESIGN.md 8.1"
-                                 % (rt_counters.get("TCC_EA0_ATOMIC_sum", float("nan")), PMC_SUMMARY)) if default_job else None,
+            "binding_resource": ("FP64/integer VALU issue (%.3g VALU wave-instructions per launch, ~180 per 64 cells and source with two sources per "
+                                 "workgroup: the SIMDs are ~70 %% busy), then the memory-side rate atomics (TCC_EA0_ATOMIC %.3g 64-B requests per "
+                                 "launch, %s; ~10 %% of the launch); DESIGN.md 8.0"
+                                 % (rt_counters.get("SQ_INSTS_VALU", float("nan")), rt_counters.get("TCC_EA0_ATOMIC_sum", float("nan")), PMC_SUMMARY))
+                                if default_job else None,
         },
         "roofline_kernels": [
             {"kernel": "raytrace_octant_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -367,10 +367,32 @@ static int subbox_core(const SubboxCall &c, long long &total_nbox, double &total
 
     total_nbox = 0;
     total_loss = 0.0;
-    // sources in batches bounded by the shell-buffer scratch (8 octants x 2 buffers x 3 W^2 doubles per source)
+    // Round 3: the sources whose column densities do not go back to the caller are swept on the ASORA kernel's tabulated
+    // geometry (cells within R_max_LLS only; raytrace.hip, SUBBOX) when that applies; the dumped source -- it needs the
+    // whole cube -- and everything else stay with the on-the-fly kernel of subbox.hip
+    RtParams tp;
+    fill_rt_params(tp, c.R, c.sig, c.dr, c.minlogtau, c.dlogtau, c.NumTau);
+    tp.numtau_f = p.numtau_f; tp.lut_k1 = p.lut_k1; tp.lut_k0 = p.lut_k0; tp.tau_zero = INFINITY;
+    tp.table_len = c.table_len; tp.tables = c.tables;
+    tp.fortran_consts = 1; tp.grey = grey ? 1 : 0; tp.z_transposed = 1;
+    tp.logtab = st.logtab_dev;
+    tp.src_pos = c.src_pos; tp.src_flux = c.src_flux;
+    tp.flux_src = p.flux_src;
+    const bool has_dump = c.dump != nullptr;
+    SubboxTables tab;
+    const int table_sources = c.src_count - (has_dump ? 1 : 0);
+    {
+        if (range_open && table_sources > 0)
+            if (int rc = subbox_tables_prepare(st, tp, ext_r, ext_l, c.subboxsize, table_sources, c.heat, tab)) return rc;
+    }
+
+    // sources in batches bounded by the scratch: the on-the-fly kernel keeps 8 octants x 2 buffers x 3 W^2 doubles per source
+    // (6.4 MB at 256^3), the tabulated sweep one trailing shell per source and unit (tab.max_batch)
     const size_t per_src = 8 * p.unit_stride * sizeof(double);
     const size_t budget = (size_t)4 << 30;
-    const int max_batch = (int)std::max<size_t>(8, std::min<size_t>((budget / per_src) / 8 * 8, 1 << 20));
+    // (one batch when the trailing shells of all tabulated sources fit: the dumped source then runs beside them)
+    const int max_batch = tab.ok ? (tab.max_batch >= table_sources ? std::max(c.src_count, 1) : tab.max_batch)
+                                 : (int)std::max<size_t>(8, std::min<size_t>((budget / per_src) / 8 * 8, 1 << 20));
     const int cap = std::min(std::max(c.src_count, 1), max_batch);
     if ((size_t)cap > st.subbox_cap) {                   // per-source bookkeeping of a batch, kept between calls
         for (void *q : {(void *)st.sb_active, (void *)st.sb_nbox, (void *)st.sb_loss, (void *)st.sb_loss_final})
@@ -385,25 +407,6 @@ static int subbox_core(const SubboxCall &c, long long &total_nbox, double &total
     if (!st.sb_nactive) ASORA_HIP_TRY(hipMalloc(&st.sb_nactive, sizeof(int)));
     std::vector<int> h_nbox((size_t)cap);
     std::vector<double> h_loss((size_t)cap);
-
-    // Round 3: the sources whose column densities do not go back to the caller are swept on the ASORA kernel's tabulated
-    // geometry (cells within R_max_LLS only; raytrace.hip, SUBBOX) when that applies; the dumped source -- it needs the
-    // whole cube -- and everything else stay with the on-the-fly kernel of subbox.hip
-    RtParams tp;
-    fill_rt_params(tp, c.R, c.sig, c.dr, c.minlogtau, c.dlogtau, c.NumTau);
-    tp.numtau_f = p.numtau_f; tp.lut_k1 = p.lut_k1; tp.lut_k0 = p.lut_k0; tp.tau_zero = INFINITY;
-    tp.table_len = c.table_len; tp.tables = c.tables;
-    tp.fortran_consts = 1; tp.grey = grey ? 1 : 0; tp.z_transposed = 1;
-    tp.logtab = st.logtab_dev;
-    tp.src_pos = c.src_pos; tp.src_flux = c.src_flux;
-    tp.flux_src = p.flux_src;
-    const bool has_dump = c.dump != nullptr;
-    SubboxTables tab;
-    {
-        const int table_sources = c.src_count - (has_dump ? 1 : 0);
-        if (range_open && table_sources > 0)
-            if (int rc = subbox_tables_prepare(st, tp, ext_r, ext_l, c.subboxsize, std::min(table_sources, max_batch), c.heat, tab)) return rc;
-    }
 
     for (int done = 0; done < c.src_count;) {
         const int batch = std::min(c.src_count - done, max_batch);

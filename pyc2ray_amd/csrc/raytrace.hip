@@ -493,10 +493,14 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
         const double n2 = (double)(a * a + b * b + c * c);
         const double volfac = n2 * (dr * dr * FOURPI) * path;                              // raytracing.cu:302-307 without nHI
         const unsigned own_slot = cur_A.y & CELL_SLOT_MASK;
-        if (SUBBOX) {       // is the cell on a face of the current sub-box?
-            const unsigned nb = cur_A.y >> CELL_NEG_SHIFT;
-            cur_edge = a == ((nb & 1u) ? edge_mir[0] : edge_own[0]) || b == ((nb & 2u) ? edge_mir[1] : edge_own[1]) ||
-                       c == ((nb & 4u) ? edge_mir[2] : edge_own[2]);
+        if (SUBBOX) {       // is the cell on a face of the current sub-box?  only from the shell of the nearest face on (a
+            // wave's entries belong to one shell: a wave-uniform branch; without clipping that is the box's last shell only)
+            cur_edge = false;
+            if (__builtin_amdgcn_readfirstlane(s) >= min(p.sb_edge_r, p.sb_edge_l)) {
+                const unsigned nb = cur_A.y >> CELL_NEG_SHIFT;
+                cur_edge = a == ((nb & 1u) ? edge_mir[0] : edge_own[0]) || b == ((nb & 2u) ? edge_mir[1] : edge_own[1]) ||
+                           c == ((nb & 4u) ? edge_mir[2] : edge_own[2]);
+            }
         }
         n_eval += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid)) * nreal;
 
@@ -625,18 +629,23 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
                 }
                 if (SUBBOX) {
                     // what leaves the PREVIOUS step's cell through the far side, if that cell lies on a face of the box
-                    const double ta = lookup_value(pend_A[0]), tb = lookup_value(pend_B[0]);
-                    const double po = pend_thick[0] ? pend_pv * tb : pend_pv * (tb - pend_dtau[0] * ta);
-                    if (late_ok[0] && pend_edge) loss += po;
-                    // flux / volume of this step's cell: pref * nHI, or the quotient itself where nHI = 0 (pref = inf)
-                    double pv = pref[0] * cur_nhi[0];
-                    if (__builtin_amdgcn_ballot_w64(cur_nhi[0] == 0.0) != 0ull) {
-                        const double n2s = (double)((cur_A.x & 1023) * (cur_A.x & 1023) + ((cur_A.x >> 10) & 1023) * ((cur_A.x >> 10) & 1023) +
-                                                    ((cur_A.x >> 20) & 1023) * ((cur_A.x >> 20) & 1023));
-                        const double vol = n2s * (dr * dr * FOURPI) * (__hiloint2double((int)cur_A.w, (int)cur_A.z) * dr);
-                        if (cur_nhi[0] == 0.0) pv = flux[0] / vol;
+                    if (__builtin_amdgcn_ballot_w64(late_ok[0] && pend_edge) != 0ull) {
+                        const double ta = lookup_value(pend_A[0]), tb = lookup_value(pend_B[0]);
+                        const double po = pend_thick[0] ? pend_pv * tb : pend_pv * (tb - pend_dtau[0] * ta);
+                        if (late_ok[0] && pend_edge) loss += po;
                     }
-                    pend_pv = pv;
+                    // flux / volume of this step's cell, should it lie on a face: pref * nHI, or the quotient itself where
+                    // nHI = 0 (pref = inf)
+                    if (__builtin_amdgcn_ballot_w64(cur_edge) != 0ull) {
+                        double pv = pref[0] * cur_nhi[0];
+                        if (__builtin_amdgcn_ballot_w64(cur_nhi[0] == 0.0) != 0ull) {
+                            const double n2s = (double)((cur_A.x & 1023) * (cur_A.x & 1023) + ((cur_A.x >> 10) & 1023) * ((cur_A.x >> 10) & 1023) +
+                                                        ((cur_A.x >> 20) & 1023) * ((cur_A.x >> 20) & 1023));
+                            const double vol = n2s * (dr * dr * FOURPI) * (__hiloint2double((int)cur_A.w, (int)cur_A.z) * dr);
+                            if (cur_nhi[0] == 0.0) pv = flux[0] / vol;
+                        }
+                        pend_pv = pv;
+                    }
                     pend_edge = cur_edge;
                 }
 #pragma unroll
@@ -1790,7 +1799,10 @@ int subbox_tables_prepare(State &st, RtParams &p, int ext_r, int ext_l, int subb
     if (int rc = ensure_geometry(st, p, threads, units, &sbg)) return rc;
     const size_t slots = ((size_t)p.max_cells + 2) & ~(size_t)1;
     if (2 * slots * sizeof(double) + lds_table_bytes(256) > LDS_LIMIT_BYTES) return 0;
-    const size_t need = (size_t)src_count * units * slots * sizeof(double);
+    // one trailing shell per source and unit, within 2 GiB (82 KB per source at r_RT = 32: 26 000 sources per launch)
+    const size_t per_source = (size_t)units * slots * sizeof(double);
+    const int max_batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)src_count, ((size_t)2 << 30) / per_source));
+    const size_t need = (size_t)max_batch * per_source;
     if (need > st.sb_trail_bytes) {
         if (st.sb_trail) ASORA_HIP_TRY(hipFree(st.sb_trail));
         st.sb_trail = nullptr; st.sb_trail_bytes = 0;
@@ -1798,7 +1810,7 @@ int subbox_tables_prepare(State &st, RtParams &p, int ext_r, int ext_l, int subb
         st.sb_trail_bytes = need;
     }
     p.sb_trail = st.sb_trail;
-    out.units = units; out.threads = threads; out.S = p.S; out.ok = true;
+    out.units = units; out.threads = threads; out.S = p.S; out.max_batch = max_batch; out.ok = true;
     return 0;
 }
 

@@ -1,4 +1,5 @@
-# usage: bash tools/pmc_c2ray.sh  -- HBM and atomic counters of the sub-box sweep kernel (libc2ray.raytracing.do_all_sources
+# usage: bash tools/pmc_c2ray.sh  -- HBM and atomic counters of the sub-box sweep kernels (raytrace_octant_kernel = the tabulated SUBBOX variant, round 3;
+# subbox_sweep_kernel = the on-the-fly one, now only the dumped source) (libc2ray.raytracing.do_all_sources
 # semantics, 1000 sources, 256^3, r_RT = 32), one rocprofv3 --pmc pass per group -> gpurun_out/pmc_c2ray_summary.txt
 export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun exports it) to the repository root}
 cd /tmp; i=0
@@ -15,7 +16,7 @@ for d in sorted(glob.glob("$R/gpurun_out/pmc_c2ray_[0-9]*/")):
         agg=collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             name=r["Kernel_Name"].split("(")[0].replace("void ","").replace("asora::","").split("<")[0]
-            if "subbox_sweep" in name: agg[(name,r["Counter_Name"])].append(float(r["Counter_Value"]))
+            if "subbox_sweep" in name or "raytrace_octant" in name: agg[(name,r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (k,c),v in sorted(agg.items()):
             line=f"{k:28s} {c:24s} n={len(v)} mean={sum(v)/len(v):.5g}"; print(line); out.write(line+"\n")
 PY
