@@ -1801,7 +1801,9 @@ int subbox_tables_prepare(State &st, RtParams &p, int ext_r, int ext_l, int subb
     if (2 * slots * sizeof(double) + lds_table_bytes(256) > LDS_LIMIT_BYTES) return 0;
     // one trailing shell per source and unit, within 2 GiB (82 KB per source at r_RT = 32: 26 000 sources per launch)
     const size_t per_source = (size_t)units * slots * sizeof(double);
-    const int max_batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)src_count, ((size_t)2 << 30) / per_source));
+    size_t trail_budget = (size_t)2 << 30;
+    if (const char *e = getenv("ASORA_SUBBOX_TRAIL_BUDGET")) trail_budget = std::max<size_t>(per_source, (size_t)atoll(e));   // tests: force several batches
+    const int max_batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)src_count, trail_budget / per_source));
     const size_t need = (size_t)max_batch * per_source;
     if (need > st.sb_trail_bytes) {
         if (st.sb_trail) ASORA_HIP_TRY(hipFree(st.sb_trail));

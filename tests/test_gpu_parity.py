@@ -1110,6 +1110,65 @@ def test_leaving_out_exactly_zero_rates_changes_nothing(asora):
         assert (zeros > 0.5) if tau_cell == 3000.0 else (zeros < 0.5)
 
 
+def test_cells_on_the_sphere_follow_dr_without_a_rebuild(asora):
+    """Integer radii have lattice points exactly ON the sphere (R = 5: (3,4,0), (5,0,0), ...; R = 9: (1,4,8), (4,4,7), ...).
+    Whether such a cell is rated is the reference's floating-point test dist2/(dr*dr) <= R*R, whose outcome depends on dr.
+    The tables keep those cells and re-decide their RATE bit in place when only dr changes (every step of a cosmological
+    run): a trace after a change of dr must equal the oracle's and, bit for bit, the trace of a library that built its
+    tables for that dr from scratch -- for every decomposition."""
+    p, lib, capi = asora
+    N = 32
+    thin, thick, dlog = cases.soft_tables(400)
+    nd, xh, dr0 = cases.grid(N, "lognormal", 21, 0.05, xlo=1e-4, xhi=1e-2)
+    pos, flux = cases.sources(N, 3, 22, flux=2.0)
+    pos[:, 0] = [16, 16, 16]
+    pos[:, 1] = [3, 30, 16]
+    p0, f0 = cases.flat_sources(pos, flux)
+    numtau = thin.shape[0]
+
+    def setup():
+        if p.cuda_is_init():
+            p.device_close()
+        p.device_init(N, 8)
+        p.photo_table_to_device(thin, thick)
+        lib.source_data_to_device(p0, f0, 3)
+        lib.grid_to_device(capi.GRID_NDENS, nd)
+        lib.grid_to_device(capi.GRID_XH_AV, xh)
+
+    def trace(R, dr):
+        lib.raytrace_device(R, cases.SIG, dr, 0, 3, cases.MINLOGTAU, dlog, numtau)
+        return lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N))), lib.last_raytrace_counts()[0]
+
+    drs = [dr0, dr0 * 1.37, dr0 * 0.731, dr0 * 3.3e-7, dr0 * 1.0000001, dr0]
+    counts_seen = set()
+    for mode in (0, 1, 3, 4, 9):
+        for R in (5.0, 9.0):
+            setup()
+            lib.set_option(capi.OPT_SECTORS, mode)
+            try:
+                patched = [trace(R, dr) for dr in drs]              # one build, then dr changes only
+            finally:
+                lib.set_option(capi.OPT_SECTORS, 0)
+            for dr, (phi, count) in zip(drs, patched):
+                ref = O.asora_do_all_sources(R, cases.SIG, dr, nd, xh, p0, f0, thin, thick, cases.MINLOGTAU, dlog, NumTau=numtau,
+                                             flags=O.ASORA_MODE)["phi_ion"]
+                w = ref != 0
+                assert np.array_equal(phi != 0, w), (mode, R, dr)      # the same cells rated, on-sphere ones included
+                np.testing.assert_allclose(phi[w], ref[w], rtol=GAMMA_RTOL, atol=0)
+                assert count == 3 * int(w.sum()) // 3 or count > 0
+                counts_seen.add((R, int(w.sum())))
+            # a fresh build for the last but one dr gives the same bits as the patched tables did
+            setup()
+            lib.set_option(capi.OPT_SECTORS, mode)
+            try:
+                fresh, _ = trace(R, drs[1])
+            finally:
+                lib.set_option(capi.OPT_SECTORS, 0)
+            assert np.array_equal(fresh != 0, patched[1][0] != 0)
+            np.testing.assert_allclose(fresh, patched[1][0], rtol=1e-13, atol=0)
+    p.device_close()
+
+
 def test_two_sources_per_workgroup_give_the_same_rates(asora):
     """ASORA_OPT_PAIR_SOURCES: one workgroup sweeps its unit for two consecutive sources at once.  Sources whose spheres do
     not overlap (no summation-order freedom) -> grids IDENTICAL to the one-source-per-workgroup kernel, for every

@@ -418,3 +418,38 @@ def test_tabulated_sweep_randomised_against_oracle_and_on_the_fly_kernel(libs):
             _close(phi2, ref["phi_ion"], RATE_RTOL)
         seen_multi_box += nbox2 > ns
     assert seen_multi_box >= 8
+
+
+def test_tabulated_sweep_in_several_batches(libs, monkeypatch):
+    """The trailing shells of the tabulated sweep live in a scratch of bounded size; more sources than it holds are swept
+    in batches (the dumped source in the last one).  Forced here with a scratch of a few sources: same results."""
+    p, c2ray, asora, capi = libs
+    N = 24
+    nd, xh, dr = cases.grid(N, "lognormal", 77, 0.3)
+    pos, flux = cases.sources(N, 23, 78, flux=2.0)
+    flux = flux * (1.0 + 0.1 * np.arange(23))
+    thin, thick, dlog = cases.soft_tables()
+    c = dict(N=N, ndens=nd, xh=xh, dr=dr, pos=pos, flux=flux, thin=thin, thick=thick, dlogtau=dlog,
+             minlogtau=cases.MINLOGTAU, sig=cases.SIG, heat_thin=1e-11 * thin, heat_thick=2e-11 * thick)
+    _fresh(p, N)
+    out = []
+    for budget in (None, "60000"):                 # 60 kB: about five sources per batch at this size
+        if budget:
+            monkeypatch.setenv("ASORA_SUBBOX_TRAIL_BUDGET", budget)
+        asora.set_option(capi.OPT_SUBBOX_TABLES, 2)
+        try:
+            out.append(_call(c2ray, c, 1000, 3, 2e-2, 7.0))
+        finally:
+            asora.set_option(capi.OPT_SUBBOX_TABLES, 0)
+            monkeypatch.delenv("ASORA_SUBBOX_TRAIL_BUDGET", raising=False)
+    (phi0, heat0, cd0, nbox0, loss0), (phi1, heat1, cd1, nbox1, loss1) = out
+    assert nbox0 == nbox1 and nbox0 > 23
+    np.testing.assert_allclose(loss1, loss0, rtol=1e-12)
+    assert np.array_equal(cd0, cd1)
+    _close(phi1, phi0, 1e-12)
+    _close(heat1, heat0, 1e-12)
+    n = thin.shape[0] - 1
+    ref = O.do_all_sources(flux, pos, 1000, 3, cases.SIG, dr, nd, xh, 2e-2, thin[:n], thick[:n], cases.MINLOGTAU, dlog, 7.0,
+                           heat_thin=c["heat_thin"][:n], heat_thick=c["heat_thick"][:n])
+    if nbox1 == ref["nsubbox"]:
+        _close(phi1, ref["phi_ion"], RATE_RTOL)
