@@ -523,6 +523,9 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
             double cdi = ASORA_DIV(x1 * q1 + x2 * q2 + x3 * q3 + x4 * q4, q1 + q2 + q3 + q4);     // (the weights sum to 1, each max() is >= 0.6)
 #endif
             if (s == 1) {                                    // diagonal neighbours of the source, cu:431-441
+                // (round 3: a wave's entries belong to one shell, so this could be a scalar branch instead of the dozen selects
+                //  the compiler makes of it -- measured: no gain at R = 16 / 32, +5 % at R = 64: the branch splits the
+                //  scheduling region around the LDS reads; left as it is)
                 const int nz = (a == 0) + (b == 0) + (c == 0);
                 const double r3 = p.fortran_consts ? (double)1.7320507764816284 : 1.73205080757; // f90:608 / cu:435
                 const double r2 = p.fortran_consts ? (double)1.4142135381698608 : 1.41421356237; // f90:609 / cu:439
