@@ -201,6 +201,10 @@ int asora_chemistry_device(double dt, double bh00, double albpow, double colh0, 
 int asora_chemistry_range(double dt, double bh00, double albpow, double colh0, double temph0, double abu_c,
                           int i_begin, int i_count, int first);
 int asora_chemistry_finish(int *conv_flag, double *sum_xh1, double *sum_xh0);
+/* Device address of the three reductions {sum(xh_intermed), sum(1 - xh_intermed), conv_flag} (doubles) that
+ * asora_chemistry_range accumulates: a multi-GPU caller sums them across ranks in place (one RCCL all-reduce ordered after
+ * asora_stream()) and reads them back once, instead of asora_chemistry_finish + a host round trip per rank. */
+void *asora_reduction_ptr(void);
 
 /* The whole outer loop of evolve3D (pyc2ray/evolve.py:168-240) on the device.  Per iteration the host of the
  * reference uploads xh_av, downloads phi_ion, reshapes, runs global_pass, forms two sums with numpy and tests

@@ -59,6 +59,7 @@ SIGNATURES = {
     "asora_chemistry_range": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                         C.c_int, C.c_int, C.c_int]),
     "asora_chemistry_finish": (C.c_int, [C.POINTER(C.c_int), _dp, _dp]),
+    "asora_reduction_ptr": (C.c_void_p, []),
     "asora_evolve_begin": (C.c_int, [C.c_double] * 11 + [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]),
     "asora_evolve_enqueue": (C.c_int, [C.c_int]),
     "asora_evolve_poll": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_int, C.POINTER(C.c_int)]),

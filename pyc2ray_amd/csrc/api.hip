@@ -1081,6 +1081,8 @@ int asora_chemistry_finish(int *conv_flag, double *sum_xh1, double *sum_xh0)
     return 0;
 }
 
+void *asora_reduction_ptr(void) { return g_state.init ? (void *)g_state.red_final : nullptr; }
+
 int c2ray_global_pass(double dt, const double *ndens, const double *temp, const double *xh, double *xh_av,
                       double *xh_intermed, const double *phi_ion, double bh00, double albpow, double colh0,
                       double temph0, double abu_c, int m1, int m2, int m3, int *conv_flag)

@@ -159,8 +159,14 @@ class SlabPlan:
     def send_schedule(self, r, K):
         """sched[c] = [(q, a, b), ...]: the pieces of runs[r][q] (q != r) rank r sends once it has traced its chunks
         0..c -- the planes no later chunk reaches, not sent before; the last chunk sends everything that is left.  Every
-        plane of every run is sent exactly once."""
+        plane of every run is sent exactly once.  (Memoised: an iteration must not pay for this again.)"""
         K = max(1, int(K))
+        cache = self.__dict__.setdefault("_send_cache", {})
+        if (r, K) not in cache:
+            cache[(r, K)] = self._send_schedule(r, K)
+        return cache[(r, K)]
+
+    def _send_schedule(self, r, K):
         n = self.i0[r].size
         b = self.chunk_bounds(n, K)
         sent = np.zeros(self.N, dtype=bool)
@@ -180,7 +186,13 @@ class SlabPlan:
         return sched
 
     def recv_schedule(self, q, K):
-        """rsched[c] = [(r, a, b), ...]: what the other ranks send to q after their chunk c (rank order)."""
+        """rsched[c] = [(r, a, b), ...]: what the other ranks send to q after their chunk c (rank order).  Memoised."""
+        cache = self.__dict__.setdefault("_recv_cache", {})
+        if (q, int(K)) not in cache:
+            cache[(q, int(K))] = self._recv_schedule(q, K)
+        return cache[(q, int(K))]
+
+    def _recv_schedule(self, q, K):
         out = [[] for _ in range(max(1, int(K)))]
         for r in range(self.P):
             if r == q:
@@ -190,11 +202,14 @@ class SlabPlan:
         return out
 
     def work_runs(self, r):
-        """Planes rank r zeroes its accumulators on and forms nHI on: what its sources reach plus what it owns."""
-        mask = self.reach[r].copy()
-        a, b = self.own[r]
-        mask[a:b] = True
-        return _runs_of(mask)
+        """Planes rank r zeroes its accumulators on and forms nHI on: what its sources reach plus what it owns.  Memoised."""
+        cache = self.__dict__.setdefault("_work_cache", {})
+        if r not in cache:
+            mask = self.reach[r].copy()
+            a, b = self.own[r]
+            mask[a:b] = True
+            cache[r] = _runs_of(mask)
+        return cache[r]
 
     def reach_runs(self, r):
         return _runs_of(self.reach[r])
@@ -366,8 +381,20 @@ class TorchComm:
         return pos[:, order], flux[order], bounds
 
     def _planes_view(self, libasora, which, N):
+        """Zero-copy (N, N*N) view of a library grid; kept per (address, N): the grids do not move between iterations."""
         import torch
-        return torch.as_tensor(_DevicePointer(libasora.device_ptr(which), N ** 3), device="cuda").view(N, N * N)
+        ptr = libasora.device_ptr(which)
+        cache = self.__dict__.setdefault("_views", {})
+        if (ptr, N) not in cache:
+            cache[(ptr, N)] = torch.as_tensor(_DevicePointer(ptr, N ** 3), device="cuda").view(N, N * N)
+        return cache[(ptr, N)]
+
+    def _library_stream(self, libasora):
+        import torch
+        ptr = libasora.stream_ptr()
+        if getattr(self, "_lib_stream_ptr", None) != ptr:
+            self._lib_stream, self._lib_stream_ptr = torch.cuda.ExternalStream(ptr), ptr
+        return self._lib_stream
 
     def _post(self, libasora, which, N, sends, recvs, add, tag):
         """Start one round of plane transfers of grid `which`: `sends` = [(peer, a, b)] planes [a, b) to peer, `recvs` =
@@ -380,19 +407,21 @@ class TorchComm:
         if not sends and not recvs:
             return None
         if self._backend() == "nccl":
-            lib_stream = torch.cuda.ExternalStream(libasora.stream_ptr())
+            lib_stream = self._library_stream(libasora)
             with torch.cuda.stream(lib_stream):
                 grid = self._planes_view(libasora, which, N)
-                if add:
-                    key = (tag, N, tuple(recvs))
-                    cache = self.__dict__.setdefault("_stages", {})
-                    if key not in cache:                                   # staging kept between iterations
-                        cache[key] = [torch.empty((b - a, N * N), dtype=torch.float64, device="cuda") for _, a, b in recvs]
-                    targets = cache[key]
-                else:
-                    targets = [grid[a:b] for _, a, b in recvs]
-                ops = [dist.P2POp(dist.isend, grid[a:b], q, group=self._group) for q, a, b in sends]
-                ops += [dist.P2POp(dist.irecv, t, q, group=self._group) for (q, _, _), t in zip(recvs, targets)]
+                # staging buffers, receive targets and the P2POp list are the same every iteration: built once per round
+                key = (tag, which, N, add, tuple(sends), tuple(recvs), grid.data_ptr())
+                cache = self.__dict__.setdefault("_rounds", {})
+                if key not in cache:
+                    if add:
+                        targets = [torch.empty((b - a, N * N), dtype=torch.float64, device="cuda") for _, a, b in recvs]
+                    else:
+                        targets = [grid[a:b] for _, a, b in recvs]
+                    ops = [dist.P2POp(dist.isend, grid[a:b], q, group=self._group) for q, a, b in sends]
+                    ops += [dist.P2POp(dist.irecv, t, q, group=self._group) for (q, _, _), t in zip(recvs, targets)]
+                    cache[key] = (targets, ops)
+                targets, ops = cache[key]
                 works = dist.batch_isend_irecv(ops)
             return ("nccl", works, recvs, targets, add)
         # gloo (CPU tests, several ranks on one GPU): staged through the host
@@ -410,7 +439,7 @@ class TorchComm:
             return
         kind, works, recvs, targets, add = handle[:5]
         if kind == "nccl":
-            lib_stream = torch.cuda.ExternalStream(libasora.stream_ptr())
+            lib_stream = self._library_stream(libasora)
             with torch.cuda.stream(lib_stream):
                 for w in works:
                     w.wait()                       # the library's stream waits, not the host
@@ -428,10 +457,23 @@ class TorchComm:
             else:
                 libasora.planes_to_device(which, a, t.numpy())
 
-    def _sum_scalars(self, part):
-        """Sum of (conv_flag, sum x, sum 1-x) over the ranks: ONE all-reduce of three doubles and one read-back (the result
-        of an all-reduce is the same on every rank, so every rank takes the same convergence decision)."""
+    def _sum_scalars(self, libasora):
+        """Sum of (conv_flag, sum x, sum 1-x) of the slab chemistry over the ranks: ONE all-reduce of three doubles and ONE
+        read-back per iteration (the result of an all-reduce is the same on every rank, so every rank takes the same
+        convergence decision).  With RCCL the all-reduce runs in place on the library's reduction buffer, ordered on its
+        stream behind the chemistry -- the host does not wait for the chemistry first."""
         import torch
+        if self._backend() == "nccl" and hasattr(libasora, "reduction_ptr"):
+            ptr = libasora.reduction_ptr()
+            cache = self.__dict__.setdefault("_views", {})
+            if (ptr, 3) not in cache:
+                cache[(ptr, 3)] = torch.as_tensor(_DevicePointer(ptr, 3), device="cuda")
+            red = cache[(ptr, 3)]                               # {sum x, sum 1-x, conv_flag}
+            with torch.cuda.stream(self._library_stream(libasora)):
+                self._dist.all_reduce(red, op=self._dist.ReduceOp.SUM, group=self._group)
+                v = red.cpu().tolist()
+            return int(round(v[2])), v[0], v[1]
+        part = libasora.chemistry_finish()                      # (conv_flag, sum x, sum 1-x) of this rank
         t = torch.tensor([float(part[0]), float(part[1]), float(part[2])], dtype=torch.float64)
         if self._backend() == "nccl":
             t = t.cuda()
@@ -472,12 +514,14 @@ class TorchComm:
         for h in handles:                                               # chunk order, then rank order: a fixed order of additions
             self._complete(libasora, _capi.GRID_PHI_ION, N, h)
         libasora.chemistry_range(*chemistry, a, b - a, True)
-        part = libasora.chemistry_finish()
         # xh_av back: the owner q of a run sends it to the rank r that traces through it
-        sends = [(r, s0, s1) for r in range(plan.P) if r != me for s0, s1 in plan.runs[r][me]]
-        recvs = [(q, s0, s1) for q in range(plan.P) if q != me for s0, s1 in plan.runs[me][q]]
+        back = plan.__dict__.setdefault("_back_cache", {})
+        if me not in back:
+            back[me] = ([(r, s0, s1) for r in range(plan.P) if r != me for s0, s1 in plan.runs[r][me]],
+                        [(q, s0, s1) for q in range(plan.P) if q != me for s0, s1 in plan.runs[me][q]])
+        sends, recvs = back[me]
         self._complete(libasora, _capi.GRID_XH_AV, N, self._post(libasora, _capi.GRID_XH_AV, N, sends, recvs, False, "xh_av"))
-        return self._sum_scalars(part)
+        return self._sum_scalars(libasora)
 
     def slab_gather(self, libasora, plan, which, N):
         """Every rank gets every owner's slab of grid `which` (end of a time step: xh_intermed, phi_ion)."""

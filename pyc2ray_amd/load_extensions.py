@@ -200,6 +200,10 @@ class _LibAsora:
         _capi.check(self._lib.asora_chemistry_finish(C.byref(conv), C.byref(s1), C.byref(s0)), "chemistry_finish")
         return conv.value, s1.value, s0.value
 
+    def reduction_ptr(self):
+        """Device address of {sum x, sum 1-x, conv_flag} of the chemistry_range calls so far (three doubles)."""
+        return self._lib.asora_reduction_ptr()
+
     def evolve_begin(self, dt, bh00, albpow, colh0, temph0, abu_c, R, sig, dr, minlogtau, dlogtau, NumTau,
                      src_begin, src_count, conv_criterion, convergence_fraction):
         """Start a time step of the device-resident loop (NDENS, TEMP, XH on the device)."""

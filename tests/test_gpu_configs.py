@@ -6,7 +6,8 @@
               by the REFERENCE Fortran at this size (tests/golden/make_fullsize_golden.py)
   configs[3]  256^3 log-normal density, sources on the densest cells (adjacent sources, same-address atomics):
               ALL 1000 sources against a sparse fixture produced by the REFERENCE Fortran (tests/golden/
-              make_bigconfig_golden.py), 96 of them (plus coincident ones) against the oracle on the host cores of the GPU box
+              make_bigconfig_golden.py); ONE WHOLE TIME STEP of evolve3D (the device-resident loop) against the reference's
+              kernels driven by the reference's loop (make_fullsize_evolve_golden.py); 96 of them (plus coincident ones) against the oracle on the host cores of the GPU box
   configs[4]  512^3 (indices beyond 2^31 bytes): ALL 1e5 sources on the densest cells through two iterations of the evolve
               loop (counts, finiteness, fused loop == separate calls), 256 of them against a sparse fixture produced by the
               REFERENCE Fortran, superposition; corner sources, exact pair counts, one source against the oracle
@@ -195,6 +196,52 @@ def test_config3_256_lognormal_all_1000_sources_against_reference_fortran(asora,
     gam, _ = lib.last_raytrace_counts()
     assert gam == NS * _lattice_points_within(R)
     _against_bigconfig_fixture(phi, g, MB, N, pos)
+
+
+def test_config3_256_one_whole_time_step_against_the_reference_kernels(asora, bench_tables, tmp_path):
+    """BASELINE configs[3] through `evolve3D` itself -- the device-resident loop: raytrace of all 1000 sources, fused pass,
+    convergence test on the device, batches of iterations -- for one whole time step at full size, against the reference
+    Fortran's kernels driven by the reference's loop (tests/golden/make_fullsize_evolve_golden.py): same number of outer
+    iterations, the same count of non-converged cells in every iteration (to a handful of cells that sit on the 1e-3
+    threshold), ionised fraction to 1e-8, last iteration's rates to 1e-7."""
+    import re
+    import bench
+    import make_bigconfig_golden as MB
+    p, lib, capi = asora
+    N, NS, R = 256, 1000, 32.0
+    g = np.load(os.path.join(G, "fullsize_evolve_cosmo256.npz"))
+    thin, thick, dlog = bench_tables
+    np.testing.assert_allclose([thin.sum(), thick.sum()], g["table_sums"], rtol=1e-13)
+    ndens, xh, temp, dr, pos, flux = bench.make_workload("cosmo", N, NS)
+    chk = MB.input_checksums(ndens, pos, flux)
+    assert int(chk["pos_sum"]) == int(g["pos_sum"])
+    np.testing.assert_allclose([float(chk["ndens_sum"]), float(chk["flux_sum"])], [float(g["ndens_sum"]), float(g["flux_sum"])], rtol=1e-12)
+    _fresh(p, N)
+    p.photo_table_to_device(thin, thick)
+    log = str(tmp_path / "log.txt")
+    lib.set_option(capi.OPT_FORTRAN_CONSTANTS, 1)            # the fixture is the Fortran path: its constants
+    try:
+        x, phi = p.evolve3D(float(g["dt"]), dr, flux * float(g["flux_scale"]), pos, True, 1000, N, 1e-2, temp, ndens, xh, thin, thick, bench.MINLOGTAU, dlog,
+                            R, 1e-4, bench.SIG, bench.BH00, bench.ALBPOW, bench.COLH0, bench.TEMPH0, bench.ABU_C, logfile=log, quiet=True)
+    finally:
+        lib.set_option(capi.OPT_FORTRAN_CONSTANTS, 0)
+    niter = int(g["niter"])
+    assert p.evolve._evolve.last_niter == niter and niter >= 5
+    flags = [int(v) for v in re.findall(r"Number of non-converged points: (\d+) of", open(log).read())]
+    assert len(flags) == niter
+    want = g["rows"][:, 0]
+    assert np.all(np.abs(np.array(flags) - want) <= np.maximum(5, 1e-4 * want)), (flags, want)
+    np.testing.assert_allclose(float(x.mean()), float(g["x_mean"]), rtol=1e-10)
+    idx = MB.sample_indices(N, pos, 20260400)
+    src_flat = ((pos[0] - 1) * N + (pos[1] - 1)) * N + (pos[2] - 1)
+    for name, grid, rtol in (("x", x, 1e-8), ("phi", phi, 1e-7)):
+        flat = np.ascontiguousarray(grid).ravel()
+        np.testing.assert_allclose(flat[idx], g[f"{name}_vals"], rtol=rtol, atol=0, err_msg=name)
+        np.testing.assert_allclose(flat[src_flat], g[f"{name}_src_vals"], rtol=rtol, atol=0, err_msg=name)
+        d = MB.digest(np.ascontiguousarray(grid))
+        np.testing.assert_allclose(d["plane_sums"], g[f"{name}_plane_sums"], rtol=rtol)
+        np.testing.assert_allclose(d["block_sums"], g[f"{name}_block_sums"], rtol=rtol, atol=1e-12 * float(np.abs(g[f"{name}_block_sums"]).max()))
+    assert 1e-3 < float(x.mean()) < 0.5 and float(x.max()) > 0.9           # ionised bubbles in a mostly neutral box
 
 
 # ---- configs[4] ---------------------------------------------------------------------------------------------------

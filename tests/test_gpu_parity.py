@@ -477,6 +477,66 @@ def test_rccl_allreduce_on_library_grid_world1(asora):
     p.device_close()
 
 
+def test_slab_iteration_over_rccl_world1_equals_the_single_gpu_loop(asora, tmp_path):
+    """evolve3D_MPI with a TorchComm over backend nccl (= RCCL), ONE rank (the box has one GPU): the slab path with its
+    stream hand-over (torch ExternalStream on the library's stream), the zero-copy views of the library's grids, the chunked
+    trace with folds, the slab chemistry and -- the part that needs RCCL -- the in-place all-reduce of the three
+    convergence scalars on the library's reduction buffer, read back once per iteration.  Same iteration count and fields
+    as evolve3D on the device-resident loop."""
+    import socket
+    import torch.distributed as dist
+    from pyc2ray_amd import dist as pd
+    p, lib, capi = asora
+    N = 32
+    nd, xh, dr = cases.grid(N, "lognormal", 91, 0.15, xlo=1e-4, xhi=2e-3)
+    temp = np.full((N, N, N), 1e4)
+    pos, flux = cases.sources(N, 11, 92, flux=3e-4 * (N / 16.0) ** 3 / 11)
+    thin, thick, dlog = cases.soft_tables()
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 8)
+    p.photo_table_to_device(thin, thick)
+    if not dist.is_initialized():
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        pd.init_process_group_from_env("nccl")
+    args = (3.15576e13 * 3, dr, flux, pos, True, 1000, N, 1e-2)
+    rest = (temp, nd, xh, thin, thick, cases.MINLOGTAU, dlog, 7.0, 1e-4, cases.SIG, cases.BH00, cases.ALBPOW, cases.COLH0,
+            cases.TEMPH0, cases.ABU_C)
+    x1, phi1 = p.evolve3D(*args, *rest, logfile=str(tmp_path / "a"), quiet=True)
+    n1 = p.evolve._evolve.last_niter
+    import pyc2ray_amd.evolve as E
+    for chunks in (1, 3):
+        comm = pd.TorchComm()
+        comm.exchange, comm.slab_chunks = "slab", chunks
+        # (one rank: evolve3D_MPI takes the distributed branch only with nprocs > 1; drive the slab path directly)
+        from pyc2ray_amd.utils.sourceutils import format_sources
+        spos, sflux, bounds = comm.shard_sources_by_slab(pos, flux, 1)
+        plan = pd.SlabPlan(N, 1, 7.0, [spos[0] - 1])
+        p0, f0 = format_sources(spos, sflux)
+        lib.source_data_to_device(p0, f0, 11)
+        for which, a in ((capi.GRID_NDENS, nd), (capi.GRID_TEMP, temp), (capi.GRID_XH, xh)):
+            lib.grid_to_device(which, a)
+        lib.grid_copy(capi.GRID_XH_AV, capi.GRID_XH)
+        lib.grid_copy(capi.GRID_XH_INTERMED, capi.GRID_XH)
+        chem = (3.15576e13 * 3, cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C)
+        ncell, prev1, prev0, niter, converged = N ** 3, 2 * N ** 3, 2 * N ** 3, 0, False
+        crit = min(int(1e-4 * ncell), (11 - 1) / 3)
+        while not converged:
+            niter += 1
+            conv, s1, s0 = comm.slab_iteration(lib, plan, N, 7.0, cases.SIG, dr, 11, cases.MINLOGTAU, dlog, thin.shape[0], chem, niter == 1)
+            r1, r0 = abs((s1 - prev1) / s1), abs((s0 - prev0) / s0)
+            converged = conv < crit or (r1 < 1e-4 and r0 < 1e-4)
+            prev1, prev0 = s1, s0
+            assert niter < 100
+        x2 = lib.grid_to_host(capi.GRID_XH_INTERMED, np.empty((N, N, N)))
+        phi2 = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+        assert niter == n1, (chunks, niter, n1)
+        np.testing.assert_allclose(x2, x1, rtol=1e-10, atol=0)
+        np.testing.assert_allclose(phi2, phi1, rtol=1e-10, atol=0)
+    p.device_close()
+
+
 # ---- edge cases -----------------------------------------------------------------------------------------
 def _edge_case(p, lib, capi, N, pos, flux, R, tau_cell=0.1, seed=71, tables="soft", xh_override=None):
     nd, xh, dr = cases.grid(N, "lognormal", seed, tau_cell)
