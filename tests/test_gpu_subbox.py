@@ -387,18 +387,21 @@ def test_tabulated_sweep_randomised_against_oracle_and_on_the_fly_kernel(libs):
         lf = float(rng.choice([0.0, 1e-3, 0.05, 0.3]))
         R = float(rng.choice([1000.0, 1000.0, 2.5, 4.0, 5.0, N / 3.0]))
         use_heat = bool(trial % 2)
+        own_flux = trial % 3 == 0                      # ASORA_OPT_C2RAY_OWN_FLUX: each source its own flux (default: the last one's)
         zeros = np.zeros(thin.shape[0])
         _fresh(p, N)
         out = {}
         for tables in (1, 2):
             phi = np.zeros((N, N, N), order="F"); heat = np.zeros((N, N, N), order="F"); cd = np.zeros((N, N, N), order="F")
             asora.set_option(capi.OPT_SUBBOX_TABLES, tables)
+            asora.set_option(capi.OPT_C2RAY_OWN_FLUX, 1 if own_flux else 0)
             try:
                 nbox, loss = c2ray.raytracing.do_all_sources(flux, pos, max_subbox, subboxsize, cd, cases.SIG, dr, nd, xh, phi, heat,
                                                              lf, thin, thick, ht if use_heat else zeros, hk if use_heat else zeros,
                                                              cases.MINLOGTAU, dlog, R)
             finally:
                 asora.set_option(capi.OPT_SUBBOX_TABLES, 0)
+                asora.set_option(capi.OPT_C2RAY_OWN_FLUX, 0)
             out[tables] = (phi, heat, cd, nbox, loss)
         tag = f"trial {trial}: N={N} ns={ns} max_subbox={max_subbox} subboxsize={subboxsize} lf={lf} tau={tau_cell:.3g} R={R} heat={use_heat}"
         (phi1, heat1, cd1, nbox1, loss1), (phi2, heat2, cd2, nbox2, loss2) = out[1], out[2]
@@ -408,7 +411,8 @@ def test_tabulated_sweep_randomised_against_oracle_and_on_the_fly_kernel(libs):
         _close(phi2, phi1, RATE_RTOL)
         _close(heat2, heat1, RATE_RTOL)
         ref = O.do_all_sources(flux, pos, max_subbox, subboxsize, cases.SIG, dr, nd, xh, lf, thin, thick, cases.MINLOGTAU,
-                               dlog, R, heat_thin=ht if use_heat else None, heat_thick=hk if use_heat else None)
+                               dlog, R, heat_thin=ht if use_heat else None, heat_thick=hk if use_heat else None,
+                               **({"flags": O.PER_SOURCE_FLUX} if own_flux else {}))
         if R >= 1000.0:
             assert nbox2 == ref["nsubbox"], tag
             np.testing.assert_allclose(loss2, ref["photon_loss"], rtol=RATE_RTOL, err_msg=tag)
