@@ -17,16 +17,28 @@ constexpr int LOG_TABLE_SIZE = 1 << LOG_TABLE_BITS;
 // log2 c at the interval centres, staged in LDS) + degree-6 series in r = m/c - 1, |r| < 2^-8
 // (truncation 3e-18).  Absolute error ~1 ulp of the result, like libm's log10; it replaces
 // log10 in the table lookup because two of them per cell dominated the instruction count.
+// ASORA_FREXP_LOG = 1: mantissa and exponent through v_frexp_mant_f64 / v_frexp_exp_i32_f64 (x = m * 2^e, m in [0.5, 1)) instead of
+// shifts and masks on the bit pattern (4 instead of 7 integer instructions per logarithm); the table then holds {2/c, log2(c) - 1}
+// for the same interval centres c in [1, 2) (ensure_logtab), so that r = m * (2/c) - 1 and log2 x = e + (log2 c - 1) + log2(1 + r).
+#ifndef ASORA_FREXP_LOG
+#define ASORA_FREXP_LOG 1
+#endif
 __device__ __forceinline__ double log2_pos(double x, const double2 *__restrict__ logtab, int diag_linear_index = 0)
 {
+#if ASORA_FREXP_LOG
+    const double m = __builtin_amdgcn_frexp_mant(x);
+    const int e = __builtin_amdgcn_frexp_exp(x);
+    int idx = (int)(__double_as_longlong(m) >> (52 - LOG_TABLE_BITS)) & (LOG_TABLE_SIZE - 1);
+#else
     const long long bits = __double_as_longlong(x);
     const int e = (int)(bits >> 52) - 1023;
     int idx = (int)(bits >> (52 - LOG_TABLE_BITS)) & (LOG_TABLE_SIZE - 1);
+    const double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);
+#endif
 #ifdef ASORA_ENABLE_ABLATION
     if (diag_linear_index) idx = threadIdx.x & (LOG_TABLE_SIZE - 1);   // diagnostic: conflict-free table reads (wrong values)
 #endif
-    const double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);
-    const double2 t = logtab[idx];                 // {1/c, log2 c}
+    const double2 t = logtab[idx];                 // {1/c, log2 c}  (ASORA_FREXP_LOG: {2/c, log2 c - 1})
     const double r = fma(m, t.x, -1.0);
     // log2(1+r) = r/ln2 * (1 - r/2 + r^2/3 - r^3/4 + r^4/5 - r^5/6)
     const double C1 = 1.4426950408889634074, C2 = -0.72134752044448170368, C3 = 0.48089834696298780245,

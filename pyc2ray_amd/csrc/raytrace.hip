@@ -353,6 +353,14 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
         if (BUFATOM) (void)asora_buffer_atomic_fadd_f64(v, rs_heat, ok ? (int)(idx * 8u) : ASORA_OOB_OFFSET, 0, 0);
         else if (ok) unsafeAtomicAdd(p.heat + idx, v);
     };
+    // BUFATOM: a pending rate is carried as the byte offset its atomic will use -- ASORA_OOB_OFFSET when the lane has nothing
+    // to add -- instead of an index and a flag (a flag that lives across the step costs a select to make and a compare to use)
+    auto add_phi_at = [&](int off, double v) {
+        if (ASORA_ABLATED(1)) off = v == 1.2345e-300 ? off : ASORA_OOB_OFFSET;
+        if (ASORA_ABLATED(64)) off &= 0x7FFF8;
+        (void)asora_buffer_atomic_fadd_f64(v, rs_phi, off, 0, 0);
+    };
+    auto add_heat_at = [&](int off, double v) { (void)asora_buffer_atomic_fadd_f64(v, rs_heat, off, 0, 0); };
 
     // ---- SUBBOX, a later box of the source: continue from the trailing shell of the box before ------------
     const bool continues = SUBBOX && !p.sb_first;
@@ -413,6 +421,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     double late_v[NSRC], late_h[NSRC];
 #endif
     unsigned late_idx[NSRC];
+    int late_off[NSRC];                // BUFATOM: byte offset of the pending rate's atomic, or ASORA_OOB_OFFSET
 #if ASORA_LATE_LOOKUP
     Lookup pend_A[NSRC], pend_B[NSRC];             // lookups issued in the previous step, consumed in this one
     bool pend_thick[NSRC];
@@ -420,7 +429,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
 #endif
 #pragma unroll
     for (int q = 0; q < NSRC; ++q) {
-        late_ok[q] = false; late_idx[q] = 0;
+        late_ok[q] = false; late_idx[q] = 0; late_off[q] = ASORA_OOB_OFFSET;
 #if !ASORA_LATE_LOOKUP
         late_v[q] = 0.0; late_h[q] = 0.0;
 #else
@@ -632,10 +641,11 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
                 }
                 if (SUBBOX) {
                     // what leaves the PREVIOUS step's cell through the far side, if that cell lies on a face of the box
-                    if (__builtin_amdgcn_ballot_w64(late_ok[0] && pend_edge) != 0ull) {
+                    const bool lost = (BUFATOM ? late_off[0] != ASORA_OOB_OFFSET : late_ok[0]) && pend_edge;
+                    if (__builtin_amdgcn_ballot_w64(lost) != 0ull) {
                         const double ta = lookup_value(pend_A[0]), tb = lookup_value(pend_B[0]);
                         const double po = pend_thick[0] ? pend_pv * tb : pend_pv * (tb - pend_dtau[0] * ta);
-                        if (late_ok[0] && pend_edge) loss += po;
+                        if (lost) loss += po;
                     }
                     // flux / volume of this step's cell, should it lie on a face: pref * nHI, or the quotient itself where
                     // nHI = 0 (pref = inf)
@@ -653,14 +663,19 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
                 }
 #pragma unroll
                 for (int q = 0; q < NSRC; ++q) {
-                    add_phi(late_ok[q], late_idx[q], v_prev[q]);
-                    if (HEAT) add_heat(late_ok[q], late_idx[q], h_prev[q]);
+                    if (BUFATOM) {
+                        add_phi_at(late_off[q], v_prev[q]);
+                        if (HEAT) add_heat_at(late_off[q], h_prev[q]);
+                    } else {
+                        add_phi(late_ok[q], late_idx[q], v_prev[q]);
+                        if (HEAT) add_heat(late_ok[q], late_idx[q], h_prev[q]);
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < NSRC; ++q) {
                     pend_A[q] = A2[q]; pend_B[q] = B2[q]; pend_thick[q] = thick[q]; pend_pref[q] = pref[q]; pend_dtau[q] = dtau[q];
-                    late_idx[q] = dst_idx[q];
-                    late_ok[q] = add[q];
+                    if (BUFATOM) late_off[q] = add[q] ? (int)(dst_idx[q] * 8u) : ASORA_OOB_OFFSET;
+                    else { late_idx[q] = dst_idx[q]; late_ok[q] = add[q]; }
                 }
             }
 #elif ASORA_LATE_ATOMIC
@@ -747,10 +762,12 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     for (int q = 0; q < NSRC; ++q) {
 #if ASORA_LATE_LOOKUP
         const double ta = lookup_value(pend_A[q]), tb = lookup_value(pend_B[q]);
-        add_phi(late_ok[q], late_idx[q], pend_thick[q] ? pend_pref[q] * (ta - tb) : pend_pref[q] * pend_dtau[q] * ta);
+        const double v_last = pend_thick[q] ? pend_pref[q] * (ta - tb) : pend_pref[q] * pend_dtau[q] * ta;
+        if (BUFATOM) add_phi_at(late_off[q], v_last); else add_phi(late_ok[q], late_idx[q], v_last);
         if (HEAT) {
             const double ha = lookup_heat(pend_A[q]), hb = lookup_heat(pend_B[q]);
-            add_heat(late_ok[q], late_idx[q], pend_thick[q] ? pend_pref[q] * (ha - hb) : pend_pref[q] * pend_dtau[q] * ha);
+            const double h_last = pend_thick[q] ? pend_pref[q] * (ha - hb) : pend_pref[q] * pend_dtau[q] * ha;
+            if (BUFATOM) add_heat_at(late_off[q], h_last); else add_heat(late_ok[q], late_idx[q], h_last);
         }
 #else
         add_phi(late_ok[q], late_idx[q], late_v[q]);
@@ -763,7 +780,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
         {
             const double ta = lookup_value(pend_A[0]), tb = lookup_value(pend_B[0]);
             const double po = pend_thick[0] ? pend_pv * tb : pend_pv * (tb - pend_dtau[0] * ta);
-            if (late_ok[0] && pend_edge) loss += po;
+            if ((BUFATOM ? late_off[0] != ASORA_OOB_OFFSET : late_ok[0]) && pend_edge) loss += po;
         }
         // hand the last shell swept to the next sub-box's launch (the step that closed it ended with the barrier and the
         // swap: it is `prev`, complete)
@@ -1080,8 +1097,13 @@ int ensure_logtab(State &st)
     std::vector<double2> lt(LOG_TABLE_SIZE);
     for (int i = 0; i < LOG_TABLE_SIZE; ++i) {
         const long double c = 1.0L + ((long double)i + 0.5L) / (long double)LOG_TABLE_SIZE;
+#if ASORA_FREXP_LOG       // the mantissa comes as m in [0.5, 1): c/2 is its interval centre (rates_device.hpp)
+        lt[i].x = (double)(2.0L / c);
+        lt[i].y = (double)(std::log2(c) - 1.0L);
+#else
         lt[i].x = (double)(1.0L / c);
         lt[i].y = (double)std::log2(c);
+#endif
     }
     double2 *d = nullptr;
     ASORA_HIP_TRY(hipMalloc(&d, lt.size() * sizeof(double2)));
