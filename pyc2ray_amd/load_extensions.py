@@ -49,6 +49,12 @@ class _LibAsora:
         else:
             _capi.check(self._lib.asora_device_init_ex(int(N), int(num_src_par), int(device_id)), "device_init")
         self._N = int(N)
+        # PYC2RAY_AMD_OPTIONS="13=2,14=2": library options applied after every device_init (asora_set_option; the numbers are
+        # those of include/asora_hip.h).  For running an existing script or the test suite with a non-default variant.
+        import os
+        for item in filter(None, os.environ.get("PYC2RAY_AMD_OPTIONS", "").split(",")):
+            opt, _, val = item.partition("=")
+            self.set_option(int(opt), int(val))
 
     def device_close(self):
         _capi.check(self._lib.asora_device_close(), "device_close")
