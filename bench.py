@@ -608,7 +608,14 @@ def main():
             {"kernel": "raytrace_octant_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "bytes_per_unit": RT_BYTES_PER_UPDATE,
              "units_per_launch": gamma_cells, "avg_launch_ms": rt_ms / max(rt_n, 1), "share_of_step": (rt_ms / n_timed) / (elapsed / K * 1e3),
-             "counter_bytes": pmc_traffic_bytes("raytrace_octant_kernel") if default_job else None},
+             "counter_bytes": pmc_traffic_bytes("raytrace_octant_kernel") if default_job else None,
+             # secondary line ("FP64-vector utilisation ... may make the raytrace compute-bound before HBM"): VALU
+             # wave-instructions per launch from the committed counters over this run's launch time, against one wave-instruction
+             # per SIMD every 4 cycles (1024 SIMDs at the 2.4 GHz maximum clock, MI355X_MICROARCH.md)
+             "valu_issue": ({"wave_instructions_per_launch": rt_counters["SQ_INSTS_VALU"],
+                             "achieved_per_s": rt_counters["SQ_INSTS_VALU"] / rt_launch_s, "peak_per_s": 1024 * 2.4e9 / 4.0,
+                             "frac": rt_counters["SQ_INSTS_VALU"] / rt_launch_s / (1024 * 2.4e9 / 4.0), "source": PMC_SUMMARY}
+                            if (default_job and "SQ_INSTS_VALU" in rt_counters and rt_n) else None)},
             {"kernel": "chemistry_tile_kernel", "bound": "hbm", "achieved": ch_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": (ch_achieved / HBM_PEAK_GBS) if ch_achieved else None, "bytes_per_unit": CHEM_BYTES_PER_UPDATE,
              "units_per_launch": chem_cells, "avg_launch_ms": ch_ms / max(ch_n, 1), "share_of_step": (ch_ms / n_timed) / (elapsed / K * 1e3),
