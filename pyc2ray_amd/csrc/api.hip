@@ -151,6 +151,7 @@ static int release_all()
     drop(st.src_pos); drop(st.src_flux); drop(st.src_pos_sorted); drop(st.src_flux_sorted); st.src_i0_sorted.clear(); st.num_src = 0;
     drop(st.shell_scratch); st.shell_scratch_bytes = 0;
     drop(st.sb_trail); st.sb_trail_bytes = 0;
+    if (st.geom_patch_dev) { (void)hipFree(st.geom_patch_dev); st.geom_patch_dev = nullptr; st.geom_patch_cap = 0; }
     drop(st.sb_active); drop(st.sb_nbox); drop(st.sb_loss); drop(st.sb_loss_final); st.subbox_cap = 0;
     release_geometry(st);
     st.init = false; st.N = 0; st.ncell = 0;
