@@ -78,6 +78,56 @@ def main():
             def Bcast(self, buf, root=0):
                 return comm.Bcast(buf, root=root)
         the_comm = _MPIOnly()
+    if spec[0] == "cfg3":
+        # BASELINE configs[3] at full size, sharded over the ranks (all of them on GPU 0, planes staged through the host by
+        # gloo): ONE slab iteration of the real library -- trace of the rank's sources, rates to the owners, slab chemistry,
+        # xh_av back -- then the owners' slabs gathered; the caller compares with the reference Fortran's fixture
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import bench
+        import make_bigconfig_golden as MB
+        import pyc2ray_amd as p
+        from pyc2ray_amd import _capi
+        from pyc2ray_amd.load_extensions import load_asora
+        from pyc2ray_amd.utils.sourceutils import format_sources
+        N, NS, R = 256, 1000, 32.0
+        thin, thick, dlog = bench.make_tables()
+        if "512" in spec[1:]:       # configs[4]'s grid and source list, the 256 sources of the reference fixture (cfg3:512)
+            N = 512
+            ndens, xh, temp, dr, pos, flux = bench.make_workload("cosmo", N, 100000)
+            sub = MB.subset_indices(100000, 256)
+            pos, flux = pos[:, sub], flux[sub]
+            NS = 256
+        else:
+            ndens, xh, temp, dr, pos, flux = bench.make_workload("cosmo", N, NS)
+        lib = load_asora()
+        p.device_init(N, 8, device_id=0)
+        p.photo_table_to_device(thin, thick)
+        comm.exchange = "slab"
+        spos, sflux, bounds = comm.shard_sources_by_slab(pos, flux, world)
+        plan = pd.SlabPlan(N, world, R, [spos[0, bounds[r]:bounds[r + 1]] - 1 for r in range(world)])
+        lo, hi = bounds[rank], bounds[rank + 1]
+        p0, f0 = format_sources(spos[:, lo:hi], sflux[lo:hi])
+        lib.source_data_to_device(p0, f0, hi - lo)
+        for which, a in ((_capi.GRID_NDENS, ndens), (_capi.GRID_TEMP, temp), (_capi.GRID_XH, xh)):
+            lib.grid_to_device(which, a)
+        lib.grid_copy(_capi.GRID_XH_AV, _capi.GRID_XH)
+        lib.grid_copy(_capi.GRID_XH_INTERMED, _capi.GRID_XH)
+        lib.set_option(_capi.OPT_FORTRAN_CONSTANTS, 1)          # the fixture is the Fortran path
+        chem = (bench.MYR, bench.BH00, bench.ALBPOW, bench.COLH0, bench.TEMPH0, bench.ABU_C)
+        conv, s1, s0 = comm.slab_iteration(lib, plan, N, R, bench.SIG, dr, hi - lo, bench.MINLOGTAU, dlog, thin.shape[0] - 1, chem, True)
+        comm.slab_gather(lib, plan, _capi.GRID_PHI_ION, N)
+        comm.slab_gather(lib, plan, _capi.GRID_XH_INTERMED, N)
+        phi = lib.grid_to_host(_capi.GRID_PHI_ION, np.empty((N, N, N)))
+        x = lib.grid_to_host(_capi.GRID_XH_INTERMED, np.empty((N, N, N)))
+        d = MB.digest(phi)
+        src_flat = ((pos[0] - 1) * N + (pos[1] - 1)) * N + (pos[2] - 1)
+        np.savez(out, vals=phi.ravel()[MB.sample_indices(N, pos, 20260300 + N)], src_vals=phi.ravel()[src_flat], plane_sums=d["plane_sums"],
+                 block_sums=d["block_sums"], nonzero=d["nonzero"], total=d["total"], conv=conv, s1=s1, s0=s0, x_sum=float(x.sum()),
+                 nsrc=hi - lo, sent=plan.bytes_per_rank(rank)[0])
+        p.device_close()
+        comm.Barrier()
+        _shutdown()
+        return
     golden_case = None
     if spec[0] == "mpigolden":
         # a use_gpu=True case of tests/cases.py, every time step of it: compared with the REFERENCE'S evolve3D_MPI

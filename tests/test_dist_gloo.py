@@ -310,3 +310,41 @@ def test_evolve3D_MPI_with_the_hip_library_reproduces_the_reference_evolve3D_MPI
     """The same with the HIP library under every rank (all ranks on GPU 0, exchanges staged through the host by gloo)."""
     res = _run_workers(tmp_path, world, f"mpigolden:{name}:slab:real")
     _check_against_reference_mpi(res, name, world, 1e-8, 1e-7)
+
+
+@pytest.mark.gpu
+def test_config4_grid_sharded_over_two_ranks_against_reference_fortran(tmp_path):
+    """The same at configs[4]'s size: 512^3 (1 GiB grids, plane runs of 64 MiB and more through the exchange), the 256 sources
+    of the reference fixture sharded over two ranks."""
+    res = _run_workers(tmp_path, 2, "cfg3:512", timeout=1100)
+    g = np.load(os.path.join(HERE, "golden", "fullsize_cosmo512_R32.npz"))
+    assert sum(int(r["nsrc"]) for r in res) == 256
+    for r in res:
+        assert int(r["conv"]) == int(res[0]["conv"]) and float(r["x_sum"]) == float(res[0]["x_sum"])
+        np.testing.assert_allclose(r["vals"], g["vals"], rtol=1e-8, atol=0)
+        np.testing.assert_allclose(r["src_vals"], g["src_vals"], rtol=1e-8, atol=0)
+        assert int(r["nonzero"]) == int(g["nonzero"])
+        np.testing.assert_allclose(r["plane_sums"], g["plane_sums"], rtol=1e-9)
+        np.testing.assert_allclose(float(r["total"]), float(g["total"]), rtol=1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_config3_full_size_sharded_over_ranks_against_reference_fortran(tmp_path, world):
+    """BASELINE configs[3] at its full size in its multi-GPU mode -- 256^3 log-normal density, the 1000 sources sharded over
+    the ranks by slab of the first coordinate, rates sent plane-wise to the owners, slab chemistry, xh_av back -- with the HIP
+    library under every rank (all ranks on GPU 0, planes through the host by gloo).  The summed rates every rank ends up with
+    against the reference Fortran's sparse fixture (tests/golden/make_bigconfig_golden.py); the slab chemistry's reductions
+    identical on every rank."""
+    res = _run_workers(tmp_path, world, "cfg3", timeout=900)
+    g = np.load(os.path.join(HERE, "golden", "fullsize_cosmo256_R32.npz"))
+    assert sum(int(r["nsrc"]) for r in res) == 1000
+    for r in res:
+        assert int(r["conv"]) == int(res[0]["conv"]) and float(r["s1"]) == float(res[0]["s1"]) and float(r["x_sum"]) == float(res[0]["x_sum"])
+        np.testing.assert_allclose(r["vals"], g["vals"], rtol=1e-8, atol=0)
+        np.testing.assert_allclose(r["src_vals"], g["src_vals"], rtol=1e-8, atol=0)
+        assert int(r["nonzero"]) == int(g["nonzero"])
+        np.testing.assert_allclose(r["plane_sums"], g["plane_sums"], rtol=1e-9)
+        np.testing.assert_allclose(r["block_sums"], g["block_sums"], rtol=1e-9, atol=1e-12 * float(np.abs(g["block_sums"]).max()))
+        np.testing.assert_allclose(float(r["total"]), float(g["total"]), rtol=1e-10)
+    assert max(int(r["sent"]) for r in res) < 100 * 256 * 256 * 8          # planes, not grids, travel
