@@ -109,6 +109,10 @@ def workload_label(kind, N, nsrc_total, R, world, strong):
 
 
 PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.txt")
+# 64-B atomic requests per second the memory side takes from no-return global_atomic_add_f64 (rows of 8 ... 4096 doubles at any
+# alignment, scattered over 2 x 256^3 doubles): tools/micro/atomic_rate.hip, measured on MI355X
+ATOMIC_REQUEST_CEILING = 2.28e10
+ATOMIC_CEILING_SOURCE = os.path.join("profiles", "r03_atomic_rate_microbench.txt")
 
 
 def pmc_counters(kernel):
@@ -598,10 +602,13 @@ def main():
             "algorithmic_bytes_per_launch": RT_BYTES_PER_UPDATE * gamma_cells,
             "avg_launch_ms": rt_ms / max(rt_n, 1),
             "launches_timed": rt_n,
-            "binding_resource": ("FP64/integer VALU issue (%.3g VALU wave-instructions per launch, ~180 per 64 cells and source with two sources per "
-                                 "workgroup: the SIMDs are ~70 %% busy), then the memory-side rate atomics (TCC_EA0_ATOMIC %.3g 64-B requests per "
-                                 "launch, %s; ~10 %% of the launch); DESIGN.md 8.0"
-                                 % (rt_counters.get("SQ_INSTS_VALU", float("nan")), rt_counters.get("TCC_EA0_ATOMIC_sum", float("nan")), PMC_SUMMARY))
+            "binding_resource": ("the memory-side rate atomics: every double added to the rate grid leaves the L2 in a 64-B atomic request "
+                                 "(TCC_EA0_ATOMIC %.3g per launch, %s: 5.9 doubles each, 6.4 is the bound of the sphere's row geometry), and "
+                                 "the memory side takes %.3g of them per second (%s); `atomic_requests.frac` in roofline_kernels is this "
+                                 "launch against that ceiling.  Next the FP64/integer VALU stream (%.3g wave-instructions per launch, "
+                                 "`valu_issue`); HBM bytes are not close (`traffic`).  DESIGN.md 8.0"
+                                 % (rt_counters.get("TCC_EA0_ATOMIC_sum", float("nan")), PMC_SUMMARY, ATOMIC_REQUEST_CEILING,
+                                    ATOMIC_CEILING_SOURCE, rt_counters.get("SQ_INSTS_VALU", float("nan"))))
                                 if default_job else None,
         },
         "roofline_kernels": [
@@ -615,7 +622,14 @@ def main():
              "valu_issue": ({"wave_instructions_per_launch": rt_counters["SQ_INSTS_VALU"],
                              "achieved_per_s": rt_counters["SQ_INSTS_VALU"] / rt_launch_s, "peak_per_s": 1024 * 2.4e9 / 4.0,
                              "frac": rt_counters["SQ_INSTS_VALU"] / rt_launch_s / (1024 * 2.4e9 / 4.0), "source": PMC_SUMMARY}
-                            if (default_job and "SQ_INSTS_VALU" in rt_counters and rt_n) else None)},
+                            if (default_job and "SQ_INSTS_VALU" in rt_counters and rt_n) else None),
+             # what binds the launch: 64-B atomic requests leaving the L2 (committed counters) over this run's launch time,
+             # against the rate a bare stream of such atomics reaches (tools/micro/atomic_rate.hip)
+             "atomic_requests": ({"requests_per_launch": rt_counters["TCC_EA0_ATOMIC_sum"],
+                                  "achieved_per_s": rt_counters["TCC_EA0_ATOMIC_sum"] / rt_launch_s, "ceiling_per_s": ATOMIC_REQUEST_CEILING,
+                                  "frac": rt_counters["TCC_EA0_ATOMIC_sum"] / rt_launch_s / ATOMIC_REQUEST_CEILING,
+                                  "source": PMC_SUMMARY + ", " + ATOMIC_CEILING_SOURCE}
+                                 if (default_job and "TCC_EA0_ATOMIC_sum" in rt_counters and rt_n) else None)},
             {"kernel": "chemistry_tile_kernel", "bound": "hbm", "achieved": ch_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": (ch_achieved / HBM_PEAK_GBS) if ch_achieved else None, "bytes_per_unit": CHEM_BYTES_PER_UPDATE,
              "units_per_launch": chem_cells, "avg_launch_ms": ch_ms / max(ch_n, 1), "share_of_step": (ch_ms / n_timed) / (elapsed / K * 1e3),

@@ -181,8 +181,8 @@ static void fill_rt_params(RtParams &p, double R, double sig, double dr, double 
     p.N = st.N;
     p.R = R; p.sig = sig; p.dr = dr;
     p.minlogtau = minlogtau; p.dlogtau = dlogtau;
-    p.NumTau = NumTau; p.numtau_f = (double)(float)NumTau;     // min(float(NumTau), ...) rates.cu:79
     p.table_len = st.table_len > 0 ? st.table_len : 1;
+    p.NumTau = NumTau; p.numtau_f = lut_index_limit(NumTau, p.table_len);
     p.fortran_consts = st.opt[ASORA_OPT_FORTRAN_CONSTANTS];
     p.grey = st.opt[ASORA_OPT_GREY_NOTABLES];
     p.z_transposed = st.opt[ASORA_OPT_Z_TRANSPOSED] != 0 ? 1 : 0;
@@ -351,7 +351,7 @@ static int subbox_core(const SubboxCall &c, long long &total_nbox, double &total
     p.N = N; p.W = std::max(S_all, 0) + 1;
     p.ext_r = ext_r; p.ext_l = ext_l;
     p.sig = c.sig; p.dr = c.dr; p.R = c.R;
-    p.numtau_f = (double)(float)c.NumTau;                                  // photorates.f90:141 real(NumTau)
+    p.numtau_f = lut_index_limit(c.NumTau, c.table_len);                   // photorates.f90:141 real(NumTau)
     p.lut_k1 = 0.30102999566398119521 / c.dlogtau;
     p.lut_k0 = 1.0 - c.minlogtau / c.dlogtau;
     p.table_len = c.table_len;

@@ -28,6 +28,16 @@ constexpr int MAX_UNITS = 96;   // workgroups per source: 8 octants, 12 mirrored
 // nothing, and asora_last_raytrace_counts sums the slots.
 constexpr int COUNTER_SLOTS = 4096;
 
+// Upper limit of the real table index in photo_lookuptable: min(float(NumTau), ...) of rates.cu:79 / real(NumTau) of
+// photorates.f90:141, and never beyond the last element the device table holds (the reference reads one past the end when the
+// caller passes NumTau = len(table), asora_core.py:54; index table_len - 1 is the pair {T[last], 0}).  With the limit applied to
+// the REAL index the integer index needs no clamp of its own (rates_device.hpp, lookup_issue).
+inline double lut_index_limit(int NumTau, int table_len)
+{
+    const double by_reference = (double)(float)NumTau, by_table = (double)(table_len > 0 ? table_len - 1 : 0);
+    return by_reference < by_table ? by_reference : by_table;
+}
+
 struct RtParams {
     int N;
     int S;                 // last Chebyshev shell over all octants

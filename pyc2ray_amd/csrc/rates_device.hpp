@@ -6,17 +6,24 @@
 namespace asora {
 
 constexpr double FOURPI = 12.566370614359172463991853874177;   // raytracing.cu:12
-constexpr int LOG_TABLE_BITS = 7;
+#ifndef ASORA_LOG_TABLE_BITS
+#define ASORA_LOG_TABLE_BITS 8
+#endif
+constexpr int LOG_TABLE_BITS = ASORA_LOG_TABLE_BITS;
 constexpr int LOG_TABLE_SIZE = 1 << LOG_TABLE_BITS;
 
 // ---------------------------------------------------------------------------------------------
 // Rates (src/asora/rates.cu)
 // ---------------------------------------------------------------------------------------------
 
-// log2 of a positive normal double: exponent + table (2^7 intervals of the mantissa: 1/c and
-// log2 c at the interval centres, staged in LDS) + degree-6 series in r = m/c - 1, |r| < 2^-8
-// (truncation 3e-18).  Absolute error ~1 ulp of the result, like libm's log10; it replaces
-// log10 in the table lookup because two of them per cell dominated the instruction count.
+// log2 of a positive normal double: exponent + table (2^LOG_TABLE_BITS intervals of the mantissa: 1/c and
+// log2 c at the interval centres, staged in LDS) + series in r = m/c - 1; it replaces log10 in the table
+// lookup because two of them per cell dominated the instruction count.
+//   7 bits (rounds 1-3a): |r| < 2^-8, six terms, truncation 3e-18;
+//   8 bits (4 KiB of LDS): |r| < 2^-9, FOUR terms; the first one dropped is r^5/(5 ln 2) < 8.2e-15, against an ulp of
+//   3.5e-15 ... 7e-15 of log2(tau) itself for tau outside [2^-16, 2^16] and of 2.3e-13 ... 3.6e-12 of the table index
+//   k0 + k1 log2(tau) (k0 = 1 - minlogtau/dlogtau = 1668 ... 16668) that the logarithm is formed for: below the rounding
+//   of the index, like libm's log10 in the reference.
 // ASORA_FREXP_LOG = 1: mantissa and exponent through v_frexp_mant_f64 / v_frexp_exp_i32_f64 (x = m * 2^e, m in [0.5, 1)) instead of
 // shifts and masks on the bit pattern (4 instead of 7 integer instructions per logarithm); the table then holds {2/c, log2(c) - 1}
 // for the same interval centres c in [1, 2) (ensure_logtab), so that r = m * (2/c) - 1 and log2 x = e + (log2 c - 1) + log2(1 + r).
@@ -43,7 +50,12 @@ __device__ __forceinline__ double log2_pos(double x, const double2 *__restrict__
     // log2(1+r) = r/ln2 * (1 - r/2 + r^2/3 - r^3/4 + r^4/5 - r^5/6)
     const double C1 = 1.4426950408889634074, C2 = -0.72134752044448170368, C3 = 0.48089834696298780245,
                  C4 = -0.36067376022224085184, C5 = 0.28853900817779268147, C6 = -0.24044917348149390123;
+#if ASORA_LOG_TABLE_BITS >= 8
+    (void)C5; (void)C6;
+    const double p = r * fma(r, fma(r, fma(r, C4, C3), C2), C1);
+#else
     const double p = r * fma(r, fma(r, fma(r, fma(r, fma(r, C6, C5), C4), C3), C2), C1);
+#endif
     return (double)e + (t.y + p);
 }
 
@@ -63,16 +75,20 @@ __device__ __forceinline__ Lookup lookup_issue(const double2 *__restrict__ table
 #else
     const double l2 = log2_pos(fmax(1.0e-20, tau), logtab);
 #endif
+    // numtau_f is clamped to table_len - 1 on the host (lut_index_limit): real_i >= table_len - 1 reads the last pair
+    // {T[last], 0} whatever the residual, as the reference's i0 = i1 = NumTau does -- no integer clamp here
     const double real_i = fmin(p.numtau_f, fmax(0.0, fma(l2, p.lut_k1, p.lut_k0)));
     const int i0 = (int)real_i;
     Lookup L;
     L.residual = __builtin_amdgcn_fract(real_i);          // real_i - (double)i0 for real_i >= 0, one instruction
-    int i = min(i0, p.table_len - 1) + offset;
+    unsigned i = (unsigned)(i0 + offset);
 #ifdef ASORA_ENABLE_ABLATION
-    if (p.ablate & 8) i = 15000 + (threadIdx.x & 3);   // diagnostic: perfectly coalesced lookups
+    if (p.ablate & 8) i = 15000u + (threadIdx.x & 3);   // diagnostic: perfectly coalesced lookups
 #endif
-    L.t = table[i];
-    if (HEAT) L.h = table[i + 2 * p.table_len]; else L.h = L.t;
+    // a 32-bit byte offset from the (wave-uniform) table base: one shift, and the load takes base + offset by itself
+    const char *base = reinterpret_cast<const char *>(table);
+    L.t = *reinterpret_cast<const double2 *>(base + (i << 4));
+    if (HEAT) L.h = *reinterpret_cast<const double2 *>(base + ((i + 2u * (unsigned)p.table_len) << 4)); else L.h = L.t;
     return L;
 }
 __device__ __forceinline__ double lookup_value(const Lookup &L) { return fma(L.residual, L.t.y, L.t.x); }
@@ -93,17 +109,24 @@ __device__ __forceinline__ double add_unfused(double a, double b)
     return a + b;
 }
 
-// x / y for finite y != 0 of ordinary magnitude: hardware reciprocal, two Newton steps, one correction of the quotient --
-// 8 instructions instead of the 12 of the IEEE sequence (v_div_scale x 2, v_div_fmas, v_div_fixup guard against operands
-// near the ends of the exponent range, which column densities, interpolation weights and cell volumes are not).  The
-// quotient is within half an ulp of the exact one in all but ~1e-4 of the cases and within one ulp otherwise; results
-// are compared with the oracle at 1e-8 (rates) and 1e-12 (column densities).  y = 0 gives NaN: callers that can meet it
-// handle it themselves (see pref in raytrace.hip).
+// x / y for finite y != 0 of ordinary magnitude: hardware reciprocal, Newton on the reciprocal, one correction of the
+// quotient -- 6 instructions instead of the 12 of the IEEE sequence (v_div_scale x 2, v_div_fmas, v_div_fixup guard against
+// operands near the ends of the exponent range, which column densities, interpolation weights and cell volumes are not).
+// ONE Newton step (ASORA_DIV_NEWTON_STEPS; two until the middle of round 3): v_rcp_f64 is good to 2^-24.4 (measured,
+// tools/micro/div_accuracy.hip -> profiles/r03_div_accuracy.txt); a step squares that, and the correction q + r (x - y q)
+// multiplies the quotient's error by the reciprocal's once more: 2^-73, far below half an ulp.  Over 6.7e7 random operand
+// pairs both forms returned the correctly rounded (IEEE) quotient every time.
+// y = 0 gives NaN: callers that can meet it handle it themselves (see pref in raytrace.hip).
+#ifndef ASORA_DIV_NEWTON_STEPS
+#define ASORA_DIV_NEWTON_STEPS 1
+#endif
 __device__ __forceinline__ double div_newton(double x, double y)
 {
     double r = __builtin_amdgcn_rcp(y);
     r = fma(fma(-y, r, 1.0), r, r);
+#if ASORA_DIV_NEWTON_STEPS >= 2
     r = fma(fma(-y, r, 1.0), r, r);
+#endif
     const double q = x * r;
     return fma(fma(-y, q, x), r, q);
 }

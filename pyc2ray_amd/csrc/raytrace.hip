@@ -405,7 +405,12 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
         // the [k][j][i] copies follow the [i][j][k] grids in memory: one 32-bit index covers both
         // (one formula with the outer and inner coordinate swapped, rather than two under a branch)
         const unsigned outer = zt ? k : i, inner = zt ? i : k;
-        idx = (outer * N + j) * N + inner + (zt ? p.ncell : 0u);
+        // (24-bit multiplies: N <= 1280 (device_init) so outer * N + j < 2^21; a 32-bit integer multiply runs at a quarter of their rate)
+        // (spelled out: from __umul24 the compiler makes one 24-bit and one 64-bit multiply-add)
+        unsigned row, cell;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row) : "v"(outer), "s"(N), "v"(j));
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(cell) : "v"(row), "s"(N), "v"(inner));
+        idx = cell + (zt ? p.ncell : 0u);
         if (ASORA_ABLATED(128)) return p.nhi + (idx & 0xFFFFu);   // diagnostic: nHI from a 512 KiB window (wrong results)
         return p.nhi + idx;
     };
@@ -447,8 +452,11 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     const int edge_own[3] = {sa > 0 ? p.sb_edge_r : p.sb_edge_l, sb > 0 ? p.sb_edge_r : p.sb_edge_l, sc > 0 ? p.sb_edge_r : p.sb_edge_l};
     const int edge_mir[3] = {sa > 0 ? p.sb_edge_l : p.sb_edge_r, sb > 0 ? p.sb_edge_l : p.sb_edge_r, sc > 0 ? p.sb_edge_l : p.sb_edge_r};
 
-    auto step = [&](unsigned e_pf, const uint4 &cur_A, const uint4 &cur_B, const double (&cur_nhi)[NSRC], const unsigned (&cur_idx)[NSRC],
+    // `first_c`: std::true_type for the steps of a unit's first triple -- the only ones that can hold shell 1, whose cells next to
+    // the source get the diagonal factors of raytracing.cu:431-441; every other step is compiled without that block.
+    auto step = [&](auto first_c, unsigned e_pf, const uint4 &cur_A, const uint4 &cur_B, const double (&cur_nhi)[NSRC], const unsigned (&cur_idx)[NSRC],
                     const uint4 &nxt_A, double (&nxt_nhi)[NSRC], unsigned (&nxt_idx)[NSRC], uint4 &pf_A, uint4 &pf_B) {
+        constexpr bool FIRST_TRIPLE = decltype(first_c)::value;
 #if ASORA_STEP_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);      // nothing of this step is scheduled into the previous one (see the macro)
 #endif
@@ -531,7 +539,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
 #else
             double cdi = ASORA_DIV(x1 * q1 + x2 * q2 + x3 * q3 + x4 * q4, q1 + q2 + q3 + q4);     // (the weights sum to 1, each max() is >= 0.6)
 #endif
-            if (s == 1) {                                    // diagonal neighbours of the source, cu:431-441
+            if (FIRST_TRIPLE && s == 1) {                    // diagonal neighbours of the source, cu:431-441
                 // (round 3: a wave's entries belong to one shell, so this could be a scalar branch instead of the dozen selects
                 //  the compiler makes of it -- measured: no gain at R = 16 / 32, +5 % at R = 64: the branch splits the
                 //  scheduling region around the LDS reads; left as it is)
@@ -753,10 +761,18 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
 
     // nsteps is a multiple of 3 (the tables are padded to it) and is followed by two more
     // all-invalid steps, so every look-ahead stays inside the tables.
-    for (int k = k_first; k < k_last; k += 3, e += 3 * RT_THREADS) {
-        step(e + 2 * RT_THREADS, A0, B0, nhi0, idx0, A1, nhi1, idx1, A2, B2);
-        step(e + 3 * RT_THREADS, A1, B1, nhi1, idx1, A2, nhi2, idx2, A0, B0);
-        step(e + 4 * RT_THREADS, A2, B2, nhi2, idx2, A0, nhi0, idx0, A1, B1);
+    // Shell 1 (at most 26 cells) is step 0 of a unit's table: the first triple is peeled off with the shell-1 block in it.
+    int k = k_first;
+    if (k == 0 && k < k_last) {
+        step(std::true_type{}, e + 2 * RT_THREADS, A0, B0, nhi0, idx0, A1, nhi1, idx1, A2, B2);
+        step(std::true_type{}, e + 3 * RT_THREADS, A1, B1, nhi1, idx1, A2, nhi2, idx2, A0, B0);
+        step(std::true_type{}, e + 4 * RT_THREADS, A2, B2, nhi2, idx2, A0, nhi0, idx0, A1, B1);
+        k += 3; e += 3 * RT_THREADS;
+    }
+    for (; k < k_last; k += 3, e += 3 * RT_THREADS) {
+        step(std::false_type{}, e + 2 * RT_THREADS, A0, B0, nhi0, idx0, A1, nhi1, idx1, A2, B2);
+        step(std::false_type{}, e + 3 * RT_THREADS, A1, B1, nhi1, idx1, A2, nhi2, idx2, A0, B0);
+        step(std::false_type{}, e + 4 * RT_THREADS, A2, B2, nhi2, idx2, A0, nhi0, idx0, A1, B1);
     }
 #pragma unroll
     for (int q = 0; q < NSRC; ++q) {
@@ -1299,6 +1315,12 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units, const
         if (owner[u] != u) continue;
         if (hg[u].inconsistent)
             return fail(11, "raytrace geometry: a cell of a unit reads a corner outside the unit (internal error)");
+        // the kernel compiles the shell-1 factors into a unit's first three steps only
+        for (size_t q = 3 * (size_t)threads; q < hg[u].cellA.size(); ++q) {
+            const uint4 &ca = hg[u].cellA[q];
+            if ((ca.y & CELL_VALID) && std::max({ca.x & 1023u, (ca.x >> 10) & 1023u, (ca.x >> 20) & 1023u}) == 1u)
+                return fail(11, "raytrace geometry: a cell of shell 1 lies beyond the first three steps (internal error)");
+        }
         Smax = std::max(Smax, hg[u].S);
         max_cells = std::max(max_cells, hg[u].max_cells);
     }

@@ -18,7 +18,8 @@ __global__ void __launch_bounds__(256) adds(double *grid, const unsigned *idx, i
 int main(int argc, char **argv)
 {
     const int row = argc > 1 ? atoi(argv[1]) : 40;          // doubles per row
-    const size_t ncell = (size_t)2 * 256 * 256 * 256;
+    const size_t edge = argc > 2 ? (size_t)atoi(argv[2]) : 256;   // footprint of the target: 2 x edge^3 doubles (256: 256 MiB, the Infinity Cache's size)
+    const size_t ncell = (size_t)2 * edge * edge * edge;
     const int blocks = 256 * 16, threads = 256, per_lane = 64;
     const size_t nthreads = (size_t)blocks * threads, n = nthreads * per_lane;
     std::vector<unsigned> h(n);
@@ -48,7 +49,7 @@ int main(int argc, char **argv)
     for (int r = 0; r < 5; ++r) adds<<<blocks, threads>>>(g, d, per_lane, 1.0);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
-    printf("row=%d doubles: %.3f ms per launch, %.3e atomics/s, %.3e requests/s (%.2f doubles per request)\n", row, ms,
+    printf("target 2 x %zu^3 doubles, row=%d doubles: %.3f ms per launch, %.3e atomics/s, %.3e requests/s (%.2f doubles per request)\n", edge, row, ms,
            n / (ms * 1e-3), requests / (ms * 1e-3), (double)n / requests);
     return 0;
 }

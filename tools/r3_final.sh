@@ -22,4 +22,6 @@ timeout -k 10 300 python tools/pcie_inclusive.py > $O/pcie_inclusive.json 2> $O/
 timeout -k 10 600 python tools/paper_benchmark.py > $O/paper_protocol.json 2> $O/paper.err
 timeout -k 10 300 python tools/test1_stromgren.py --cpu-steps 0 > $O/test1.json 2> $O/test1.err
 timeout -k 10 300 python tools/time_steps_resident.py > $O/time_steps_resident.json 2> $O/tsr.err
+hipcc -O3 --offload-arch=gfx950 -munsafe-fp-atomics -o /tmp/atomic_rate tools/micro/atomic_rate.hip 2> /dev/null && { for ROW in 8 24 40 64 4096; do /tmp/atomic_rate $ROW; done; for EDGE in 64 128 192 320 400; do /tmp/atomic_rate 40 $EDGE; done; } > $O/atomic_rate_microbench.txt 2>&1
+hipcc -O3 --offload-arch=gfx950 -o /tmp/div_accuracy tools/micro/div_accuracy.hip 2> /dev/null && /tmp/div_accuracy > $O/div_accuracy.txt 2>&1
 ls -la $O
