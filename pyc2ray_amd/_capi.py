@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libasora_hip.so")
 GRID_NDENS, GRID_XH_AV, GRID_PHI_ION, GRID_TEMP, GRID_XH, GRID_XH_INTERMED, GRID_PHI_HEAT = range(7)
 (OPT_FORTRAN_CONSTANTS, OPT_GREY_NOTABLES, OPT_TIMING, OPT_Z_TRANSPOSED, OPT_BLOCK_THREADS, OPT_SECTORS,
  OPT_HEATING, OPT_C2RAY_OWN_FLUX, OPT_NO_UNIFORM_T, OPT_SUBBOX_GLOBAL_SHELLS, OPT_PIPELINED_COPIES,
- OPT_SKIP_ZERO_RATES, OPT_GLOBAL_ATOMICS, OPT_PAIR_SOURCES, OPT_SUBBOX_TABLES) = range(15)
+ OPT_SKIP_ZERO_RATES, OPT_GLOBAL_ATOMICS, OPT_PAIR_SOURCES, OPT_SUBBOX_TABLES, OPT_ALIGNED_ROWS) = range(16)
 KERNEL_RAYTRACE, KERNEL_CHEMISTRY, KERNEL_PREP, KERNEL_FINISH = range(4)
 
 _dp = C.POINTER(C.c_double)

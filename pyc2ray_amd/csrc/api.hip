@@ -149,6 +149,8 @@ static int release_all()
     st.have_heat_tables = false;
     drop(st.tables); st.table_len = 0;
     drop(st.src_pos); drop(st.src_flux); drop(st.src_pos_sorted); drop(st.src_flux_sorted); st.src_i0_sorted.clear(); st.num_src = 0;
+    st.src_pos_host.clear(); st.src_pos_sorted_host.clear();
+    release_pair_lists(st);
     drop(st.shell_scratch); st.shell_scratch_bytes = 0;
     drop(st.sb_trail); st.sb_trail_bytes = 0;
     if (st.geom_patch_dev) { (void)hipFree(st.geom_patch_dev); st.geom_patch_dev = nullptr; st.geom_patch_cap = 0; }
@@ -889,6 +891,8 @@ int asora_source_data_to_device(const int32_t *pos, const double *flux, int NumS
     if (st.src_pos_sorted) { (void)hipFree(st.src_pos_sorted); st.src_pos_sorted = nullptr; }
     if (st.src_flux_sorted) { (void)hipFree(st.src_flux_sorted); st.src_flux_sorted = nullptr; }
     st.src_i0_sorted.clear();
+    st.src_pos_host.clear(); st.src_pos_sorted_host.clear();
+    release_pair_lists(st);
     st.num_src = 0;
     if (NumSrc == 0) return 0;
     ASORA_HIP_TRY(hipMalloc(&st.src_pos, sizeof(int32_t) * 3 * (size_t)NumSrc));
@@ -919,7 +923,9 @@ int asora_source_data_to_device(const int32_t *pos, const double *flux, int NumS
         ASORA_HIP_TRY(hipMalloc(&st.src_flux_sorted, sizeof(double) * (size_t)NumSrc));
         ASORA_HIP_TRY(hipMemcpy(st.src_pos_sorted, ps.data(), sizeof(int32_t) * 3 * (size_t)NumSrc, hipMemcpyHostToDevice));
         ASORA_HIP_TRY(hipMemcpy(st.src_flux_sorted, fs.data(), sizeof(double) * (size_t)NumSrc, hipMemcpyHostToDevice));
+        st.src_pos_sorted_host.swap(ps);
     }
+    st.src_pos_host.assign(pos, pos + 3 * (size_t)NumSrc);
     st.num_src = NumSrc;
     return 0;
 }

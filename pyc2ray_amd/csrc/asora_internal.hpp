@@ -67,6 +67,11 @@ struct RtParams {
     double *shell_scratch;      // global shell buffers when they do not fit LDS, else nullptr
     unsigned long long *counters;
     const int *done_flag;       // evolve loop: device flag "the step has converged" -> the launch does nothing; or nullptr
+    // ---- rows cut at 64-byte lines (ASORA_OPT_ALIGNED_ROWS; launch_raytrace) ----
+    int aligned;                // 1: geom[] holds 8 x units tables, [class * units + unit], class = source position & 7 along the
+                                //    memory-contiguous axis of the unit's face (k for the x- and y-sectors, i for the z-sector)
+    const int2 *pairs[2];       // NSRC = 2 && aligned: the workgroup's two sources (indices into src_pos; .y < 0: only one) for
+    int npairs[2];              //    [0] units of the x- / y-sector (equal k & 7), [1] units of the z-sector (equal i & 7)
     // ---- SUBBOX kernels only (the reference's CPU semantics on the tabulated geometry, raytrace.hip / subbox.hip) ----
     int sb_k0[12], sb_k1[12];   // per unit: this launch sweeps the table steps [k0, k1) = the shells of one sub-box (multiples of 3)
     int sb_first;               // 1: the launch starts at the source cell; 0: it continues from the trailing shell in sb_trail
@@ -127,7 +132,13 @@ struct State {
 
     // raytracing geometry tables (built once per (N, R, dr), see raytrace.hip)
     std::vector<void *> geom_owned;
-    OctGeomDev geom_host[MAX_UNITS];        // device pointers of the unit tables
+    OctGeomDev geom_host[MAX_UNITS];        // device pointers of the unit tables ([class * units + unit] when geom_aligned)
+    bool geom_aligned = false;
+    // host copies of the two source lists (as uploaded, and in lexicographic order of the position) and, for the paired-sources
+    // variant on aligned tables, who shares a workgroup with whom: built once per (list, range), see source_pairs_by_class
+    std::vector<int32_t> src_pos_host, src_pos_sorted_host;
+    struct PairList { const void *list; int begin, count; int2 *dev[2]; int n[2]; };
+    std::vector<PairList> pair_lists;      // (a sharded or chunked trace asks for the same few ranges every iteration)
     int geom_units = 0;
     double2 *logtab_dev = nullptr;          // log2 table (ensure_logtab), lives until the runtime is torn down
     bool geom_valid = false;
@@ -208,7 +219,7 @@ struct State {
     struct PendingTimer { int which; hipEvent_t e0, e1; };
     std::vector<PendingTimer> pending_timers;     // recorded, not yet resolved
     std::vector<hipEvent_t> free_events;
-    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0};
+    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0};
     double k_ms[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
     long k_n[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
 };
@@ -240,6 +251,7 @@ struct KernelTimer {
 // ---------------------------------------------------------------------------------------------
 
 void release_geometry(State &st);
+void release_pair_lists(State &st);     // with every change of the source lists
 int launch_fold_range(State &st, const double *src_t, double *dst, int i_begin, int i_count);   // dst[i][j][k] += src_t[k][j][i], i in the range
 int ensure_logtab(State &st);
 int launch_prepare_nhi(State &st, bool need_transposed);

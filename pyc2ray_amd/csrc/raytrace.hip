@@ -269,28 +269,42 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
 #if ASORA_UNITS_LARGEST_FIRST
     unit = p.units - 1 - unit;   // sector units: z (most cells) first, x (fewest) last in dispatch order
 #endif
-    if (src_local * NSRC >= p.src_count) return;
+    const int uinfo = p.geom[unit].info;           // sign bits of the unit | merged axes << 3 | rates-source << 6 | (face + 1) << 8
+    // p.aligned: the unit's tables come in eight forms, by the source's position modulo 8 along the memory-contiguous axis of
+    // the unit's face; the two sources of a workgroup agree in it (the host paired them so: p.pairs)
+    const bool by_class = !SUBBOX && p.aligned != 0;
+    const int face_type = ((uinfo >> 8) & 3) == 3 ? 1 : 0;          // 1: z-sector (rows along i), 0: x- / y-sector (rows along k)
+    const bool listed = by_class && NSRC == 2;
+    if (listed ? src_local >= p.npairs[face_type] : src_local * NSRC >= p.src_count) return;
     if (SUBBOX) { if (!p.sb_active[src_local]) return; }            // this source stopped growing after an earlier box
 
-    const uint4 *__restrict__ cellA = p.geom[unit].cellA;
-    const uint4 *__restrict__ cellB = p.geom[unit].cellB;
-    const int nsteps = p.geom[unit].nsteps;
-    const int uinfo = p.geom[unit].info;           // sign bits of the unit | merged axes << 3 | rates-source << 6
     const int N = p.N;
     int i0[NSRC], j0[NSRC], k0[NSRC];
     double flux[NSRC];
     bool have[NSRC];
     unsigned nreal = 0;
+    int2 listed_pair = {0, -1};
+    if (listed) listed_pair = p.pairs[face_type][src_local];
 #pragma unroll
     for (int q = 0; q < NSRC; ++q) {
-        have[q] = src_local * NSRC + q < p.src_count;
-        const int ns = p.src_begin + (have[q] ? src_local * NSRC + q : src_local * NSRC);
+        int ns;
+        if (listed) {
+            have[q] = q == 0 || listed_pair.y >= 0;
+            ns = (q == 0 || listed_pair.y < 0) ? listed_pair.x : listed_pair.y;
+        } else {
+            have[q] = src_local * NSRC + q < p.src_count;
+            ns = p.src_begin + (have[q] ? src_local * NSRC + q : src_local * NSRC);
+        }
         i0[q] = p.src_pos[3 * ns + 0];
         j0[q] = p.src_pos[3 * ns + 1];
         k0[q] = p.src_pos[3 * ns + 2];
         flux[q] = p.src_flux[(SUBBOX && p.flux_src >= 0) ? p.flux_src : ns];
         nreal += have[q] ? 1u : 0u;
     }
+    const int table = by_class ? unit + p.units * ((face_type ? i0[0] : k0[0]) & 7) : unit;
+    const uint4 *__restrict__ cellA = p.geom[table].cellA;
+    const uint4 *__restrict__ cellB = p.geom[table].cellB;
+    const int nsteps = p.geom[table].nsteps;
     const int sa = (uinfo & 1) ? -1 : 1, sb = (uinfo & 2) ? -1 : 1, sc = (uinfo & 4) ? -1 : 1;
 
     // LDS: the small tables sit first, at compile-time offsets (TABCAP entries each), then the shell buffers
@@ -874,8 +888,13 @@ struct UnitSpec {
 
 // boxsize > 0 (sub-box tables): every shell that closes a sub-box (a multiple of boxsize) is followed by all-invalid steps
 // up to a whole triple of steps, so that a launch can sweep exactly one sub-box with the three-step pipeline
+// align_class in 0..7 (units of ONE face only): the tables of the sources whose position along the memory-contiguous axis of
+// that face (k for the x- and y-sector, i for the z-sector, whose rates go to the [k][j][i] twin) is align_class modulo 8.
+// The rated cells of a row that fall into one 64-byte line of the rate grid then never straddle two 64-lane waves (invalid
+// entries fill the wave up instead: ~3 % more lane-steps), so a wave's atomics leave as whole-line requests: 6.4 instead of
+// 5.9 doubles per request at r_RT = 32.  -1: entries packed densely.
 void build_unit_geometry(HostGeom &h, const UnitSpec &us, double R, double dr, int q_max, uint32_t zero_slot_marker,
-                         int RT_THREADS, int boxsize = 0)
+                         int RT_THREADS, int boxsize = 0, int align_class = -1)
 {
     const double R2 = R * R;
     const double R2hi = R2 * (1.0 + 1e-9) + 1e-9;
@@ -995,6 +1014,39 @@ void build_unit_geometry(HostGeom &h, const UnitSpec &us, double R, double dr, i
             }
         }
         if (count == 0) break;                        // nothing further out either
+        if (align_class >= 0 && us.face >= 0) {
+            // repack the shell (it starts on a step, hence a wave boundary): runs of rated own-face cells of one row within one
+            // 64-byte line stay in one wave
+            const size_t end = h.cellA.size(), begin = end - count;
+            const int fast = us.face == 2 ? 0 : 2;
+            const uint32_t fast_mask = ~((1023u << (10 * fast)));
+            const uint32_t other_neg = (7u & ~(1u << fast)) << CELL_NEG_SHIFT;
+            auto fast_of = [&](const uint4 &ca) -> int {
+                const int mag = (int)((ca.x >> (10 * fast)) & 1023u);
+                return ((ca.y >> (CELL_NEG_SHIFT + fast)) & 1u) ? -mag : mag;
+            };
+            auto line_of = [&](int f) -> int { return (align_class + f + 8192) >> 3; };
+            auto rated = [&](const uint4 &ca) -> bool { return (ca.y & (CELL_RATE | CELL_SPHERE)) != 0 && (int)(ca.x >> 30) == us.face; };
+            std::vector<uint4> ra, rb;
+            ra.reserve(count + count / 8); rb.reserve(count + count / 8);
+            size_t q = begin;
+            while (q < end) {
+                size_t e = q + 1;
+                if (rated(h.cellA[q])) {
+                    const int line = line_of(fast_of(h.cellA[q]));
+                    while (e < end && rated(h.cellA[e]) && (h.cellA[e].x & fast_mask) == (h.cellA[q].x & fast_mask) &&
+                           (h.cellA[e].y & other_neg) == (h.cellA[q].y & other_neg) &&
+                           fast_of(h.cellA[e]) == fast_of(h.cellA[e - 1]) + 1 && line_of(fast_of(h.cellA[e])) == line) ++e;
+                }
+                const size_t n = e - q, pos = ra.size() % 64;
+                if (pos + n > 64) for (size_t t = pos; t < 64; ++t) { ra.push_back(pad_a); rb.push_back(pad_b); }
+                for (size_t t = q; t < e; ++t) { ra.push_back(h.cellA[t]); rb.push_back(h.cellB[t]); }
+                q = e;
+            }
+            h.cellA.resize(begin); h.cellB.resize(begin);
+            h.cellA.insert(h.cellA.end(), ra.begin(), ra.end());
+            h.cellB.insert(h.cellB.end(), rb.begin(), rb.end());
+        }
         // pad the shell to whole steps and flag every entry of its last step
         while (h.cellA.size() % RT_THREADS) { h.cellA.push_back(pad_a); h.cellB.push_back(pad_b); }
         for (size_t q = h.cellA.size() - RT_THREADS; q < h.cellA.size(); ++q) h.cellA[q].y |= CELL_LAST;
@@ -1171,8 +1223,11 @@ static int patch_sphere_cells(State &st, double R, double dr)
 // Build (or reuse) the geometry tables for this (N, R, dr).  dr only enters through the
 // classification of cells sitting exactly on the sphere (see inside_radius_reference).
 struct SubboxGeometry { int ext_r, ext_l, boxsize; };     // sub-box tables: the traversal range of raytracing.f90:174-175, the box size
-static int ensure_geometry(State &st, RtParams &p, int threads, int units, const SubboxGeometry *sbg = nullptr)
+static int ensure_geometry(State &st, RtParams &p, int threads, int units, const SubboxGeometry *sbg = nullptr, bool aligned = false)
 {
+    // aligned (units of one face: 6 or 12 per source): eight tables per unit, [class * units + unit], see build_unit_geometry
+    if (aligned && (sbg || !(units == 6 || units == 12))) return fail(11, "raytrace geometry: aligned tables for this kind of unit (internal error)");
+    const int classes = aligned ? 8 : 1, tables = units * classes;
     const int N = p.N;
     // (the Fortran path has no octahedron bound and its own range instead of the ASORA window)
     const int q_max = sbg ? (1 << 28) : (int)std::ceil(1.73205080757 * std::min(p.R, 1.73205080757 * N / 2.0));   // raytracing.cu:14,101
@@ -1182,13 +1237,14 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units, const
     // dr only matters for the cells that sit exactly on the sphere (a cosmological run changes dr every step): their RATE
     // bits are re-decided in place
     if (st.geom_valid && st.geom_N == N && st.geom_R == p.R && st.geom_threads == threads && st.geom_units == units &&
-        st.geom_subbox == (sbg ? 1 : 0) && (!sbg || (st.geom_ext_r == ext_pos && st.geom_ext_l == ext_neg && st.geom_boxsize == boxsize))) {
+        st.geom_aligned == aligned && st.geom_subbox == (sbg ? 1 : 0) && (!sbg || (st.geom_ext_r == ext_pos && st.geom_ext_l == ext_neg && st.geom_boxsize == boxsize))) {
         if (st.geom_dr != p.dr && !st.geom_sphere.empty()) {
             if (int rc = patch_sphere_cells(st, p.R, p.dr)) return rc;
         }
         st.geom_dr = p.dr;
-        for (int o = 0; o < units; ++o) p.geom[o] = st.geom_host[o];
+        for (int o = 0; o < tables; ++o) p.geom[o] = st.geom_host[o];
         p.units = units;
+        p.aligned = aligned ? 1 : 0;
         p.logtab = st.logtab_dev; p.S = st.geom_S; p.max_cells = st.geom_max_cells;
         return 0;
     }
@@ -1252,7 +1308,7 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units, const
         us.ext_neg = ext_neg;
         // exactly one unit rates the source cell: the all-positive one (of the z-sector when there are sectors)
         const bool rates_source = !neg[0] && !neg[1] && !neg[2] && (us.face == -1 || us.face == 2) && us.wedge <= 0;
-        info[u] = neg[0] | (neg[1] << 1) | (neg[2] << 2) | (us.merge_mask << 3) | (rates_source ? 64 : 0);
+        info[u] = neg[0] | (neg[1] << 1) | (neg[2] << 2) | (us.merge_mask << 3) | (rates_source ? 64 : 0) | ((us.face + 1) << 8);
     }
     int owner[MAX_UNITS];
     for (int u = 0; u < units; ++u) {
@@ -1266,7 +1322,7 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units, const
             }
         }
     }
-    std::vector<HostGeom> hg(units);
+    std::vector<HostGeom> hg(tables);       // [class * units + unit]; the distinct ones are at [class * units + owner[unit]]
     OctGeomDev od[MAX_UNITS];
     const bool geom_timing = getenv("ASORA_GEOM_TIMING") != nullptr;
     auto now_s = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1280,13 +1336,16 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units, const
         std::vector<std::thread> workers;
         const double R_all = p.R, dr_all = p.dr;
         if (units != 96) {
-            for (int u = 0; u < units; ++u) {
-                if (owner[u] != u) continue;
-                workers.emplace_back([&hg, &spec, u, R_all, dr_all, q_max, threads, boxsize]() {
-                    build_unit_geometry(hg[u], spec[u], R_all, dr_all, q_max, MARK, threads, boxsize);
-                });
+            for (int cls = 0; cls < classes; ++cls) {
+                for (int u = 0; u < units; ++u) {
+                    if (owner[u] != u) continue;
+                    workers.emplace_back([&hg, &spec, u, cls, units, aligned, R_all, dr_all, q_max, threads, boxsize]() {
+                        build_unit_geometry(hg[cls * units + u], spec[u], R_all, dr_all, q_max, MARK, threads, boxsize, aligned ? cls : -1);
+                    });
+                }
+                for (auto &w : workers) w.join();
+                workers.clear();
             }
-            for (auto &w : workers) w.join();
         } else {
             // quarter sectors: every distinct sector ONCE (units 0..23 are the wedge-0 units, one per sector and octant),
             // then its four wedges and what they read, again side by side
@@ -1311,24 +1370,24 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units, const
             for (auto &w : workers) w.join();
         }
     }
-    for (int u = 0; u < units; ++u) {
-        if (owner[u] != u) continue;
-        if (hg[u].inconsistent)
+    for (int v = 0; v < tables; ++v) {
+        if (owner[v % units] != v % units) continue;
+        if (hg[v].inconsistent)
             return fail(11, "raytrace geometry: a cell of a unit reads a corner outside the unit (internal error)");
         // the kernel compiles the shell-1 factors into a unit's first three steps only
-        for (size_t q = 3 * (size_t)threads; q < hg[u].cellA.size(); ++q) {
-            const uint4 &ca = hg[u].cellA[q];
+        for (size_t q = 3 * (size_t)threads; q < hg[v].cellA.size(); ++q) {
+            const uint4 &ca = hg[v].cellA[q];
             if ((ca.y & CELL_VALID) && std::max({ca.x & 1023u, (ca.x >> 10) & 1023u, (ca.x >> 20) & 1023u}) == 1u)
                 return fail(11, "raytrace geometry: a cell of shell 1 lies beyond the first three steps (internal error)");
         }
-        Smax = std::max(Smax, hg[u].S);
-        max_cells = std::max(max_cells, hg[u].max_cells);
+        Smax = std::max(Smax, hg[v].S);
+        max_cells = std::max(max_cells, hg[v].max_cells);
     }
     const double t_built = now_s();
     // zero-slot marker -> max_cells (the slot that holds 0.0), then upload
-    for (int u = 0; u < units; ++u) {
-        if (owner[u] != u) continue;
-        HostGeom &h = hg[u];
+    for (int v = 0; v < tables; ++v) {
+        if (owner[v % units] != v % units) continue;
+        HostGeom &h = hg[v];
         for (auto &nb : h.cellB) {
             if (nb.x == MARK) nb.x = max_cells;
             if (nb.y == MARK) nb.y = max_cells;
@@ -1340,7 +1399,7 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units, const
         d.info = 0;
         if (int rc = upload(h.cellA, d.cellA, st.geom_owned)) return rc;
         if (int rc = upload(h.cellB, d.cellB, st.geom_owned)) return rc;
-        od[u] = d;
+        od[v] = d;
         if (h.on_sphere)         // where the on-sphere cells of this table live on the device (see patch_sphere_cells)
             for (size_t e = 0; e < h.cellA.size(); ++e)
                 if (h.cellA[e].y & CELL_SPHERE) {
@@ -1349,10 +1408,10 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units, const
                                               h.cellA[e].y & ~CELL_RATE, (int)(x & 1023), (int)((x >> 10) & 1023), (int)((x >> 20) & 1023)});
                 }
     }
-    for (int u = 0; u < units; ++u) { od[u] = od[owner[u]]; od[u].info = info[u]; }
+    for (int v = 0; v < tables; ++v) { od[v] = od[(v / units) * units + owner[v % units]]; od[v].info = info[v % units]; }
     if (geom_timing) {
         size_t entries = 0;
-        for (int u = 0; u < units; ++u) if (owner[u] == u) entries += hg[u].cellA.size();
+        for (int v = 0; v < tables; ++v) if (owner[v % units] == v % units) entries += hg[v].cellA.size();
         fprintf(stderr, "asora geometry: %d units, %.1f M entries (%.0f MB); sectors %.3f s, wedges/units %.3f s, markers + upload %.3f s\n",
                 units, entries * 1e-6, entries * 32e-6, t_sectors - t_begin, t_built - t_sectors, now_s() - t_built);
     }
@@ -1360,15 +1419,17 @@ static int ensure_geometry(State &st, RtParams &p, int threads, int units, const
     if (int rc = ensure_logtab(st)) return rc;
     const double2 *ltd = st.logtab_dev;
 
-    for (int o = 0; o < units; ++o) st.geom_host[o] = od[o];
+    for (int o = 0; o < tables; ++o) st.geom_host[o] = od[o];
     st.geom_units = units;
+    st.geom_aligned = aligned;
     st.geom_N = N; st.geom_R = p.R; st.geom_dr = p.dr; st.geom_S = Smax; st.geom_max_cells = (int)max_cells;
     st.geom_threads = threads;
     st.geom_subbox = sbg ? 1 : 0; st.geom_ext_r = ext_pos; st.geom_ext_l = ext_neg; st.geom_boxsize = boxsize;
     for (int u = 0; u < units && u < 12; ++u) st.geom_step_after_shell[u] = hg[owner[u]].step_after_shell;
     st.geom_valid = true;
-    for (int o = 0; o < units; ++o) p.geom[o] = od[o];
+    for (int o = 0; o < tables; ++o) p.geom[o] = od[o];
     p.units = units;
+    p.aligned = aligned ? 1 : 0;
     p.logtab = ltd; p.S = Smax; p.max_cells = (int)max_cells;
     return 0;
 }
@@ -1683,6 +1744,42 @@ static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t ld
     return 0;
 }
 
+// Who shares a workgroup with whom when the tables are the aligned kind (build_unit_geometry, align_class): two sources
+// that agree modulo 8 in k (units of the x- and y-sector: list 0) or in i (units of the z-sector: list 1).  The list is walked
+// in its order -- position-sorted for a whole-list call -- and a source waits for the next one of its class, so partners are
+// neighbours in the list, hence in space; what is left over at the end sweeps alone.
+void release_pair_lists(State &st)
+{
+    for (auto &e : st.pair_lists) for (int ft = 0; ft < 2; ++ft) if (e.dev[ft]) (void)hipFree(e.dev[ft]);
+    st.pair_lists.clear();
+}
+
+static int source_pairs_by_class(State &st, const int32_t *host_pos, const void *list, int begin, int count, const State::PairList *&out)
+{
+    for (const auto &e : st.pair_lists)
+        if (e.list == list && e.begin == begin && e.count == count) { out = &e; return 0; }
+    if (st.pair_lists.size() >= 64) release_pair_lists(st);
+    State::PairList e{list, begin, count, {nullptr, nullptr}, {0, 0}};
+    for (int ft = 0; ft < 2; ++ft) {
+        const int axis = ft ? 0 : 2;
+        std::vector<int2> pairs;
+        pairs.reserve((size_t)count / 2 + 8);
+        int open[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+        for (int s = begin; s < begin + count; ++s) {
+            const int c = host_pos[3 * (size_t)s + axis] & 7;
+            if (open[c] < 0) open[c] = s;
+            else { pairs.push_back(int2{open[c], s}); open[c] = -1; }
+        }
+        for (int c = 0; c < 8; ++c) if (open[c] >= 0) pairs.push_back(int2{open[c], -1});
+        e.n[ft] = (int)pairs.size();
+        ASORA_HIP_TRY(hipMalloc(&e.dev[ft], std::max<size_t>(1, pairs.size()) * sizeof(int2)));
+        ASORA_HIP_TRY(hipMemcpy(e.dev[ft], pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice));
+    }
+    st.pair_lists.push_back(e);
+    out = &st.pair_lists.back();
+    return 0;
+}
+
 int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t side)
 {
     int units, threads;   // one workgroup per (source, octant) or per (source, octant, sector)
@@ -1693,7 +1790,19 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
         const int S_est = std::isfinite(R2hi) ? (int)std::min((double)Emax, std::floor(std::sqrt(R2hi))) : Emax;
         if (S_est + 1 > 256 && threads < 256) threads = 256;
     }
-    if (int rc = ensure_geometry(st, p, threads, units)) return rc;
+    // rows cut at 64-byte lines (ASORA_OPT_ALIGNED_ROWS): units of one face, a mesh whose rows start on lines, the [k][j][i]
+    // twin for the z-faces, a source list whose positions the host knows (pairing), and eight times the tables: up to
+    // r ~ 70 (0.5 GB) by default, ~110 on request
+    const int32_t *host_pos = p.src_pos == st.src_pos_sorted ? st.src_pos_sorted_host.data()
+                            : p.src_pos == st.src_pos ? st.src_pos_host.data() : nullptr;
+    bool aligned = false;
+    {
+        const int want = st.opt[ASORA_OPT_ALIGNED_ROWS];
+        const double r = std::min(p.R, 0.87 * p.N);
+        const bool possible = (units == 6 || units == 12) && !dump && p.N % 8 == 0 && p.z_transposed && host_pos != nullptr && r <= 110.0;
+        aligned = possible && (want == 2 || (want == 0 && r <= 72.0));
+    }
+    if (int rc = ensure_geometry(st, p, threads, units, nullptr, aligned)) return rc;
     p.lut_k1 = 0.30102999566398119521 / p.dlogtau;      // log10(2)/dlogtau
     p.lut_k0 = 1.0 - p.minlogtau / p.dlogtau;
     // optical depth from which BOTH lookups of a thick cell return the same table value (index clamped to NumTau, or on
@@ -1763,7 +1872,13 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
         q.src_begin = p.src_begin + done;
         q.src_count = batch;
         q.shell_scratch = use_lds ? nullptr : st.shell_scratch;
-        const int groups = pairs ? (batch + 1) / 2 : batch;              // workgroups per unit
+        int groups = pairs ? (batch + 1) / 2 : batch;              // workgroups per unit
+        if (pairs && aligned) {
+            const State::PairList *pl = nullptr;
+            if (int rc = source_pairs_by_class(st, host_pos, p.src_pos, q.src_begin, batch, pl)) return rc;
+            for (int ft = 0; ft < 2; ++ft) { q.pairs[ft] = pl->dev[ft]; q.npairs[ft] = pl->n[ft]; }
+            groups = std::max(pl->n[0], pl->n[1]);
+        }
         q.spread = (long)groups * units <= 2L * st.cu_count ? 1 : 0;     // few workgroups: spread a source's units over the XCDs
         const unsigned grid = q.spread ? (unsigned)units * (unsigned)groups : 8u * (unsigned)units * (unsigned)((groups + 7) / 8);
         {

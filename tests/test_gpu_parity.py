@@ -1292,6 +1292,74 @@ def test_two_sources_per_workgroup_give_the_same_rates(asora):
     p.device_close()
 
 
+def test_rows_cut_at_64_byte_lines_give_the_same_rates(asora):
+    """ASORA_OPT_ALIGNED_ROWS: the units of one face (six sectors, twelve sector pairs) take their tables by the source's
+    position modulo 8 along the memory-contiguous axis, and the paired variant puts two sources into a workgroup only when
+    they agree in it.  Sources in every class of i and of k whose spheres do not overlap (no summation-order freedom) ->
+    grids IDENTICAL to the densely packed tables, with one and with two sources per workgroup, even, odd and tiny source
+    counts, every workgroup size, sources whose spheres wrap around the box, the Fortran constants; the pair counts the
+    library reports do not change; overlapping sources against the oracle."""
+    p, lib, capi = asora
+    N = 96
+    thin, thick, dlog = cases.soft_tables(400)
+    nd, xh, dr = cases.grid(N, "lognormal", 14, 0.4, xlo=1e-4, xhi=1e-2)
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 8)
+    p.photo_table_to_device(thin, thick)
+    lib.grid_to_device(capi.GRID_NDENS, nd)
+    lib.grid_to_device(capi.GRID_XH_AV, xh)
+    lattice = np.array([(i, j, k) for i in range(2, N, 12) for j in range(2, N, 12) for k in range(2, N, 12)]).T     # spacing 12
+    rng = np.random.RandomState(15)
+    pick = rng.permutation(lattice.shape[1])[:97]
+    pos = lattice[:, pick] + rng.randint(-1, 3, size=(3, 97))    # every residue modulo 8 occurs on every axis; distance >= 9 > 2 R
+    pos[:, 0] = [1, 1, 1]                                         # corners: the periodic wrap is in play
+    pos[:, 1] = [N, 38, N]
+    assert set((pos[0] - 1) % 8) == set(range(8)) and set((pos[2] - 1) % 8) == set(range(8))
+    flux = rng.uniform(1.0, 5.0, 97)
+    p0, f0 = cases.flat_sources(pos, flux)
+
+    def trace(R, n, aligned, pairs, **opts):
+        lib.source_data_to_device(p0[:3 * n], f0[:n], n)
+        lib.set_option(capi.OPT_ALIGNED_ROWS, aligned)
+        lib.set_option(capi.OPT_PAIR_SOURCES, pairs)
+        for k, v in opts.items():
+            lib.set_option(getattr(capi, k), v)
+        try:
+            lib.raytrace_device(R, cases.SIG, dr, 0, n, cases.MINLOGTAU, dlog, thin.shape[0])
+            phi = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+            counts = lib.last_raytrace_counts()
+        finally:
+            lib.set_option(capi.OPT_ALIGNED_ROWS, 0)
+            lib.set_option(capi.OPT_PAIR_SOURCES, 0)
+            for k in opts:
+                lib.set_option(getattr(capi, k), 0)
+        return phi, counts
+
+    for R in (4.0, 4.4):
+        inside = int(((np.add.outer(np.add.outer(np.arange(-6, 7) ** 2, np.arange(-6, 7) ** 2), np.arange(-6, 7) ** 2)) <= R * R).sum())
+        for n in (96, 97, 1, 2, 3):
+            for opts in ({"OPT_SECTORS": 9}, {"OPT_SECTORS": 3}, {"OPT_SECTORS": 9, "OPT_BLOCK_THREADS": 64},
+                         {"OPT_SECTORS": 9, "OPT_BLOCK_THREADS": 128}, {"OPT_SECTORS": 3, "OPT_BLOCK_THREADS": 256},
+                         {"OPT_SECTORS": 9, "OPT_BLOCK_THREADS": 512}, {"OPT_SECTORS": 9, "OPT_FORTRAN_CONSTANTS": 1}):
+                dense, c0 = trace(R, n, 1, 1, **opts)
+                for pairs in (1, 2):
+                    cut, c1 = trace(R, n, 2, pairs, **opts)
+                    assert np.array_equal(dense, cut), (R, n, pairs, opts)
+                    assert c0[0] == c1[0] == n * inside, (R, n, pairs, opts, c0, c1)
+                assert dense.max() > 0
+    # overlapping spheres against the oracle, odd count, both kinds of unit; and a kind of unit that has no aligned tables
+    ref = O.asora_do_all_sources(9.0, cases.SIG, dr, nd, xh, p0, f0, thin, thick, cases.MINLOGTAU, dlog,
+                                 NumTau=thin.shape[0], flags=O.ASORA_MODE)["phi_ion"]
+    w = ref != 0
+    for mode in (9, 3, 1):
+        for pairs in (1, 2):
+            phi, _ = trace(9.0, 97, 2, pairs, OPT_SECTORS=mode)
+            assert np.array_equal(phi != 0, w)
+            np.testing.assert_allclose(phi[w], ref[w], rtol=GAMMA_RTOL, atol=0)
+    p.device_close()
+
+
 def test_buffer_and_global_rate_atomics_give_the_same_rates(asora):
     """The rate atomics go through buffer descriptors by default (out-of-range offset = lane has nothing to add) and as
     global atomics under a branch with ASORA_OPT_GLOBAL_ATOMICS.  80 sources whose spheres do not overlap (no
