@@ -603,11 +603,12 @@ def main():
             "avg_launch_ms": rt_ms / max(rt_n, 1),
             "launches_timed": rt_n,
             "binding_resource": ("the memory-side rate atomics: every double added to the rate grid leaves the L2 in a 64-B atomic request "
-                                 "(TCC_EA0_ATOMIC %.3g per launch, %s: 5.9 doubles each, 6.4 is the bound of the sphere's row geometry), and "
+                                 "(TCC_EA0_ATOMIC %.3g per launch, %s: %.2f doubles each; 6.41 is what whole rows of the sphere give), and "
                                  "the memory side takes %.3g of them per second (%s); `atomic_requests.frac` in roofline_kernels is this "
                                  "launch against that ceiling.  Next the FP64/integer VALU stream (%.3g wave-instructions per launch, "
                                  "`valu_issue`); HBM bytes are not close (`traffic`).  DESIGN.md 8.0"
-                                 % (rt_counters.get("TCC_EA0_ATOMIC_sum", float("nan")), PMC_SUMMARY, ATOMIC_REQUEST_CEILING,
+                                 % (rt_counters.get("TCC_EA0_ATOMIC_sum", float("nan")), PMC_SUMMARY,
+                                    gamma_cells / rt_counters.get("TCC_EA0_ATOMIC_sum", float("nan")), ATOMIC_REQUEST_CEILING,
                                     ATOMIC_CEILING_SOURCE, rt_counters.get("SQ_INSTS_VALU", float("nan"))))
                                 if default_job else None,
         },

@@ -1791,8 +1791,9 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
         if (S_est + 1 > 256 && threads < 256) threads = 256;
     }
     // rows cut at 64-byte lines (ASORA_OPT_ALIGNED_ROWS): units of one face, a mesh whose rows start on lines, the [k][j][i]
-    // twin for the z-faces, a source list whose positions the host knows (pairing), and eight times the tables: up to
-    // r ~ 70 (0.5 GB) by default, ~110 on request
+    // twin for the z-faces, a source list whose positions the host knows (pairing), and eight times the tables.  By default
+    // where two sources share a workgroup (r < 52.5: -1.5 ... -4.7 %; beyond, with one source per workgroup and 0.2-0.35 GB of
+    // tables, nothing: profiles/r03_ab_aligned_rows.txt); on request up to r ~ 110
     const int32_t *host_pos = p.src_pos == st.src_pos_sorted ? st.src_pos_sorted_host.data()
                             : p.src_pos == st.src_pos ? st.src_pos_host.data() : nullptr;
     bool aligned = false;
@@ -1800,7 +1801,7 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
         const int want = st.opt[ASORA_OPT_ALIGNED_ROWS];
         const double r = std::min(p.R, 0.87 * p.N);
         const bool possible = (units == 6 || units == 12) && !dump && p.N % 8 == 0 && p.z_transposed && host_pos != nullptr && r <= 110.0;
-        aligned = possible && (want == 2 || (want == 0 && r <= 72.0));
+        aligned = possible && (want == 2 || (want == 0 && r < 52.5));
     }
     if (int rc = ensure_geometry(st, p, threads, units, nullptr, aligned)) return rc;
     p.lut_k1 = 0.30102999566398119521 / p.dlogtau;      // log10(2)/dlogtau

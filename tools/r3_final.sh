@@ -6,7 +6,7 @@ for RR in 16 64; do timeout -k 10 300 python bench.py --steps 10 --warmup 3 --R 
 timeout -k 10 400 python bench.py --steps 10 --warmup 3 --workload cosmo --cpu-sources 0 > $O/bench_cosmo_R32.json 2> $O/bench_cosmo_R32.err
 timeout -k 10 600 python bench.py --N 512 --nsrc 100000 --workload cosmo --steps 3 --warmup 1 --repeats 3 --cpu-sources 0 > $O/bench_cfg4_512_1e5.json 2> $O/cfg4.err; echo "cfg4 exit $?"
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 10 --warmup 3 --repeats 1 --cpu-sources 0 > $O/stats.log 2>&1; echo "stats exit $?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --repeats 2 --cpu-sources 0 > $O/stats.log 2>&1; echo "stats exit $?"
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv; rm -rf $O/stats
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats16 -- python3 $R/bench.py --steps 10 --warmup 3 --repeats 1 --cpu-sources 0 --R 16 > $O/stats16.log 2>&1
 cp $(find $O/stats16 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_R16.csv; rm -rf $O/stats16
