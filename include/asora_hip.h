@@ -301,7 +301,8 @@ enum {
      * exists (table rates, N <= 512).  The source whose column densities are returned always takes the on-the-fly kernel. */
     ASORA_OPT_SUBBOX_TABLES = 14,
     /* 15: rows of the rate grid cut at 64-byte lines: 0 = the library decides (units of one face, i.e. six sectors or twelve
-     * sector pairs per source, mesh a multiple of 8, r_RT < 52.5 cells), 1 = never, 2 = whenever possible (r_RT <= 110).  The geometry
+     * sector pairs per source, mesh a multiple of 8, r_RT < 52.5 cells, and a radius that does not change from call to call: after the first change only
+     * once a radius has served 32 launches in a row), 1 = never, 2 = whenever possible (r_RT <= 110).  The geometry
      * tables then exist in eight forms, by the source's position modulo 8 along the axis that is contiguous in memory for
      * the unit's face; in each, the cells of one row that fall into one 64-byte line of the rate grid never straddle two
      * waves, so every wave's rate atomics leave as whole-line requests (about 8 % fewer requests; the memory side's

@@ -157,6 +157,7 @@ static int release_all()
     drop(st.sb_active); drop(st.sb_nbox); drop(st.sb_loss); drop(st.sb_loss_final); st.subbox_cap = 0;
     release_geometry(st);
     st.init = false; st.N = 0; st.ncell = 0;
+    st.rt_last_R = -1.0; st.rt_same_R_launches = 0; st.rt_R_has_changed = false;
     st.rt_open = false;
     return 0;
 }

@@ -134,6 +134,10 @@ struct State {
     std::vector<void *> geom_owned;
     OctGeomDev geom_host[MAX_UNITS];        // device pointers of the unit tables ([class * units + unit] when geom_aligned)
     bool geom_aligned = false;
+    // how the radius has behaved across raytrace launches (launch_raytrace: the eight-fold tables only pay when they are reused)
+    double rt_last_R = -1.0;
+    long rt_same_R_launches = 0;
+    bool rt_R_has_changed = false;
     // host copies of the two source lists (as uploaded, and in lexicographic order of the position) and, for the paired-sources
     // variant on aligned tables, who shares a workgroup with whom: built once per (list, range), see source_pairs_by_class
     std::vector<int32_t> src_pos_host, src_pos_sorted_host;

@@ -1792,16 +1792,27 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
     }
     // rows cut at 64-byte lines (ASORA_OPT_ALIGNED_ROWS): units of one face, a mesh whose rows start on lines, the [k][j][i]
     // twin for the z-faces, a source list whose positions the host knows (pairing), and eight times the tables.  By default
-    // where two sources share a workgroup (r < 52.5: -1.5 ... -4.7 %; beyond, with one source per workgroup and 0.2-0.35 GB of
+    // where two sources share a workgroup (r < 52.5: -1.5 ... -4.7 %; beyond, with one source per workgroup and 0.13-0.2 GB of
     // tables, nothing: profiles/r03_ab_aligned_rows.txt); on request up to r ~ 110
     const int32_t *host_pos = p.src_pos == st.src_pos_sorted ? st.src_pos_sorted_host.data()
                             : p.src_pos == st.src_pos ? st.src_pos_host.data() : nullptr;
+    // ... and, left to the library, a radius that stays: building eight forms costs eight times as long (12 ms instead of
+    // 2.5 at r = 30), which a run whose r_RT changes with every time step (R_max_LLS in cells under cosmological expansion,
+    // ref: c2ray_base.py:460; a dozen launches per step) would pay every step for 0.3 ms saved.  So: aligned from the first
+    // launch on until the radius changes for the first time, afterwards only once a radius has served 32 launches in a row.
+    if (p.R != st.rt_last_R) {
+        if (st.rt_last_R >= 0.0) st.rt_R_has_changed = true;
+        st.rt_last_R = p.R;
+        st.rt_same_R_launches = 0;
+    }
+    st.rt_same_R_launches += 1;
     bool aligned = false;
     {
         const int want = st.opt[ASORA_OPT_ALIGNED_ROWS];
         const double r = std::min(p.R, 0.87 * p.N);
         const bool possible = (units == 6 || units == 12) && !dump && p.N % 8 == 0 && p.z_transposed && host_pos != nullptr && r <= 110.0;
-        aligned = possible && (want == 2 || (want == 0 && r < 52.5));
+        const bool radius_stays = !st.rt_R_has_changed || st.rt_same_R_launches > 32;
+        aligned = possible && (want == 2 || (want == 0 && r < 52.5 && radius_stays));
     }
     if (int rc = ensure_geometry(st, p, threads, units, nullptr, aligned)) return rc;
     p.lut_k1 = 0.30102999566398119521 / p.dlogtau;      // log10(2)/dlogtau
