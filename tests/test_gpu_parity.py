@@ -1359,6 +1359,26 @@ def test_rows_cut_at_64_byte_lines_give_the_same_rates(asora):
             np.testing.assert_allclose(phi[w], ref[w], rtol=GAMMA_RTOL, atol=0)
     p.device_close()
 
+    # spheres that reach the periodic window (the units of the + and - side then differ: no table is shared between them)
+    # and beyond it, on a small mesh: cut tables against dense ones, same support, rates to summation order
+    N = 40
+    nd, xh, dr = cases.grid(N, "lognormal", 16, 0.15, xlo=1e-4, xhi=1e-2)
+    p.device_init(N, 8)
+    p.photo_table_to_device(thin, thick)
+    lib.grid_to_device(capi.GRID_NDENS, nd)
+    lib.grid_to_device(capi.GRID_XH_AV, xh)
+    pos, flux = cases.sources(N, 37, 17, flux=2.0)
+    p0, f0 = cases.flat_sources(pos, flux)
+    for R in (12.5, 19.0, 20.0, 27.0, 40.0):
+        for mode in (9, 3):
+            dense, c0 = trace(R, 37, 1, 1, OPT_SECTORS=mode)
+            for pairs in (1, 2):
+                cut, c1 = trace(R, 37, 2, pairs, OPT_SECTORS=mode)
+                assert c0 == c1, (R, mode, pairs, c0, c1)
+                assert np.array_equal(dense != 0, cut != 0), (R, mode, pairs)
+                np.testing.assert_allclose(cut, dense, rtol=1e-11, atol=0, err_msg=str((R, mode, pairs)))
+    p.device_close()
+
 
 def test_buffer_and_global_rate_atomics_give_the_same_rates(asora):
     """The rate atomics go through buffer descriptors by default (out-of-range offset = lane has nothing to add) and as
