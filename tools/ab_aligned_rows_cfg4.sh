@@ -1,4 +1,5 @@
-cd "$GRAFT_REPO_ROOT" || exit 1
+# A/B of ASORA_OPT_ALIGNED_ROWS on BASELINE configs[4] on one GPU (512^3, 1e5 sources): bash tools/ab_aligned_rows_cfg4.sh
+cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun exports it) to the repository root}" || exit 1
 mkdir -p gpurun_out/r3z
 for round in 1 2; do
   for mode in off auto; do

@@ -1,5 +1,9 @@
-import os, sys
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+"""When does the library build the eight-fold (line-aligned) geometry tables?  Run with ASORA_GEOM_TIMING=1: every build prints its
+size to stderr.  Expected: aligned for the first radius, dense right after a change of radius, aligned again once a radius has
+served 32 launches (launch_raytrace, ASORA_OPT_ALIGNED_ROWS = 0).  usage (GPU box): ASORA_GEOM_TIMING=1 python tools/check_aligned_heuristic.py"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bench
 import pyc2ray_amd as p
