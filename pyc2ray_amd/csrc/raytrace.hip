@@ -1842,12 +1842,15 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
         const int want = st.opt[ASORA_OPT_PAIR_SOURCES];
         const bool possible = use_lds && !dump && !heat && !p.grey && !std::isfinite(p.tau_zero) && !big_tables && threads <= 512 &&
                               16ull * p.ncell <= 0x80000000ull && !st.opt[ASORA_OPT_GLOBAL_ATOMICS] && p.src_count >= 2 &&
-                              2 * shell_bytes + lds_table_bytes((p.S + 1 <= 64 && threads <= 256) ? 64 : 256, 2) <= LDS_LIMIT_BYTES;
+                              2 * shell_bytes + lds_table_bytes((p.S + 1 <= 32 && threads == 256) ? 32 : (p.S + 1 <= 64 && threads <= 256) ? 64 : 256, 2) <= LDS_LIMIT_BYTES;
         pairs = possible && (want == 2 || (want == 0 && pair_sources_pays(st, p.R, p.N, p.shape_src_count > 0 ? p.shape_src_count : p.src_count, units, threads)));
     }
     const bool pairs_small = p.S + 1 <= 64 && threads <= 256;      // the paired variant has the 64-entry tables for 256 threads too
+    // ... and 32-entry ones for 256 threads: at r_RT = 30 the 1.75 KB they save are what separates two workgroups per CU from
+    // three (four shell buffers of 11.6 KB + tables: 53.9 KB against 52.2 KB; three per CU fit up to 53.3 KB; worth ~4 %)
+    const bool pairs_tiny = p.S + 1 <= 32 && threads == 256;
     if (pairs) {
-        fixed_bytes = lds_table_bytes(pairs_small ? 64 : 256, 2);
+        fixed_bytes = lds_table_bytes(pairs_tiny ? 32 : pairs_small ? 64 : 256, 2);
         shell_bytes *= 2;
     }
     size_t lds_bytes = (use_lds ? shell_bytes : 0) + fixed_bytes;
@@ -1897,7 +1900,8 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
             KernelTimer kt(ASORA_KERNEL_RAYTRACE, stream);
             int rc = 0;
             if (pairs) {
-                if (pairs_small) {
+                if (pairs_tiny) rc = launch_variant_pairs<256, 32>(st, q, grid, lds_bytes, stream);
+                else if (pairs_small) {
                     if (threads == 64)       rc = launch_variant_pairs<64, 64>(st, q, grid, lds_bytes, stream);
                     else if (threads == 128) rc = launch_variant_pairs<128, 64>(st, q, grid, lds_bytes, stream);
                     else                     rc = launch_variant_pairs<256, 64>(st, q, grid, lds_bytes, stream);
