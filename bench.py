@@ -481,13 +481,14 @@ def main():
     lib.set_option(_capi.OPT_TIMING, 0)
 
     gamma_cells, eval_cells = lib.last_raytrace_counts()
+    zero_cells = lib.last_raytrace_zero_rates()
     if slab:
         comm.slab_gather(lib, plan, _capi.GRID_XH_INTERMED, N)
         comm.slab_gather(lib, plan, _capi.GRID_PHI_ION, N)
     if comm is None:
         # the counters of the device-resident loop run on from evolve_begin: per iteration = total / iterations
         n_done, _, rows = lib.evolve_poll(min(K, 32))
-        gamma_cells, eval_cells = gamma_cells // n_done, eval_cells // n_done
+        gamma_cells, eval_cells, zero_cells = gamma_cells // n_done, eval_cells // n_done, zero_cells // n_done
         conv = (rows[-1][0],) if len(rows) else (0,)
     rt_ms, rt_n = lib.kernel_time_ms(_capi.KERNEL_RAYTRACE)
     ch_ms, ch_n = lib.kernel_time_ms(_capi.KERNEL_CHEMISTRY)
@@ -583,6 +584,10 @@ def main():
             "raytrace_updates_per_step": tot_gamma,
             "chemistry_updates_per_step": N ** 3,
             "column_density_evaluations_per_step_rank0": eval_cells,
+            # of raytrace_updates_per_step (rank 0): pairs whose rate is exactly +0 -- a thick cell beyond the last table
+            # entry -- and is therefore not added to the grid (bit-identical result; 0 for the headline workload, whose
+            # largest optical depth, 32 cells x 227, stays inside the table)
+            "exact_zero_rates_not_added_per_step_rank0": zero_cells,
             "nonconverged_cells_last_step": int(conv[0]) if conv is not None else None,
             "first_iteration_of_a_time_step_ms": first_iteration_ms,
             "step_definition": "steady-state outer iteration of evolve3D: raytrace + one fused pass (rates folded, chemistry, "

@@ -280,11 +280,16 @@ enum {
     /* 1 (default): asora_do_all_sources overlaps the upload of xh_av, the trace and the download of phi_ion slab by slab
      *    (when all uploaded sources are traced and R is small against the mesh); 0: upload, trace, download in turn. */
     ASORA_OPT_PIPELINED_COPIES = 10,
-    /* 1: a rate that is exactly +0 -- a thick cell whose optical depth lies beyond the last table entry, where both
-     *    lookups return the same value -- is not added (bit-identical result, no atomic; waves with nothing to add skip
-     *    the division, logarithms and lookups too).  Pays where r_RT x (optical depth of a cell) exceeds the table's
-     *    last entry (the benchmark medium at r_RT = 64: -25 %); costs 4.5 % where nothing can be left out, hence
-     *    0 (default): every rated cell is looked up and added, as the reference does (rates.cu:16-41, raytracing.cu:328). */
+    /* A rate that is exactly +0 -- a thick cell whose optical depth lies beyond the last table entry, where both lookups
+     * return the same value (finite flux / volume) -- need not be added: the grid is bit-identical without it.
+     * 0 (default): the kernels whose rate atomics go through buffer descriptors (table rates, shells in LDS, N <= 512: the
+     *    production path) give such a lane the out-of-range offset of a lane without a rate, so its atomic never leaves the
+     *    wave, and a wave none of whose lanes has anything to add leaves out the division, logarithms and index arithmetic
+     *    too (it issues as many wave-uniform table loads as the other path, so the two paths meet with the same operations
+     *    in flight).  Costs nothing where no such cell exists (r_RT = 32 in the benchmark medium: +-0.1 %); the benchmark
+     *    medium at r_RT = 64, where two thirds of the pairs lie beyond the table: -23 %; every other kernel adds everything.
+     * 1: as 0, and the kernels without buffer atomics take a variant that tests and branches (4.5 % where nothing is left out).
+     * 2: every rated cell is looked up and added, as the reference does (rates.cu:16-41, raytracing.cu:328). */
     ASORA_OPT_SKIP_ZERO_RATES = 11,
     /* 1: the rate atomics are global_atomic_add_f64 under `if (lane has a rate)` even where the grids are small enough for
      *    the default, buffer_atomic_add_f64 through a descriptor over [phi | phi_t] with out-of-range offsets for lanes
@@ -328,6 +333,9 @@ int asora_synchronize(void);
  * (|d|<=R inside the periodic window: the Gamma-contributing set of raytracing.cu:315), and
  * (source,cell) column-density evaluations actually performed (incl. octant-boundary planes). */
 int asora_last_raytrace_counts(long long *gamma_cells, long long *evaluated_cells);
+/* The same, and how many of the rate-receiving pairs got a rate of exactly +0 that was therefore not added to the grid
+ * (ASORA_OPT_SKIP_ZERO_RATES; they are part of gamma_cells). */
+int asora_last_raytrace_counts_ex(long long *gamma_cells, long long *evaluated_cells, long long *zero_rates_left_out);
 
 /* Outgoing column density of ONE source over the cells its trace covers, written into a host
  * N^3 grid (zero elsewhere), C-order.  For parity tests of the column density

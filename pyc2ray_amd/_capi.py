@@ -71,6 +71,7 @@ SIGNATURES = {
     "asora_kernel_time_reset": (C.c_int, []),
     "asora_synchronize": (C.c_int, []),
     "asora_last_raytrace_counts": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "asora_last_raytrace_counts_ex": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "asora_debug_coldens": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int, _dp, C.c_int]),
 }
 

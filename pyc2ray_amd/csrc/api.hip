@@ -85,8 +85,8 @@ static int ensure_runtime()
     ASORA_HIP_TRY(hipMalloc(&st.red_partial, sizeof(double) * st.red_cap));
     ASORA_HIP_TRY(hipMalloc(&st.red_final, sizeof(double) * 3));
     ASORA_HIP_TRY(hipHostMalloc(&st.red_host, sizeof(double) * 3, hipHostMallocDefault));
-    ASORA_HIP_TRY(hipMalloc(&st.counters, sizeof(unsigned long long) * 2 * COUNTER_SLOTS));
-    ASORA_HIP_TRY(hipMemset(st.counters, 0, sizeof(unsigned long long) * 2 * COUNTER_SLOTS));
+    ASORA_HIP_TRY(hipMalloc(&st.counters, sizeof(unsigned long long) * COUNTER_FIELDS * COUNTER_SLOTS));
+    ASORA_HIP_TRY(hipMemset(st.counters, 0, sizeof(unsigned long long) * COUNTER_FIELDS * COUNTER_SLOTS));
     return 0;
 }
 
@@ -229,7 +229,7 @@ static int rt_begin(double R, double sig, double dr, double minlogtau, double dl
         ASORA_HIP_TRY(hipMemsetAsync(st.grid[ASORA_GRID_PHI_HEAT], 0, bytes, st.stream));
         if (zt) ASORA_HIP_TRY(hipMemsetAsync(st.heat_t, 0, bytes, st.stream));
     }
-    ASORA_HIP_TRY(hipMemsetAsync(st.counters, 0, sizeof(unsigned long long) * 2 * COUNTER_SLOTS, st.stream));
+    ASORA_HIP_TRY(hipMemsetAsync(st.counters, 0, sizeof(unsigned long long) * COUNTER_FIELDS * COUNTER_SLOTS, st.stream));
     if (int rc = launch_prepare_nhi(st, zt)) return rc;
 
     RtParams &p = st.rt_params;
@@ -559,7 +559,7 @@ static int do_all_sources_pipelined(double R, double sig, double dr, const doubl
         }
 
     ASORA_HIP_TRY(hipMemsetAsync(st.grid[ASORA_GRID_PHI_ION], 0, 2 * bytes, st.stream));      // raytracing.cu:113 (+ twin)
-    ASORA_HIP_TRY(hipMemsetAsync(st.counters, 0, sizeof(unsigned long long) * 2 * COUNTER_SLOTS, st.stream));
+    ASORA_HIP_TRY(hipMemsetAsync(st.counters, 0, sizeof(unsigned long long) * COUNTER_FIELDS * COUNTER_SLOTS, st.stream));
     RtParams base;
     fill_rt_params(base, R, sig, dr, minlogtau, dlogtau, NumTau);
     base.src_pos = st.src_pos_sorted; base.src_flux = st.src_flux_sorted;
@@ -964,7 +964,7 @@ int asora_raytrace_begin_planes(double R, double sig, double dr, double minlogta
     for (int q = 0; q < nruns; ++q)
         if (runs[2 * q] < 0 || runs[2 * q + 1] < 0 || runs[2 * q] + runs[2 * q + 1] > st.N)
             return fail(3, "raytrace_begin_planes: plane run outside the mesh");
-    ASORA_HIP_TRY(hipMemsetAsync(st.counters, 0, sizeof(unsigned long long) * 2 * COUNTER_SLOTS, st.stream));
+    ASORA_HIP_TRY(hipMemsetAsync(st.counters, 0, sizeof(unsigned long long) * COUNTER_FIELDS * COUNTER_SLOTS, st.stream));
     for (int q = 0; q < nruns; ++q)
         if (int rc = launch_prepare_range(st, runs[2 * q], runs[2 * q + 1], true, st.grid[ASORA_GRID_PHI_ION])) return rc;
     fill_rt_params(st.rt_params, R, sig, dr, minlogtau, dlogtau, NumTau);
@@ -1315,7 +1315,7 @@ int asora_evolve_begin(double dt, double bh00, double albpow, double colh0, doub
     st.ev_host->conv_criterion = conv_criterion;
     st.ev_host->conv_fraction = convergence_fraction;
     ASORA_HIP_TRY(hipMemcpyAsync(st.ev_status, st.ev_host, sizeof(EvolveStatus), hipMemcpyHostToDevice, st.stream));
-    ASORA_HIP_TRY(hipMemsetAsync(st.counters, 0, sizeof(unsigned long long) * 2 * COUNTER_SLOTS, st.stream));
+    ASORA_HIP_TRY(hipMemsetAsync(st.counters, 0, sizeof(unsigned long long) * COUNTER_FIELDS * COUNTER_SLOTS, st.stream));
     // xh_av = copy(xh) (evolve.py:136) is not materialised: nHI of the first trace is formed from xh and the first
     // chemistry pass takes xh as its starting xh_av; xh_intermed (evolve.py:137) is only ever written
     if (int rc = launch_prepare_nhi_from(st, st.grid[ASORA_GRID_XH], st.opt[ASORA_OPT_Z_TRANSPOSED] != 0)) return rc;
@@ -1501,13 +1501,22 @@ int asora_last_raytrace_counts(long long *gamma_cells, long long *evaluated_cell
 {
     clear_error();
     if (int rc = require_init("last_raytrace_counts")) return rc;
-    std::vector<unsigned long long> h(2 * (size_t)COUNTER_SLOTS, 0ULL);
+    long long zero = 0;
+    return asora_last_raytrace_counts_ex(gamma_cells, evaluated_cells, &zero);
+}
+
+int asora_last_raytrace_counts_ex(long long *gamma_cells, long long *evaluated_cells, long long *zero_rates_left_out)
+{
+    clear_error();
+    if (int rc = require_init("last_raytrace_counts")) return rc;
+    std::vector<unsigned long long> h((size_t)COUNTER_FIELDS * COUNTER_SLOTS, 0ULL);
     ASORA_HIP_TRY(hipStreamSynchronize(g_state.stream));
     ASORA_HIP_TRY(hipMemcpy(h.data(), g_state.counters, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    unsigned long long tot[2] = {0ULL, 0ULL};
-    for (int q = 0; q < COUNTER_SLOTS; ++q) { tot[0] += h[2 * q]; tot[1] += h[2 * q + 1]; }
+    unsigned long long tot[COUNTER_FIELDS] = {0ULL, 0ULL, 0ULL};
+    for (int q = 0; q < COUNTER_SLOTS; ++q) for (int f = 0; f < COUNTER_FIELDS; ++f) tot[f] += h[(size_t)COUNTER_FIELDS * q + f];
     if (gamma_cells) *gamma_cells = (long long)tot[0];
     if (evaluated_cells) *evaluated_cells = (long long)tot[1];
+    if (zero_rates_left_out) *zero_rates_left_out = (long long)tot[2];
     return 0;
 }
 

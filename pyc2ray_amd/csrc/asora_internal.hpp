@@ -27,6 +27,7 @@ constexpr int MAX_UNITS = 96;   // workgroups per source: 8 octants, 12 mirrored
 // launch (0.2 ms for 8000 workgroups, whatever the radius); spread over COUNTER_SLOTS addresses by workgroup index they cost
 // nothing, and asora_last_raytrace_counts sums the slots.
 constexpr int COUNTER_SLOTS = 4096;
+constexpr int COUNTER_FIELDS = 3;   // per slot: rated pairs, evaluated cells, rated pairs whose rate was exactly +0 and was not added
 
 // Upper limit of the real table index in photo_lookuptable: min(float(NumTau), ...) of rates.cu:79 / real(NumTau) of
 // photorates.f90:141, and never beyond the last element the device table holds (the reference reads one past the end when the
@@ -191,7 +192,7 @@ struct State {
     double *red_host = nullptr;    // pinned [3]
     int red_blocks = 0;
 
-    unsigned long long *counters = nullptr; // [2 * COUNTER_SLOTS] device: gamma cells, evaluated cells, spread over the slots
+    unsigned long long *counters = nullptr; // [COUNTER_FIELDS * COUNTER_SLOTS] device: gamma cells, evaluated cells, exact zeros left out, spread over the slots
     long long last_gamma_cells = 0, last_eval_cells = 0;
 
     // fused evolve loop (asora_evolve_*): raytrace accumulators of their own ([i][j][k] then [k][j][i]; the chemistry

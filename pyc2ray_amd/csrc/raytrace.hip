@@ -170,6 +170,12 @@ extern "C" __device__ double asora_buffer_atomic_fadd_f64(double, __amdgpu_buffe
 // 1: within a group of 8 sources the units are dispatched largest first (the z-sector units hold the most cells), so
 // that the workgroups still running when the grid drains are the short ones.  Measured (tools/ab_macro.sh, 1000 sources,
 // 256^3): R = 24 -2.6 %, 32 -1.8 %, 48 -1.7 %, 64 -0.5 %.
+// 1: in the buffer-atomic kernels a rate that is exactly +0 (a thick cell beyond the last table entry) is not added: see the
+// kernel's SKIP_ZERO.  2: and a wave without anything to add skips the rate arithmetic.  0: every rated cell is added (A/B).
+#ifndef ASORA_SUPPRESS_ZERO_ADDS
+#define ASORA_SUPPRESS_ZERO_ADDS 2
+#endif
+
 #ifndef ASORA_UNITS_LARGEST_FIRST
 #define ASORA_UNITS_LARGEST_FIRST 1
 #endif
@@ -351,7 +357,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     constexpr bool grey = GREY;
 
     // work accounting, per wave (scalar registers: population counts of the lane masks, no per-lane adds)
-    unsigned int n_gamma = 0, n_eval = 0;
+    unsigned int n_gamma = 0, n_eval = 0, n_zero = 0;      // n_zero: rated cells whose rate was exactly +0 and was not added
     unsigned int src_cell_gamma = 0, src_cell_eval = 0;      // the source cell (thread 0 only)
 
     // rate accumulation: `idx` indexes [phi | phi_t] (and [heat | heat_t])
@@ -601,11 +607,12 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
             const double limit = p.fortran_consts ? (double)1.0e-7f : 1.0e-7;
             const double2 *tab = p.tables;
             bool thick[NSRC];
-            double dtau[NSRC], arg_A[NSRC], arg_B[NSRC];
+            double dtau[NSRC], arg_A[NSRC], arg_B[NSRC], tau_at_entry[NSRC];
             int toff[NSRC];
 #pragma unroll
             for (int q = 0; q < NSRC; ++q) {
                 const double tau_in = mul_unfused(cd_in[q], sig), tau_out = mul_unfused(cd_out[q], sig);   // un-fused, see rate_issue
+                tau_at_entry[q] = tau_in;
                 dtau[q] = tau_out - tau_in;
                 thick[q] = fabs(dtau[q]) > limit;
                 // one code path for both kinds of cell: per-lane table offset and arguments.  A thin cell looks its tau_thin up
@@ -626,11 +633,29 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
             bool wave_adds = true;
 #pragma unroll
             for (int q = 0; q < NSRC; ++q) add[q] = rated[q];
-            if (SKIP_ZERO) {
-                const double tau_in0 = mul_unfused(cd_in[0], sig);
-                const bool zero_rate = thick[0] && tau_in0 >= p.tau_zero && fabs(vol_nhi[0]) > 1e-250 && (vol_nhi[0] - vol_nhi[0] == 0.0);
-                add[0] = rated[0] && !zero_rate;
-                wave_adds = __builtin_amdgcn_readfirstlane((int)__any(add[0])) != 0;
+            // BUFATOM kernels (round 3): the same test per lane, without the branch -- a lane whose rate is exactly +0 carries the
+            // out-of-range offset like a lane without a rate, so its atomic never leaves the wave; the lookups are issued
+            // regardless.  p.tau_zero = +inf switches it off (ASORA_OPT_SKIP_ZERO_RATES = 2, grey opacity).
+            if (SKIP_ZERO || (BUFATOM && !GREY && ASORA_SUPPRESS_ZERO_ADDS)) {
+#pragma unroll
+                for (int q = 0; q < NSRC; ++q) {
+                    const bool zero_rate = thick[q] && tau_at_entry[q] >= p.tau_zero && fabs(vol_nhi[q]) > 1e-250 &&
+                                           (vol_nhi[q] - vol_nhi[q] == 0.0);
+                    add[q] = rated[q] && !zero_rate;
+                    n_zero += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(rated[q] && zero_rate));
+                }
+                if (SKIP_ZERO && !BUFATOM) wave_adds = __builtin_amdgcn_readfirstlane((int)__any(add[0])) != 0;
+#if ASORA_SUPPRESS_ZERO_ADDS >= 2
+                // ... and a wave none of whose lanes has anything to add leaves out the division, the logarithms and the index
+                // arithmetic as well -- but issues as many (wave-uniform, cheap) table loads as the other path, so that the
+                // number of operations in flight is the same wherever the two paths meet
+                if (BUFATOM && !SKIP_ZERO) {
+                    bool any_add = add[0];
+#pragma unroll
+                    for (int q = 1; q < NSRC; ++q) any_add = any_add || add[q];
+                    wave_adds = __builtin_amdgcn_ballot_w64(any_add) != 0ull;
+                }
+#endif
             }
             {   // the previous step's lookups have had a whole step to arrive: form its rates now, issue this step's
                 // lookups, then add the rates behind them
@@ -661,6 +686,18 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
                         B2[q] = lookup_issue<HEAT>(tab, arg_B[q], p, logtab, SUBBOX ? 0 : toff[q]);
                     }
                 }
+#if ASORA_SUPPRESS_ZERO_ADDS >= 2
+                else if (BUFATOM && !SKIP_ZERO) {
+#pragma unroll
+                    for (int q = 0; q < NSRC; ++q) {     // (distinct addresses, or the loads would be merged)
+                        const double2 *__restrict__ dummy = tab + (threadIdx.x & 1) + 4 * q;
+                        A2[q].t = dummy[0]; A2[q].residual = 0.0;
+                        B2[q].t = dummy[2]; B2[q].residual = 0.0;
+                        if (HEAT) { A2[q].h = dummy[2 * p.table_len]; B2[q].h = dummy[2 * p.table_len + 2]; }
+                        else { A2[q].h = A2[q].t; B2[q].h = B2[q].t; }
+                    }
+                }
+#endif
                 if (SUBBOX) {
                     // what leaves the PREVIOUS step's cell through the far side, if that cell lies on a face of the box
                     const bool lost = (BUFATOM ? late_off[0] != ASORA_OOB_OFFSET : late_ok[0]) && pend_edge;
@@ -821,9 +858,10 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
 
     // work accounting: one atomic per wave and counter
     if ((threadIdx.x & 63) == 0) {
-        unsigned long long *slot = p.counters + 2 * (blockIdx.x & (COUNTER_SLOTS - 1));     // (see COUNTER_SLOTS)
+        unsigned long long *slot = p.counters + COUNTER_FIELDS * (blockIdx.x & (COUNTER_SLOTS - 1));     // (see COUNTER_SLOTS)
         atomicAdd(slot, (unsigned long long)(n_gamma + src_cell_gamma));
         atomicAdd(slot + 1, (unsigned long long)(n_eval + src_cell_eval));
+        if (n_zero) atomicAdd(slot + 2, (unsigned long long)n_zero);
     }
 }
 
@@ -1736,8 +1774,9 @@ static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t ld
     }
     else if (grey)        { if (ba) ASORA_LAUNCH(false, false, false, false, true, true); else if (use_lds) ASORA_LAUNCH(false, false, false, false, true, false); else ASORA_LAUNCH(true, false, false, false, true, false); }
     else if (heat)        { if (ba) ASORA_LAUNCH(false, false, true, false, false, true); else if (use_lds) ASORA_LAUNCH(false, false, true, false, false, false); else ASORA_LAUNCH(true, false, true, false, false, false); }
-    // ASORA_OPT_SKIP_ZERO_RATES: the variant that leaves exact zeros out
-    else if (use_lds && std::isfinite(q.tau_zero)) ASORA_LAUNCH(false, false, false, true, false, false);
+    // ASORA_OPT_SKIP_ZERO_RATES = 1 where the buffer-atomic kernel (which drops exact zeros by itself) is not available: the
+    // branching variant that leaves them out
+    else if (use_lds && !ba && std::isfinite(q.tau_zero) && st.opt[ASORA_OPT_SKIP_ZERO_RATES] == 1) ASORA_LAUNCH(false, false, false, true, false, false);
     else                  { if (ba) ASORA_LAUNCH(false, false, false, false, false, true); else if (use_lds) ASORA_LAUNCH(false, false, false, false, false, false); else ASORA_LAUNCH(true, false, false, false, false, false); }
 #undef ASORA_LAUNCH
     ASORA_HIP_TRY(hipGetLastError());
@@ -1820,8 +1859,11 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
     // optical depth from which BOTH lookups of a thick cell return the same table value (index clamped to NumTau, or on
     // the last pair of the device table, whose slope is 0): 0.01 index units beyond the exact point, far more than the
     // 1e-12 the device's log2 can be off by
+    // ASORA_OPT_SKIP_ZERO_RATES: 0 = where it costs nothing (the buffer-atomic kernels drop such lanes' atomics), 1 = everywhere
+    // (kernels without buffer atomics take the branching SKIP_ZERO variant), 2 = nowhere
     p.tau_zero = INFINITY;
-    if (st.opt[ASORA_OPT_SKIP_ZERO_RATES] && !p.grey && p.lut_k1 > 0.0) {
+    const int skip_zero_opt = st.opt[ASORA_OPT_SKIP_ZERO_RATES];
+    if (skip_zero_opt != 2 && !p.grey && p.lut_k1 > 0.0) {
         const double last = std::min(p.numtau_f, (double)(p.table_len - 1));
         p.tau_zero = std::exp2((last + 0.01 - p.lut_k0) / p.lut_k1);
     }
@@ -1840,7 +1882,7 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
     bool pairs = false;
     {
         const int want = st.opt[ASORA_OPT_PAIR_SOURCES];
-        const bool possible = use_lds && !dump && !heat && !p.grey && !std::isfinite(p.tau_zero) && !big_tables && threads <= 512 &&
+        const bool possible = use_lds && !dump && !heat && !p.grey && !big_tables && threads <= 512 &&
                               16ull * p.ncell <= 0x80000000ull && !st.opt[ASORA_OPT_GLOBAL_ATOMICS] && p.src_count >= 2 &&
                               2 * shell_bytes + lds_table_bytes((p.S + 1 <= 32 && threads == 256) ? 32 : (p.S + 1 <= 64 && threads <= 256) ? 64 : 256, 2) <= LDS_LIMIT_BYTES;
         pairs = possible && (want == 2 || (want == 0 && pair_sources_pays(st, p.R, p.N, p.shape_src_count > 0 ? p.shape_src_count : p.src_count, units, threads)));

@@ -266,6 +266,12 @@ class _LibAsora:
         _capi.check(self._lib.asora_last_raytrace_counts(C.byref(g), C.byref(e)), "last_raytrace_counts")
         return g.value, e.value
 
+    def last_raytrace_zero_rates(self):
+        """Of the rate-receiving pairs of the last raytrace: how many got exactly +0 and were not added (ASORA_OPT_SKIP_ZERO_RATES)."""
+        g, e, z = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+        _capi.check(self._lib.asora_last_raytrace_counts_ex(C.byref(g), C.byref(e), C.byref(z)), "last_raytrace_counts_ex")
+        return z.value
+
     def debug_coldens(self, R, sig, dr, source_index, N):
         out = np.zeros((N, N, N))
         _capi.check(self._lib.asora_debug_coldens(float(R), float(sig), float(dr), int(source_index),

@@ -1131,11 +1131,12 @@ def test_pipelined_copies_of_the_drop_in_call_change_nothing(asora, N, R, ns):
 
 
 def test_leaving_out_exactly_zero_rates_changes_nothing(asora):
-    """With ASORA_OPT_SKIP_ZERO_RATES a thick cell whose optical depth lies beyond the last table entry, which gets
-    pref * (T_last - T_last) = +0, is not added (no atomic; waves with nothing to add skip the lookups); by default every
-    rated cell is looked up and added.  One source (no summation-order freedom): the two grids must be IDENTICAL, zeros included,
-    in an optically thick medium where most cells are beyond the table, in a thin one where none is, and with NumTau
-    given as the table length and as length - 1."""
+    """A thick cell whose optical depth lies beyond the last table entry gets pref * (T_last - T_last) = +0.  With
+    ASORA_OPT_SKIP_ZERO_RATES = 0 (default) the buffer-atomic kernels do not add it (no atomic; waves with nothing to add skip
+    the rate arithmetic), with 1 every kernel leaves it out, with 2 every rated cell is looked up and added, as the reference
+    does.  One source (no summation-order freedom): the three grids must be IDENTICAL, zeros included, in an optically thick
+    medium where most cells are beyond the table, in a thin one where none is, and with NumTau given as the table length and
+    as length - 1; the library's count of cells left out is what the grid says."""
     p, lib, capi = asora
     N = 48
     thin, thick, dlog = cases.soft_tables(400)
@@ -1152,15 +1153,24 @@ def test_leaving_out_exactly_zero_rates_changes_nothing(asora):
         lib.grid_to_device(capi.GRID_NDENS, nd)
         lib.grid_to_device(capi.GRID_XH_AV, xh)
         for numtau in (thin.shape[0], thin.shape[0] - 1):
-            out = []
-            for skip in (1, 0):
+            out, left_out = [], []
+            for skip, atomics in ((1, 0), (0, 0), (2, 0), (1, 1), (0, 1)):
                 lib.set_option(capi.OPT_SKIP_ZERO_RATES, skip)
+                lib.set_option(capi.OPT_GLOBAL_ATOMICS, atomics)      # 1: the kernels without buffer atomics
                 try:
                     lib.raytrace_device(1000.0, cases.SIG, dr, 0, 1, cases.MINLOGTAU, dlog, numtau)
+                    left_out.append(lib.last_raytrace_zero_rates())
                 finally:
                     lib.set_option(capi.OPT_SKIP_ZERO_RATES, 0)
+                    lib.set_option(capi.OPT_GLOBAL_ATOMICS, 0)
                 out.append(lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N))))
-            assert np.array_equal(out[0], out[1])
+            for o in out[1:]:
+                assert np.array_equal(out[0], o)
+            # whole box traced, every cell rated once: what was left out is zero in the grid
+            assert left_out[2] == 0 and left_out[4] == 0
+            assert left_out[0] == left_out[1] == left_out[3]
+            assert left_out[0] <= int((out[0] == 0).sum())
+            assert (left_out[0] > 0.3 * N ** 3) if tau_cell == 3000.0 else (left_out[0] == 0)
             ref = O.asora_do_all_sources(1000.0, cases.SIG, dr, nd, xh, p0, f0, thin, thick, cases.MINLOGTAU, dlog,
                                          NumTau=numtau, flags=O.ASORA_MODE)["phi_ion"]
             assert np.array_equal(out[0] == 0, ref == 0)
@@ -1289,6 +1299,21 @@ def test_two_sources_per_workgroup_give_the_same_rates(asora):
         phi, _ = trace(9.0, 81, 2, OPT_SECTORS=mode)
         assert np.array_equal(phi != 0, w)
         np.testing.assert_allclose(phi[w], ref[w], rtol=GAMMA_RTOL, atol=0)
+    # a medium so thick that most cells lie beyond the last table entry: their rates are exactly +0 and are not added
+    # (ASORA_OPT_SKIP_ZERO_RATES = 0), whole waves of them skip the rate arithmetic -- grids IDENTICAL to adding everything (2),
+    # with one and with two sources per workgroup, on dense and on line-aligned tables
+    nd_thick = nd * 3.0e4
+    lib.grid_to_device(capi.GRID_NDENS, nd_thick)
+    for R in (4.0, 5.5):
+        for n in (80, 81):
+            for opts in ({}, {"OPT_SECTORS": 9}, {"OPT_SECTORS": 9, "OPT_ALIGNED_ROWS": 2}, {"OPT_SECTORS": 3, "OPT_BLOCK_THREADS": 256},
+                         {"OPT_SECTORS": 6}):
+                everything, _ = trace(R, n, 1, OPT_SKIP_ZERO_RATES=2, **opts)
+                assert (everything == 0).sum() > (everything != 0).sum() > 0
+                for pairs in (1, 2):
+                    phi, _ = trace(R, n, pairs, **opts)
+                    assert np.array_equal(phi, everything), (R, n, pairs, opts)
+                    assert lib.last_raytrace_zero_rates() > 0
     p.device_close()
 
 
