@@ -358,7 +358,7 @@ static int subbox_core(const SubboxCall &c, long long &total_nbox, double &total
     p.lut_k1 = 0.30102999566398119521 / c.dlogtau;
     p.lut_k0 = 1.0 - c.minlogtau / c.dlogtau;
     p.table_len = c.table_len;
-    p.grey = grey ? 1 : 0; p.heat = c.heat ? 1 : 0; p.add_zero = st.opt[ASORA_OPT_SKIP_ZERO_RATES] ? 0 : 1;
+    p.grey = grey ? 1 : 0; p.heat = c.heat ? 1 : 0; p.add_zero = st.opt[ASORA_OPT_SKIP_ZERO_RATES] == 1 ? 0 : 1;
     const int last = c.src_begin + c.src_count - 1;
     p.flux_src = st.opt[ASORA_OPT_C2RAY_OWN_FLUX] ? -1 : last;            // f90:500,503
     p.dump_src = last;
