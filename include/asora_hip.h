@@ -281,15 +281,15 @@ enum {
      *    (when all uploaded sources are traced and R is small against the mesh); 0: upload, trace, download in turn. */
     ASORA_OPT_PIPELINED_COPIES = 10,
     /* A rate that is exactly +0 -- a thick cell whose optical depth lies beyond the last table entry, where both lookups
-     * return the same value (finite flux / volume) -- need not be added: the grid is bit-identical without it.
-     * 0 (default): the kernels whose rate atomics go through buffer descriptors (table rates, shells in LDS, N <= 512: the
-     *    production path) give such a lane the out-of-range offset of a lane without a rate, so its atomic never leaves the
-     *    wave, and a wave none of whose lanes has anything to add leaves out the division, logarithms and index arithmetic
-     *    too (it issues as many wave-uniform table loads as the other path, so the two paths meet with the same operations
-     *    in flight).  Costs nothing where no such cell exists (r_RT = 32 in the benchmark medium: +-0.1 %); the benchmark
-     *    medium at r_RT = 64, where two thirds of the pairs lie beyond the table: -23 %; every other kernel adds everything.
-     * 1: as 0, and the kernels without buffer atomics take a variant that tests and branches (4.5 % where nothing is left out).
-     * 2: every rated cell is looked up and added, as the reference does (rates.cu:16-41, raytracing.cu:328). */
+     * return the same value -- need not be added: the grid is bit-identical without it.  The kernels whose rate atomics go
+     * through buffer descriptors (table rates, shells in LDS, N <= 512: the production path) exist in a second form that gives
+     * such a lane the out-of-range offset of a lane without a rate, so that its atomic never leaves the wave, and in which a
+     * wave with nothing to add skips the rate arithmetic; it costs 5 % where no such cell exists and saves a quarter of the
+     * launch where two thirds of the pairs lie beyond the table (the benchmark medium at r_RT = 64: -24 %).
+     * 0 (default): the library decides -- it takes that form while its probes (the first launch, every 64th after it, sooner
+     *    after an upload; read back without waiting) find more than 15 % of the rated pairs dark.
+     * 1: always; kernels without buffer atomics take round 2's variant that tests and branches.
+     * 2: never: every rated cell is looked up and added, as the reference does (rates.cu:16-41, raytracing.cu:328). */
     ASORA_OPT_SKIP_ZERO_RATES = 11,
     /* 1: the rate atomics are global_atomic_add_f64 under `if (lane has a rate)` even where the grids are small enough for
      *    the default, buffer_atomic_add_f64 through a descriptor over [phi | phi_t] with out-of-range offsets for lanes

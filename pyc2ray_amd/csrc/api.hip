@@ -158,6 +158,10 @@ static int release_all()
     release_geometry(st);
     st.init = false; st.N = 0; st.ncell = 0;
     st.rt_last_R = -1.0; st.rt_same_R_launches = 0; st.rt_R_has_changed = false;
+    if (st.zero_probe_dev) { (void)hipFree(st.zero_probe_dev); st.zero_probe_dev = nullptr; }
+    if (st.zero_probe_host) { (void)hipHostFree(st.zero_probe_host); st.zero_probe_host = nullptr; }
+    if (st.zero_probe_done) { (void)hipEventDestroy(st.zero_probe_done); st.zero_probe_done = nullptr; }
+    st.zero_probe_pending = false; st.zero_known = false; st.zero_dark = false; st.zero_since_probe = 0;
     st.rt_open = false;
     return 0;
 }
@@ -733,6 +737,7 @@ int asora_grid_to_device(int which, const double *host, int N, char order)
     if (!host) return fail(3, "grid_to_device: null host pointer");
     State &st = g_state;
     if (which == ASORA_GRID_PHI_HEAT) { if (int rc = ensure_heat_grid()) return rc; }
+    st.zero_since_probe = std::max(st.zero_since_probe, 48);   // new medium: look again for cells beyond the table soon (launch_raytrace: at 64)
     const size_t bytes = st.ncell * sizeof(double);
     if (order == 'C' || order == 'c') {
         ASORA_HIP_TRY(hipMemcpyAsync(st.grid[which], host, bytes, hipMemcpyHostToDevice, st.stream));
@@ -833,6 +838,7 @@ int asora_photo_table_to_device(const double *thin_table, const double *thick_ta
     if (int rc = require_init("photo_table_to_device")) return rc;
     if (NumTau < 1 || !thin_table || !thick_table) return fail(3, "photo_table_to_device: empty table");
     State &st = g_state;
+    st.zero_since_probe = std::max(st.zero_since_probe, 48);
     if (st.tables) { (void)hipFree(st.tables); st.tables = nullptr; }
     // device layout: pairs {T[i], T[i+1]-T[i]} so that one 16-byte load serves the linear interpolation
     // of photo_lookuptable (rates.cu:82); the last pair is {T[last], 0}
@@ -881,6 +887,7 @@ int asora_source_data_to_device(const int32_t *pos, const double *flux, int NumS
     if (int rc = require_init("source_data_to_device")) return rc;
     if (NumSrc < 0 || (NumSrc > 0 && (!pos || !flux))) return fail(3, "source_data_to_device: bad arguments");
     State &st = g_state;
+    st.zero_since_probe = std::max(st.zero_since_probe, 48);
     // validate on the host before anything reaches a kernel: positions index the grid directly
     for (int s = 0; s < NumSrc; ++s)
         for (int ax = 0; ax < 3; ++ax)

@@ -27,6 +27,7 @@ constexpr int MAX_UNITS = 96;   // workgroups per source: 8 octants, 12 mirrored
 // launch (0.2 ms for 8000 workgroups, whatever the radius); spread over COUNTER_SLOTS addresses by workgroup index they cost
 // nothing, and asora_last_raytrace_counts sums the slots.
 constexpr int COUNTER_SLOTS = 4096;
+constexpr int ZERO_PROBE_SLOTS = 256;   // RtParams.zero_probe: {rated pairs, exact zeros left out} of ONE launch, spread over these slots
 constexpr int COUNTER_FIELDS = 3;   // per slot: rated pairs, evaluated cells, rated pairs whose rate was exactly +0 and was not added
 
 // Upper limit of the real table index in photo_lookuptable: min(float(NumTau), ...) of rates.cu:79 / real(NumTau) of
@@ -68,6 +69,7 @@ struct RtParams {
     double *shell_scratch;      // global shell buffers when they do not fit LDS, else nullptr
     unsigned long long *counters;
     const int *done_flag;       // evolve loop: device flag "the step has converged" -> the launch does nothing; or nullptr
+    unsigned long long *zero_probe;   // SKIP_ZERO kernels: where a probe launch sums what it rated and what it left out, or nullptr
     // ---- rows cut at 64-byte lines (ASORA_OPT_ALIGNED_ROWS; launch_raytrace) ----
     int aligned;                // 1: geom[] holds 8 x units tables, [class * units + unit], class = source position & 7 along the
                                 //    memory-contiguous axis of the unit's face (k for the x- and y-sectors, i for the z-sector)
@@ -136,6 +138,13 @@ struct State {
     OctGeomDev geom_host[MAX_UNITS];        // device pointers of the unit tables ([class * units + unit] when geom_aligned)
     bool geom_aligned = false;
     // how the radius has behaved across raytrace launches (launch_raytrace: the eight-fold tables only pay when they are reused)
+    // exact-zero rates (ASORA_OPT_SKIP_ZERO_RATES = 0): launch_raytrace takes the kernels that leave them out while its probes
+    // find enough of them
+    unsigned long long *zero_probe_dev = nullptr;    // [2 * ZERO_PROBE_SLOTS]
+    unsigned long long *zero_probe_host = nullptr;   // pinned: {rated, left out} of the last probe
+    hipEvent_t zero_probe_done = nullptr;
+    bool zero_probe_pending = false, zero_known = false, zero_dark = false;
+    int zero_since_probe = 0;
     double rt_last_R = -1.0;
     long rt_same_R_launches = 0;
     bool rt_R_has_changed = false;

@@ -170,12 +170,6 @@ extern "C" __device__ double asora_buffer_atomic_fadd_f64(double, __amdgpu_buffe
 // 1: within a group of 8 sources the units are dispatched largest first (the z-sector units hold the most cells), so
 // that the workgroups still running when the grid drains are the short ones.  Measured (tools/ab_macro.sh, 1000 sources,
 // 256^3): R = 24 -2.6 %, 32 -1.8 %, 48 -1.7 %, 64 -0.5 %.
-// 1: in the buffer-atomic kernels a rate that is exactly +0 (a thick cell beyond the last table entry) is not added: see the
-// kernel's SKIP_ZERO.  2: and a wave without anything to add skips the rate arithmetic.  0: every rated cell is added (A/B).
-#ifndef ASORA_SUPPRESS_ZERO_ADDS
-#define ASORA_SUPPRESS_ZERO_ADDS 2
-#endif
-
 #ifndef ASORA_UNITS_LARGEST_FIRST
 #define ASORA_UNITS_LARGEST_FIRST 1
 #endif
@@ -254,7 +248,7 @@ template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP, bool HEAT, int TABCAP,
 __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? ASORA_PAIR_MIN_WAVES : ASORA_MIN_WAVES) : 1)) raytrace_octant_kernel(const RtParams p)
 {
     extern __shared__ double lds_raw[];
-    static_assert(NSRC == 1 || (ASORA_LATE_LOOKUP && !GLOBAL_SCRATCH && !DUMP && !SKIP_ZERO), "paired sources: production variant only");
+    static_assert(NSRC == 1 || (ASORA_LATE_LOOKUP && !GLOBAL_SCRATCH && !DUMP && BUFATOM), "paired sources: production variant only");
     static_assert(!SUBBOX || (NSRC == 1 && ASORA_LATE_LOOKUP && !GLOBAL_SCRATCH && !DUMP && !SKIP_ZERO && !GREY), "sub-box sweep: table rates, shells in LDS");
 
     if (p.done_flag && *p.done_flag) return;   // evolve loop: an iteration enqueued beyond convergence does nothing
@@ -357,7 +351,8 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     constexpr bool grey = GREY;
 
     // work accounting, per wave (scalar registers: population counts of the lane masks, no per-lane adds)
-    unsigned int n_gamma = 0, n_eval = 0, n_zero = 0;      // n_zero: rated cells whose rate was exactly +0 and was not added
+    unsigned int n_gamma = 0, n_eval = 0;
+    unsigned int n_zero_lane = 0;                           // this lane's rated cells whose rate was exactly +0 and was not added
     unsigned int src_cell_gamma = 0, src_cell_eval = 0;      // the source cell (thread 0 only)
 
     // rate accumulation: `idx` indexes [phi | phi_t] (and [heat | heat_t])
@@ -633,29 +628,28 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
             bool wave_adds = true;
 #pragma unroll
             for (int q = 0; q < NSRC; ++q) add[q] = rated[q];
-            // BUFATOM kernels (round 3): the same test per lane, without the branch -- a lane whose rate is exactly +0 carries the
-            // out-of-range offset like a lane without a rate, so its atomic never leaves the wave; the lookups are issued
-            // regardless.  p.tau_zero = +inf switches it off (ASORA_OPT_SKIP_ZERO_RATES = 2, grey opacity).
-            if (SKIP_ZERO || (BUFATOM && !GREY && ASORA_SUPPRESS_ZERO_ADDS)) {
+            // SKIP_ZERO with BUFATOM (round 3; the variant launch_raytrace takes while its probes find such cells): the same
+            // test per lane without a branch around the atomic -- the lane carries the out-of-range offset of a lane without
+            // a rate, so its atomic never becomes a request -- and, below, whole waves of them skip the rate arithmetic.
+            if (SKIP_ZERO) {
 #pragma unroll
                 for (int q = 0; q < NSRC; ++q) {
-                    const bool zero_rate = thick[q] && tau_at_entry[q] >= p.tau_zero && fabs(vol_nhi[q]) > 1e-250 &&
-                                           (vol_nhi[q] - vol_nhi[q] == 0.0);
+                    // (BUFATOM form: one compare.  A thick cell has nHI * path * sig > 1e-7, so nHI is an ordinary positive number
+                    //  and pref = flux / (volume x nHI) is finite unless the volume factor itself is out of range, which the
+                    //  branching variant's two extra tests guard against and this one leaves to vol_nhi > 0 being implied)
+                    const bool zero_rate = (SKIP_ZERO && !BUFATOM)
+                        ? (thick[q] && tau_at_entry[q] >= p.tau_zero && fabs(vol_nhi[q]) > 1e-250 && (vol_nhi[q] - vol_nhi[q] == 0.0))
+                        : (thick[q] && tau_at_entry[q] >= p.tau_zero);
                     add[q] = rated[q] && !zero_rate;
-                    n_zero += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(rated[q] && zero_rate));
+                    n_zero_lane += (rated[q] && zero_rate) ? 1u : 0u;      // per lane: one add-with-carry; summed when the workgroup ends
                 }
-                if (SKIP_ZERO && !BUFATOM) wave_adds = __builtin_amdgcn_readfirstlane((int)__any(add[0])) != 0;
-#if ASORA_SUPPRESS_ZERO_ADDS >= 2
-                // ... and a wave none of whose lanes has anything to add leaves out the division, the logarithms and the index
-                // arithmetic as well -- but issues as many (wave-uniform, cheap) table loads as the other path, so that the
-                // number of operations in flight is the same wherever the two paths meet
-                if (BUFATOM && !SKIP_ZERO) {
-                    bool any_add = add[0];
+                // a wave none of whose lanes has anything to add leaves out the division, the logarithms and the index
+                // arithmetic as well; the BUFATOM form then issues as many (wave-uniform, cheap) table loads as the other path,
+                // so that the number of operations in flight is the same wherever the two paths meet
+                bool any_add = add[0];
 #pragma unroll
-                    for (int q = 1; q < NSRC; ++q) any_add = any_add || add[q];
-                    wave_adds = __builtin_amdgcn_ballot_w64(any_add) != 0ull;
-                }
-#endif
+                for (int q = 1; q < NSRC; ++q) any_add = any_add || add[q];
+                wave_adds = __builtin_amdgcn_ballot_w64(any_add) != 0ull;
             }
             {   // the previous step's lookups have had a whole step to arrive: form its rates now, issue this step's
                 // lookups, then add the rates behind them
@@ -686,8 +680,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
                         B2[q] = lookup_issue<HEAT>(tab, arg_B[q], p, logtab, SUBBOX ? 0 : toff[q]);
                     }
                 }
-#if ASORA_SUPPRESS_ZERO_ADDS >= 2
-                else if (BUFATOM && !SKIP_ZERO) {
+                else if (BUFATOM && SKIP_ZERO) {
 #pragma unroll
                     for (int q = 0; q < NSRC; ++q) {     // (distinct addresses, or the loads would be merged)
                         const double2 *__restrict__ dummy = tab + (threadIdx.x & 1) + 4 * q;
@@ -697,7 +690,6 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
                         else { A2[q].h = A2[q].t; B2[q].h = B2[q].t; }
                     }
                 }
-#endif
                 if (SUBBOX) {
                     // what leaves the PREVIOUS step's cell through the far side, if that cell lies on a face of the box
                     const bool lost = (BUFATOM ? late_off[0] != ASORA_OOB_OFFSET : late_ok[0]) && pend_edge;
@@ -857,11 +849,18 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     }
 
     // work accounting: one atomic per wave and counter
+    unsigned int n_zero = n_zero_lane;
+    if (SKIP_ZERO) for (int o = 32; o > 0; o >>= 1) n_zero += __shfl_down(n_zero, o);
     if ((threadIdx.x & 63) == 0) {
         unsigned long long *slot = p.counters + COUNTER_FIELDS * (blockIdx.x & (COUNTER_SLOTS - 1));     // (see COUNTER_SLOTS)
         atomicAdd(slot, (unsigned long long)(n_gamma + src_cell_gamma));
         atomicAdd(slot + 1, (unsigned long long)(n_eval + src_cell_eval));
         if (n_zero) atomicAdd(slot + 2, (unsigned long long)n_zero);
+        if (SKIP_ZERO && p.zero_probe) {      // a probe launch (launch_raytrace): its own pair of sums, spread like the others
+            unsigned long long *pr = p.zero_probe + 2 * (blockIdx.x & (ZERO_PROBE_SLOTS - 1));
+            atomicAdd(pr, (unsigned long long)(n_gamma + src_cell_gamma));
+            if (n_zero) atomicAdd(pr + 1, (unsigned long long)n_zero);
+        }
     }
 }
 
@@ -1744,19 +1743,26 @@ constexpr size_t lds_table_bytes(int tabcap, int nsrc = 1) { return LOG_TABLE_SI
 // the paired-sources variant (NSRC = 2) exists for the production path only: table rates, no heating, no dump, shell
 // buffers in LDS, buffer atomics
 template <int T, int TABCAP>
-static int launch_variant_pairs(State &st, const RtParams &q, unsigned grid, size_t lds_bytes, hipStream_t stream)
+static int launch_variant_pairs(State &st, const RtParams &q, unsigned grid, size_t lds_bytes, hipStream_t stream, bool skip_zero)
 {
-    ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, false, TABCAP, false, false, true, 2>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, false, TABCAP, false, false, true, 2>), dim3(grid), dim3(T),
-                       lds_bytes, stream, q);
+    if (skip_zero) {
+        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, false, TABCAP, true, false, true, 2>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, false, TABCAP, true, false, true, 2>), dim3(grid), dim3(T),
+                           lds_bytes, stream, q);
+    } else {
+        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, false, TABCAP, false, false, true, 2>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, false, TABCAP, false, false, true, 2>), dim3(grid), dim3(T),
+                           lds_bytes, stream, q);
+    }
     ASORA_HIP_TRY(hipGetLastError());
     return 0;
 }
 
 template <int T, int TABCAP>
 static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t lds_bytes, bool use_lds, bool dump, bool heat,
-                          hipStream_t stream)
+                          hipStream_t stream, bool skip_zero)
 {
 #define ASORA_LAUNCH(GS, DP, HT, SZ, GR, BA)                                                                           \
     do {                                                                                                           \
@@ -1777,7 +1783,7 @@ static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t ld
     // ASORA_OPT_SKIP_ZERO_RATES = 1 where the buffer-atomic kernel (which drops exact zeros by itself) is not available: the
     // branching variant that leaves them out
     else if (use_lds && !ba && std::isfinite(q.tau_zero) && st.opt[ASORA_OPT_SKIP_ZERO_RATES] == 1) ASORA_LAUNCH(false, false, false, true, false, false);
-    else                  { if (ba) ASORA_LAUNCH(false, false, false, false, false, true); else if (use_lds) ASORA_LAUNCH(false, false, false, false, false, false); else ASORA_LAUNCH(true, false, false, false, false, false); }
+    else                  { if (ba && skip_zero) ASORA_LAUNCH(false, false, false, true, false, true); else if (ba) ASORA_LAUNCH(false, false, false, false, false, true); else if (use_lds) ASORA_LAUNCH(false, false, false, false, false, false); else ASORA_LAUNCH(true, false, false, false, false, false); }
 #undef ASORA_LAUNCH
     ASORA_HIP_TRY(hipGetLastError());
     return 0;
@@ -1817,6 +1823,19 @@ static int source_pairs_by_class(State &st, const int32_t *host_pos, const void 
     st.pair_lists.push_back(e);
     out = &st.pair_lists.back();
     return 0;
+}
+
+// {rated pairs, exact zeros left out} of a probe launch, summed over its slots into pinned host memory
+__global__ void __launch_bounds__(ZERO_PROBE_SLOTS) zero_probe_sum_kernel(const unsigned long long *__restrict__ slots, unsigned long long *out)
+{
+    __shared__ unsigned long long r[2][ZERO_PROBE_SLOTS];
+    r[0][threadIdx.x] = slots[2 * threadIdx.x]; r[1][threadIdx.x] = slots[2 * threadIdx.x + 1];
+    __syncthreads();
+    for (int o = ZERO_PROBE_SLOTS / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { r[0][threadIdx.x] += r[0][threadIdx.x + o]; r[1][threadIdx.x] += r[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = r[0][0]; out[1] = r[1][0]; }
 }
 
 int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t side)
@@ -1906,6 +1925,35 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
             if (st.side_pending[q]) ASORA_HIP_TRY(hipStreamWaitEvent(st.stream, st.side_done[q], 0));
     }
 
+    // Exact-zero rates (ASORA_OPT_SKIP_ZERO_RATES, see the kernel's SKIP_ZERO).  The kernels that leave them out cost 5 % where
+    // there are none, and save up to a quarter of the launch where most cells lie beyond the table (the neutral medium of an
+    // early-reionisation run).  Left to the library (0) a launch takes them while the last PROBE found more than 15 % of the
+    // rated pairs dark; a probe is such a launch whose two sums go to pinned host memory behind it and are looked at, without
+    // waiting, by a later call: the first launch, every 64th after it, every launch while the dark variant runs anyway.
+    bool skip_zero = false, probe = false;
+    {
+        const bool exists = use_lds && !dump && !heat && !p.grey && std::isfinite(p.tau_zero) && 16ull * p.ncell <= 0x80000000ull &&
+                            !st.opt[ASORA_OPT_GLOBAL_ATOMICS];
+        if (exists && skip_zero_opt == 1) skip_zero = true;
+        else if (exists && skip_zero_opt == 0) {
+            if (!st.zero_probe_dev) {
+                ASORA_HIP_TRY(hipMalloc(&st.zero_probe_dev, 2 * ZERO_PROBE_SLOTS * sizeof(unsigned long long)));
+                ASORA_HIP_TRY(hipHostMalloc(&st.zero_probe_host, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+                ASORA_HIP_TRY(hipEventCreateWithFlags(&st.zero_probe_done, hipEventDisableTiming));
+            }
+            if (st.zero_probe_pending && hipEventQuery(st.zero_probe_done) == hipSuccess) {
+                const double rated = (double)st.zero_probe_host[0], dark = (double)st.zero_probe_host[1];
+                st.zero_dark = rated > 0.0 && dark > 0.15 * rated;
+                st.zero_known = true;
+                st.zero_probe_pending = false;
+            }
+            (void)hipGetLastError();      // (hipErrorNotReady from the query is not an error)
+            st.zero_since_probe += 1;
+            probe = !st.zero_probe_pending && (!st.zero_known || st.zero_since_probe >= 64 || st.zero_dark);
+            skip_zero = probe || st.zero_dark;
+        }
+    }
+
     int done = 0;
     while (done < p.src_count) {
         int batch = p.src_count - done;
@@ -1929,6 +1977,11 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
         q.src_begin = p.src_begin + done;
         q.src_count = batch;
         q.shell_scratch = use_lds ? nullptr : st.shell_scratch;
+        q.zero_probe = nullptr;
+        if (probe && done == 0) {
+            ASORA_HIP_TRY(hipMemsetAsync(st.zero_probe_dev, 0, 2 * ZERO_PROBE_SLOTS * sizeof(unsigned long long), stream));
+            q.zero_probe = st.zero_probe_dev;
+        }
         int groups = pairs ? (batch + 1) / 2 : batch;              // workgroups per unit
         if (pairs && aligned) {
             const State::PairList *pl = nullptr;
@@ -1942,32 +1995,40 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
             KernelTimer kt(ASORA_KERNEL_RAYTRACE, stream);
             int rc = 0;
             if (pairs) {
-                if (pairs_tiny) rc = launch_variant_pairs<256, 32>(st, q, grid, lds_bytes, stream);
+                if (pairs_tiny) rc = launch_variant_pairs<256, 32>(st, q, grid, lds_bytes, stream, skip_zero);
                 else if (pairs_small) {
-                    if (threads == 64)       rc = launch_variant_pairs<64, 64>(st, q, grid, lds_bytes, stream);
-                    else if (threads == 128) rc = launch_variant_pairs<128, 64>(st, q, grid, lds_bytes, stream);
-                    else                     rc = launch_variant_pairs<256, 64>(st, q, grid, lds_bytes, stream);
+                    if (threads == 64)       rc = launch_variant_pairs<64, 64>(st, q, grid, lds_bytes, stream, skip_zero);
+                    else if (threads == 128) rc = launch_variant_pairs<128, 64>(st, q, grid, lds_bytes, stream, skip_zero);
+                    else                     rc = launch_variant_pairs<256, 64>(st, q, grid, lds_bytes, stream, skip_zero);
                 } else switch (threads) {
-                    case 64:  rc = launch_variant_pairs<64, 256>(st, q, grid, lds_bytes, stream); break;
-                    case 128: rc = launch_variant_pairs<128, 256>(st, q, grid, lds_bytes, stream); break;
-                    case 512: rc = launch_variant_pairs<512, 256>(st, q, grid, lds_bytes, stream); break;
-                    default:  rc = launch_variant_pairs<256, 256>(st, q, grid, lds_bytes, stream); break;
+                    case 64:  rc = launch_variant_pairs<64, 256>(st, q, grid, lds_bytes, stream, skip_zero); break;
+                    case 128: rc = launch_variant_pairs<128, 256>(st, q, grid, lds_bytes, stream, skip_zero); break;
+                    case 512: rc = launch_variant_pairs<512, 256>(st, q, grid, lds_bytes, stream, skip_zero); break;
+                    default:  rc = launch_variant_pairs<256, 256>(st, q, grid, lds_bytes, stream, skip_zero); break;
                 }
             } else if (big_tables) {
-                if (threads == 1024)     rc = launch_variant<1024, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat, stream);
-                else if (threads == 512) rc = launch_variant<512, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat, stream);
-                else                rc = launch_variant<256, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat, stream);
+                if (threads == 1024)     rc = launch_variant<1024, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat, stream, skip_zero);
+                else if (threads == 512) rc = launch_variant<512, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat, stream, skip_zero);
+                else                rc = launch_variant<256, 1024>(st, q, grid, lds_bytes, use_lds, dump, heat, stream, skip_zero);
             } else if (small_tables) {
-                if (threads == 64) rc = launch_variant<64, 64>(st, q, grid, lds_bytes, use_lds, dump, heat, stream);
-                else               rc = launch_variant<128, 64>(st, q, grid, lds_bytes, use_lds, dump, heat, stream);
+                if (threads == 64) rc = launch_variant<64, 64>(st, q, grid, lds_bytes, use_lds, dump, heat, stream, skip_zero);
+                else               rc = launch_variant<128, 64>(st, q, grid, lds_bytes, use_lds, dump, heat, stream, skip_zero);
             } else switch (threads) {
-                case 64:  rc = launch_variant<64, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream); break;
-                case 128: rc = launch_variant<128, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream); break;
-                case 512: rc = launch_variant<512, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream); break;
-                case 1024: rc = launch_variant<1024, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream); break;
-                default:  rc = launch_variant<256, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream); break;
+                case 64:  rc = launch_variant<64, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream, skip_zero); break;
+                case 128: rc = launch_variant<128, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream, skip_zero); break;
+                case 512: rc = launch_variant<512, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream, skip_zero); break;
+                case 1024: rc = launch_variant<1024, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream, skip_zero); break;
+                default:  rc = launch_variant<256, 256>(st, q, grid, lds_bytes, use_lds, dump, heat, stream, skip_zero); break;
             }
             if (rc) return rc;
+        }
+        if (q.zero_probe) {
+            hipLaunchKernelGGL(zero_probe_sum_kernel, dim3(1), dim3(ZERO_PROBE_SLOTS), 0, stream,
+                               (const unsigned long long *)st.zero_probe_dev, st.zero_probe_host);
+            ASORA_HIP_TRY(hipGetLastError());
+            ASORA_HIP_TRY(hipEventRecord(st.zero_probe_done, stream));
+            st.zero_probe_pending = true;
+            st.zero_since_probe = 0;
         }
         done += batch;
     }

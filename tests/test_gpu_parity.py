@@ -1304,6 +1304,7 @@ def test_two_sources_per_workgroup_give_the_same_rates(asora):
     # with one and with two sources per workgroup, on dense and on line-aligned tables
     nd_thick = nd * 3.0e4
     lib.grid_to_device(capi.GRID_NDENS, nd_thick)
+    left_out = {0: 0, 1: 0}
     for R in (4.0, 5.5):
         for n in (80, 81):
             for opts in ({}, {"OPT_SECTORS": 9}, {"OPT_SECTORS": 9, "OPT_ALIGNED_ROWS": 2}, {"OPT_SECTORS": 3, "OPT_BLOCK_THREADS": 256},
@@ -1311,9 +1312,11 @@ def test_two_sources_per_workgroup_give_the_same_rates(asora):
                 everything, _ = trace(R, n, 1, OPT_SKIP_ZERO_RATES=2, **opts)
                 assert (everything == 0).sum() > (everything != 0).sum() > 0
                 for pairs in (1, 2):
-                    phi, _ = trace(R, n, pairs, **opts)
-                    assert np.array_equal(phi, everything), (R, n, pairs, opts)
-                    assert lib.last_raytrace_zero_rates() > 0
+                    for skip in (0, 1):      # 0: the library decides by its probes (sooner or later it leaves them out), 1: always
+                        phi, _ = trace(R, n, pairs, OPT_SKIP_ZERO_RATES=skip, **opts)
+                        assert np.array_equal(phi, everything), (R, n, pairs, skip, opts)
+                        left_out[skip] = max(left_out[skip], lib.last_raytrace_zero_rates())
+    assert left_out[1] > 0 and left_out[0] > 0, left_out
     p.device_close()
 
 
