@@ -228,6 +228,92 @@ def run_cpu_workers(procs):
     return wall, res
 
 
+def trip_counts(dt, n, T, x0, xav, gamma, bh00, albpow, colh0, temph0, abu_c):
+    """do_chemistry's trip count per cell (chemistry.f90:146-203 with doric :279-311), vectorised on the host: how many times
+    each cell goes round the loop the fused pass runs per lane (a wave lasts as long as its slowest lane)."""
+    brech0 = bh00 * (T / 1e4) ** albpow
+    acolh0 = colh0 * np.sqrt(T) * np.exp(-temph0 / T)
+    nit = np.zeros(n.shape, dtype=np.int32)
+    live = np.ones(n.shape, dtype=bool)
+    xav = xav.copy()
+    for it in range(1, 402):
+        idx = np.flatnonzero(live)
+        if idx.size == 0:
+            break
+        nn, xa, g = n.flat[idx], xav.flat[idx], gamma.flat[idx]
+        de = nn * (xa + abu_c)
+        aih0 = g + de * acolh0.flat[idx]
+        delth = aih0 + de * brech0.flat[idx]
+        eqxh = aih0 / delth
+        deltht = delth * dt
+        ee = np.exp(-deltht)
+        avg = np.where(deltht < 1.0e-8, 1.0, (1.0 - ee) / np.where(deltht == 0, 1.0, deltht))
+        new = np.maximum(eqxh + (x0.flat[idx] - eqxh) * avg, 1e-14)
+        nit.flat[idx] = it
+        done = (np.abs((new - xa) / (1.0 - new)) < 1.0e-3) | (1.0 - new < 1.0e-8) | (it > 400)
+        xav.flat[idx] = new
+        live.flat[idx[done]] = False
+    return nit
+
+
+def evolving_state(lib, p, _capi, N, R, thin, thick, dlog, numtau, flux_scale=1e3, nsrc=1000, histogram=True):
+    """The counterpart of the headline's quiet medium (VERDICT r3 #5a): BASELINE configs[3] (log-normal density, sources on the
+    densest cells) with fluxes x `flux_scale`, so that one converged time step of 1 Myr ionises ~20 % of the volume; the SECOND
+    time step then starts with fronts everywhere.  Per outer iteration of that step: duration of the raytrace and of the fused
+    pass (HIP events), count of non-converged cells; for its first iteration the histogram of do_chemistry trip counts.
+    The library state (sources, grids) is replaced: call last."""
+    from pyc2ray_amd.utils.sourceutils import format_sources
+    ndens, xh, temp, dr, pos, flux = make_workload("cosmo", N, nsrc)
+    p0, f0 = format_sources(pos, flux * flux_scale)
+    lib.source_data_to_device(p0, f0, nsrc)
+    lib.grid_to_device(_capi.GRID_NDENS, ndens)
+    lib.grid_to_device(_capi.GRID_TEMP, temp)
+    lib.grid_to_device(_capi.GRID_XH, xh)
+    chem = (MYR, BH00, ALBPOW, COLH0, TEMPH0, ABU_C)
+    conv_fraction = 1e-4
+    conv_criterion = min(int(conv_fraction * N ** 3), (nsrc - 1) / 3)
+    lib.set_option(_capi.OPT_TIMING, 1)
+
+    def time_step(want_hist):
+        lib.evolve_begin(*chem, R, SIG, dr, MINLOGTAU, dlog, numtau, 0, nsrc, conv_criterion, conv_fraction)
+        rows, hist, done = [], None, False
+        while not done and len(rows) < 200:
+            x_before = lib.grid_to_host(_capi.GRID_XH, np.empty((N, N, N))) if (want_hist and not rows) else None
+            lib.kernel_time_reset()
+            lib.evolve_enqueue(1)
+            _, done, r = lib.evolve_poll(4)
+            ch_ms, _ = lib.kernel_time_ms(_capi.KERNEL_CHEMISTRY)
+            rt_ms, _ = lib.kernel_time_ms(_capi.KERNEL_RAYTRACE)
+            rows.append((rt_ms, ch_ms, int(r[0][0])))
+            if x_before is not None:
+                g = lib.grid_to_host(_capi.GRID_PHI_ION, np.empty((N, N, N)))
+                nit = trip_counts(chem[0], ndens, temp, x_before, x_before, g, *chem[1:])
+                c = np.bincount(nit.ravel(), minlength=4)
+                hist = {"trip_count_cells": {str(k): int(v) for k, v in enumerate(c) if v}, "mean_trip_count": float(nit.mean()),
+                        "max_trip_count": int(nit.max()), "mean_of_wave_maxima": float(nit.reshape(-1, 64).max(axis=1).mean())}
+        return rows, hist
+
+    rows1, _ = time_step(False)
+    x1 = lib.grid_to_host(_capi.GRID_XH_INTERMED, np.empty((N, N, N)))
+    lib.grid_to_device(_capi.GRID_XH, x1)
+    rows2, hist = time_step(histogram)
+    lib.set_option(_capi.OPT_TIMING, 0)
+    rt = [r[0] for r in rows2]
+    ch = [r[1] for r in rows2]
+    return {
+        "workload": f"BASELINE configs[3] ({N}^3 log-normal, {nsrc} sources on the densest cells, r_RT={R:g}), fluxes x {flux_scale:g}, "
+                    "dt = 1 Myr: the SECOND time step, which starts with the fronts of the first",
+        "ionised_volume_fraction_at_start": float((x1 > 0.5).mean()), "mean_x_at_start": float(x1.mean()),
+        "outer_iterations_step_1": len(rows1), "outer_iterations": len(rows2),
+        "raytrace_ms": [round(v, 4) for v in rt], "fused_pass_ms": [round(v, 4) for v in ch],
+        "raytrace_ms_mean": float(np.mean(rt)), "fused_pass_ms_mean": float(np.mean(ch)), "fused_pass_ms_max": float(np.max(ch)),
+        "nonconverged": [r[2] for r in rows2],
+        "first_iteration_trip_counts": hist,
+        "note": "the headline's medium is the CHEAPEST state of both kernels (converged field: every cell leaves do_chemistry after one "
+                "trip; optical depths inside the table); this is the same code on an evolving field",
+    }
+
+
 def main():
     if "--cpu-worker" in sys.argv:
         return _cpu_worker()
@@ -261,6 +347,12 @@ def main():
                          "their first coordinate), 0 = trace, then all-reduce; default: env PYC2RAY_AMD_OVERLAP or 0")
     ap.add_argument("--sectors", type=int, default=0, help="decomposition of a source (ASORA_OPT_SECTORS): 0 auto, 1 octants, 2 sectors, 3 sector pairs, 5 octant pairs, 6 whole sphere, 7 half spheres, 8 all-sign sectors")
     ap.add_argument("--pair-sources", type=int, default=0, help="raytrace, two sources per workgroup: 0 auto, 1 never, 2 always")
+    ap.add_argument("--one-gpu-reference", type=int, default=1,
+                    help="N>1: before the multi-rank region rank 0 ALONE runs the same workload (all sources) through the one-GPU loop "
+                         "while the others wait -> one_gpu_same_workload_ms_per_step, speedup_vs_one_gpu (0 = skip)")
+    ap.add_argument("--evolving-state", type=int, default=-1,
+                    help="one GPU: also time the trace and the fused pass on a grid WITH ionisation fronts (configs[3], fluxes x 1e3, "
+                         "second time step) -> `evolving_state`; default: on for the default job only")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -301,6 +393,7 @@ def main():
     from pyc2ray_amd.utils.sourceutils import format_sources
 
     comm = None
+    links = None
     saved_stdout = None
     if world > 1 or os.environ.get("PYC2RAY_AMD_FORCE_COLLECTIVE", "0") == "1":
         # RCCL prints a version banner on stdout when its first communicator comes up; the contract is ONE JSON
@@ -317,6 +410,13 @@ def main():
         os.environ.setdefault("PYC2RAY_AMD_DIST_TIMEOUT_S", "180")     # a collective that never completes ends the run after 3 minutes
         init_process_group_from_env(backend)
         comm = TorchComm()
+        # what the links of THIS job deliver, through the calls the two exchange schemes use (16 MiB point-to-point ring, all-reduce
+        # of one N^3 grid): `--exchange auto` decides from these, not from assumed rates; identical numbers on every rank
+        links = None
+        try:
+            links = comm.measure_links(p2p_bytes=16 << 20, allreduce_bytes=8 * N ** 3)
+        except Exception as e:
+            print(f"bench: link measurement failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
 
     lib = load_asora()
     p.device_init(N, 64, device_id=int(os.environ.get("PYC2RAY_AMD_BENCH_DEVICE", local_rank)))
@@ -341,27 +441,34 @@ def main():
         plan = SlabPlan(N, world, args.R, [pos[0, bounds[r]:bounds[r + 1]] - 1 for r in range(world)])
         if args.slab_chunks > 0:
             comm.slab_chunks = args.slab_chunks
-        # what each scheme moves per step over its busiest link, and what that costs at two assumed link rates (the build box
-        # has one GPU: no rate was ever measured); ring all-reduce: 2 (P-1) steps of N^3/P doubles over one link each
-        K = plan.common_chunks(comm.slab_chunks)
+        # what each scheme moves per step over its busiest link (exact: SlabPlan) and what that costs at the rates MEASURED in this
+        # job a moment ago (`links`); ring all-reduce: 2 (P-1) steps of N^3/P doubles over one link each -- its time for one
+        # N^3 grid was measured directly
+        Kc = plan.common_chunks(comm.slab_chunks)
         link = plan.largest_transfer()
-        sched = [plan.send_schedule(r, K) for r in range(world)]
+        sched = [plan.send_schedule(r, Kc) for r in range(world)]
         early = [sum((b - a) for pieces in sc[:-1] for _, a, b in pieces) for sc in sched]
         total = [sum((b - a) for pieces in sc for _, a, b in pieces) for sc in sched]
         hidden = min((e / t) if t else 1.0 for e, t in zip(early, total))          # share of exchange 1 that leaves before the last chunk
         ring = 2.0 * (world - 1) / world * 8.0 * N ** 3
+        measured = links is not None and links.get("p2p_GBs") and links.get("allreduce_ms")
         exchange_model = {
-            "slab_bytes_per_link_and_exchange": link, "slab_exchanges_per_step": 2, "slab_trace_chunks": K,
+            "slab_bytes_per_link_and_exchange": link, "slab_exchanges_per_step": 2, "slab_trace_chunks": Kc,
             "slab_share_of_rate_exchange_sent_before_the_last_chunk": hidden,
             "allreduce_ring_bytes_per_link_per_step": ring,
-            "assumed_link_GBs": [50.0, 100.0],
-            "slab_comm_ms": [2.0 * link / (g * 1e6) for g in (50.0, 100.0)],
-            "slab_comm_ms_with_overlap": [(2.0 - hidden) * link / (g * 1e6) for g in (50.0, 100.0)],
-            "allreduce_comm_ms": [ring / (g * 1e6) for g in (50.0, 100.0)],
-            "note": "bytes are exact (SlabPlan); the rates are assumptions; the slab scheme also runs 1/P of the chemistry per rank",
+            "rates_from": "measured in this job (measured_link_GBs)" if measured else "ASSUMED 50 GB/s per link (the link measurement failed)",
         }
-        if args.exchange == "auto" and 2.0 * link > ring:
-            slab = False                         # (every rank reaches nearly every plane: the exchange moves no less than the ring)
+        p2p_gbs = links["p2p_GBs"] if measured else 50.0
+        slab_ms = 2.0 * link / (p2p_gbs * 1e6)
+        allreduce_ms = links["allreduce_ms"] if measured else ring / (50.0 * 1e6)
+        exchange_model.update({
+            "slab_comm_ms": slab_ms, "slab_comm_ms_with_overlap": (2.0 - hidden) * link / (p2p_gbs * 1e6),
+            "allreduce_comm_ms": allreduce_ms,
+            "note": "bytes are exact (SlabPlan); slab_comm_ms = two exchanges of the busiest link's bytes at the measured point-to-point "
+                    "rate, allreduce_comm_ms = the measured all-reduce of one N^3 grid; the slab scheme also runs 1/P of the chemistry per rank",
+        })
+        if args.exchange == "auto" and slab_ms > allreduce_ms:
+            slab = False                         # (every rank reaches nearly every plane, or the point-to-point path is slow here)
         exchange_model["choice"] = "slab" if slab else "allreduce"
     if comm is not None and not slab:
         comm.exchange = "allreduce"
@@ -381,7 +488,6 @@ def main():
     elif comm is not None:
         comm.overlap = False
     p0, f0 = format_sources(my_pos, my_flux)
-    lib.source_data_to_device(p0, f0, n_local)
     lib.grid_to_device(_capi.GRID_NDENS, ndens)
     lib.grid_to_device(_capi.GRID_TEMP, temp)
     lib.grid_to_device(_capi.GRID_XH, xh)
@@ -391,6 +497,44 @@ def main():
     lib.set_option(_capi.OPT_PAIR_SOURCES, args.pair_sources)
 
     chem = (MYR, BH00, ALBPOW, COLH0, TEMPH0, ABU_C)
+    from pyc2ray_amd.evolve import EVOLVE_BATCH
+    poll_every = max(1, min(EVOLVE_BATCH, 32))      # evolve3D reads the device's status back once per batch of iterations
+
+    def one_gpu_region(n_sources, steps):
+        """`steps` outer iterations of the ONE-GPU loop exactly as evolve3D drives it (evolve.py:_device_loop): enqueue, and
+        after every batch of EVOLVE_BATCH iterations one asora_evolve_poll -- the 24-byte status read-back and the fold of the
+        last iteration's rate accumulators into phi_ion.  Returns the last poll's history rows."""
+        rows = []
+        for s_ in range(steps):
+            lib.evolve_enqueue(1)          # raytrace + fused chemistry pass + convergence test
+            if (s_ + 1) % poll_every == 0 or s_ == steps - 1:
+                _, _, r_ = lib.evolve_poll(poll_every)
+                rows = r_ if len(r_) else rows
+        return rows
+
+    # N>1: the SAME workload -- the whole source list on the same density -- on ONE GPU, inside this job: rank 0 alone, through
+    # the one-GPU loop, while the other ranks wait at a barrier.  The denominator of `speedup_vs_one_gpu` (a `--gpus 1` run
+    # of this script measures configs[2], another workload).
+    one_gpu_ms = None
+    if comm is not None and args.one_gpu_reference:
+        if rank == 0:
+            try:
+                pa, fa = format_sources(pos, flux)
+                lib.source_data_to_device(pa, fa, flux.shape[0])
+                lib.evolve_begin(*chem, args.R, SIG, dr, MINLOGTAU, dlog, numtau, 0, flux.shape[0], -1.0, 0.0)
+                one_gpu_region(flux.shape[0], 1 + W)
+                regs = []
+                for _ in range(max(1, args.repeats)):
+                    lib.synchronize()
+                    t0 = time.perf_counter()
+                    one_gpu_region(flux.shape[0], K)
+                    lib.synchronize()
+                    regs.append(time.perf_counter() - t0)
+                one_gpu_ms = float(np.median(regs)) / K * 1e3
+            except Exception as e:
+                print(f"bench: one-GPU reference run failed: {type(e).__name__}: {e}", file=sys.stderr)
+        comm.Barrier()
+    lib.source_data_to_device(p0, f0, n_local)
     state = {"first": True, "slab": slab}
 
     def begin_time_step():
@@ -461,24 +605,41 @@ def main():
     first_iteration_ms = (time.perf_counter() - t0) * 1e3
     for _ in range(W):
         step()
+    if comm is None:
+        lib.evolve_poll(0)
     lib.set_option(_capi.OPT_TIMING, 1)
     lib.kernel_time_reset()
+    if comm is not None:
+        comm.phase_reset()
+        comm.phase_timing = True       # where a step's time goes (HIP events on the library's stream; `phases_ms`)
     # the timed region -- exactly K steps between two fences -- `repeats` times back to back: one region lasts a few tens
-    # of milliseconds, and the fused pass alone varies by 20-30 % from box to box and with the box's temperature
+    # of milliseconds, and the fused pass alone varies by 20-30 % from box to box and with the box's temperature.
+    # One GPU: the polls evolve3D makes (one per EVOLVE_BATCH iterations: status read-back + fold of the rates) are
+    # INSIDE the region.
     regions = []
     conv = None
+    last_rows = []
     n_timed = 0
     for _ in range(max(1, args.repeats)):
-        if comm is None:
-            lib.evolve_poll(0)         # (untimed) the history ring of the device loop holds 64 iterations between polls
         fence()
         t0 = time.perf_counter()
-        for _ in range(K):
-            conv = step()
+        if comm is None:
+            rows_ = one_gpu_region(n_local, K)
+            last_rows = rows_ if len(rows_) else last_rows
+        else:
+            for _ in range(K):
+                conv = step()
         fence()
         regions.append(time.perf_counter() - t0)
         n_timed += K
     lib.set_option(_capi.OPT_TIMING, 0)
+    phases_ms = None
+    if comm is not None:
+        comm.phase_timing = False
+        try:
+            phases_ms = comm.phase_report()           # mean per step, MAX over the ranks (a collective)
+        except Exception as e:
+            print(f"bench: phase report failed: {type(e).__name__}: {e}", file=sys.stderr)
 
     gamma_cells, eval_cells = lib.last_raytrace_counts()
     zero_cells = lib.last_raytrace_zero_rates()
@@ -489,6 +650,7 @@ def main():
         # the counters of the device-resident loop run on from evolve_begin: per iteration = total / iterations
         n_done, _, rows = lib.evolve_poll(min(K, 32))
         gamma_cells, eval_cells, zero_cells = gamma_cells // n_done, eval_cells // n_done, zero_cells // n_done
+        rows = rows if len(rows) else last_rows
         conv = (rows[-1][0],) if len(rows) else (0,)
     rt_ms, rt_n = lib.kernel_time_ms(_capi.KERNEL_RAYTRACE)
     ch_ms, ch_n = lib.kernel_time_ms(_capi.KERNEL_CHEMISTRY)
@@ -534,7 +696,12 @@ def main():
     units_per_step = tot_gamma + N ** 3
     value = units_per_step * K / elapsed
     rt_launch_s = (rt_ms / max(rt_n, 1)) * 1e-3
-    achieved = RT_BYTES_PER_UPDATE * gamma_cells / rt_launch_s / 1e9 if rt_n else None
+    # algorithmic bytes of a launch (8 ndens + 8 xh_av + 16 rate read-modify-write per rate-receiving pair).  A pair
+    # whose rate is exactly +0 and is therefore NOT added (ASORA_OPT_SKIP_ZERO_RATES) moves no rate bytes: it counts
+    # 16 B, not 32.  0 such pairs in the headline workload.
+    rt_bytes = RT_BYTES_PER_UPDATE * (gamma_cells - zero_cells) + (RT_BYTES_PER_UPDATE - 16) * zero_cells
+    achieved = rt_bytes / rt_launch_s / 1e9 if rt_n else None
+    achieved_all32 = RT_BYTES_PER_UPDATE * gamma_cells / rt_launch_s / 1e9 if rt_n else None
     insphere = 4.0 * np.pi * args.R ** 3 / 3.0
     default_job = (args.workload == "uniform" and args.R == 32.0 and N == 256 and args.nsrc == 1000 and world == 1)
     rt_counters = pmc_counters("raytrace_octant_kernel") if default_job else {}
@@ -590,8 +757,12 @@ def main():
             "exact_zero_rates_not_added_per_step_rank0": zero_cells,
             "nonconverged_cells_last_step": int(conv[0]) if conv is not None else None,
             "first_iteration_of_a_time_step_ms": first_iteration_ms,
-            "step_definition": "steady-state outer iteration of evolve3D: raytrace + one fused pass (rates folded, chemistry, "
-                               "nHI for the next trace, accumulators zeroed) + convergence test on the device",
+            "step_definition": ("steady-state outer iteration of evolve3D: raytrace + one fused pass (chemistry, nHI for the next "
+                                "trace, next accumulators zeroed) + convergence test on the device; and, once per %d steps as in "
+                                "evolve3D's loop, asora_evolve_poll inside the timed region (status read-back + fold of the last "
+                                "iteration's rate accumulators into phi_ion)" % poll_every) if comm is None else
+                               "one outer iteration of evolve3D_MPI through the calls it makes (TorchComm.slab_iteration or "
+                               "raytrace_and_allreduce): see phases_ms",
         },
         "roofline": {
             "bound": "hbm",
@@ -604,7 +775,10 @@ def main():
             "traffic_source": (PMC_SUMMARY + ": (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch, separate rocprofv3 --pmc "
                                "passes of this command on this workload (a committed measurement, not collected in this run)")
                               if default_job else None,
-            "algorithmic_bytes_per_launch": RT_BYTES_PER_UPDATE * gamma_cells,
+            "algorithmic_bytes_per_launch": rt_bytes,
+            "frac_if_every_pair_counted_32B": (achieved_all32 / HBM_PEAK_GBS) if achieved_all32 else None,
+            "bytes_accounting": "32 B per rate-receiving pair; 16 B for a pair whose exactly-zero rate is not added "
+                                f"({zero_cells} of {gamma_cells} pairs in this launch)",
             "avg_launch_ms": rt_ms / max(rt_n, 1),
             "launches_timed": rt_n,
             "binding_resource": ("the memory-side rate atomics: every double added to the rate grid leaves the L2 in a 64-B atomic request "
@@ -653,6 +827,23 @@ def main():
         "raytrace_ns_per_source_per_insphere_cell": (rt_ms / max(rt_n, 1)) * 1e6 / (max(n_local, 1) * insphere),
     }
 
+    if comm is not None:
+        ms_step = elapsed / K * 1e3
+        out["one_gpu_same_workload_ms_per_step"] = one_gpu_ms
+        out["speedup_vs_one_gpu"] = (one_gpu_ms / ms_step) if one_gpu_ms else None
+        out["one_gpu_same_workload_note"] = ("rank 0 alone, the whole source list of THIS workload through the one-GPU loop "
+                                             "(asora_evolve_enqueue + one poll per %d steps), same steps/repeats, while the other "
+                                             "ranks waited at a barrier; speedup = that / ms_per_step" % poll_every)
+        out["phases_ms"] = phases_ms
+        out["phases_note"] = ("mean per step over the timed regions, MAX over the ranks; slab exchange: spans between HIP events on the "
+                              "library's stream (wait_rates_add = what the rate exchange left un-hidden + the adds; xh_av_exchange is "
+                              "serial by construction), all-reduce path: wall clock between the host synchronisations of its three calls")
+        out["measured_link_GBs"] = links
+    if world == 1 and (args.evolving_state == 1 or (args.evolving_state < 0 and default_job)):
+        try:
+            out["evolving_state"] = evolving_state(lib, p, _capi, N, args.R, thin, thick, dlog, numtau)
+        except Exception as e:   # reporting only
+            out["evolving_state"] = {"failed": f"{type(e).__name__}: {e}"}
     if world == 1 and args.cpu_sources > 0:
         try:
             use_ref, ns, t_rt, t_chem = cpu_baseline(args.workload, N, ndens, xh, temp, dr, pos, flux, thin, thick,

@@ -157,7 +157,7 @@ static int release_all()
     drop(st.sb_active); drop(st.sb_nbox); drop(st.sb_loss); drop(st.sb_loss_final); st.subbox_cap = 0;
     release_geometry(st);
     st.init = false; st.N = 0; st.ncell = 0;
-    st.rt_last_R = -1.0; st.rt_same_R_launches = 0; st.rt_R_has_changed = false;
+    st.rt_last_R = -1.0; st.rt_same_R_calls = 0; st.rt_R_has_changed = false;
     if (st.zero_probe_dev) { (void)hipFree(st.zero_probe_dev); st.zero_probe_dev = nullptr; }
     if (st.zero_probe_host) { (void)hipHostFree(st.zero_probe_host); st.zero_probe_host = nullptr; }
     if (st.zero_probe_done) { (void)hipEventDestroy(st.zero_probe_done); st.zero_probe_done = nullptr; }
@@ -200,6 +200,7 @@ static void fill_rt_params(RtParams &p, double R, double sig, double dr, double 
     p.heat = st.grid[ASORA_GRID_PHI_HEAT];
     p.src_pos = st.src_pos; p.src_flux = st.src_flux;
     p.counters = st.counters;
+    p.radius_stays = note_call_radius(st, R) ? 1 : 0;
 #ifdef ASORA_ENABLE_ABLATION
     { const char *ab = getenv("ASORA_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
 #endif

@@ -53,6 +53,7 @@ struct RtParams {
     int fortran_consts, grey, z_transposed;
     int src_begin, src_count;
     int shape_src_count;   // source count the launch shape is chosen for (the whole call's, not a pipelined range's)
+    int radius_stays;      // decided once per call (note_call_radius): the line-aligned tables may be built for this radius
     int ablate;            // diagnostics only (env ASORA_ABLATE): 1 = no rate atomics, 2 = no rates
     OctGeomDev geom[MAX_UNITS]; // by value: pointers read from the kernarg segment are known-global to the compiler
     int units;                  // workgroups per source: 8 octants, 24 octant-sectors, 12 mirrored sector pairs, 96 sector wedges
@@ -146,7 +147,7 @@ struct State {
     bool zero_probe_pending = false, zero_known = false, zero_dark = false;
     int zero_since_probe = 0;
     double rt_last_R = -1.0;
-    long rt_same_R_launches = 0;
+    long rt_same_R_calls = 0;
     bool rt_R_has_changed = false;
     // host copies of the two source lists (as uploaded, and in lexicographic order of the position) and, for the paired-sources
     // variant on aligned tables, who shares a workgroup with whom: built once per (list, range), see source_pairs_by_class
@@ -265,6 +266,7 @@ struct KernelTimer {
 // ---------------------------------------------------------------------------------------------
 
 void release_geometry(State &st);
+bool note_call_radius(State &st, double R);   // once per call: may the eight-fold aligned tables be built for this radius?
 void release_pair_lists(State &st);     // with every change of the source lists
 int launch_fold_range(State &st, const double *src_t, double *dst, int i_begin, int i_count);   // dst[i][j][k] += src_t[k][j][i], i in the range
 int ensure_logtab(State &st);

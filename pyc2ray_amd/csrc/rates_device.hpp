@@ -70,10 +70,13 @@ template <bool HEAT = false, typename Params = RtParams>
 __device__ __forceinline__ Lookup lookup_issue(const double2 *__restrict__ table, double tau, const Params &p,
                                                const double2 *__restrict__ logtab, int offset = 0)
 {   // offset: entries to skip in front (the thin table follows the thick one: a per-lane offset instead of a per-lane pointer)
+    // (upper clamp: log2_pos is only defined for finite arguments -- for tau = +inf the mantissa/exponent split gives -inf, i.e.
+    //  the FIRST table entry, where the reference's log10(inf) -> min(NumTau, .) reads the last one; any finite value beyond
+    //  10^maxlogtau is clamped to the last entry by numtau_f below)
 #ifdef ASORA_ENABLE_ABLATION
-    const double l2 = log2_pos(fmax(1.0e-20, tau), logtab, p.ablate & 16);
+    const double l2 = log2_pos(fmin(fmax(1.0e-20, tau), 1.0e300), logtab, p.ablate & 16);
 #else
-    const double l2 = log2_pos(fmax(1.0e-20, tau), logtab);
+    const double l2 = log2_pos(fmin(fmax(1.0e-20, tau), 1.0e300), logtab);
 #endif
     // numtau_f is clamped to table_len - 1 on the host (lut_index_limit): real_i >= table_len - 1 reads the last pair
     // {T[last], 0} whatever the residual, as the reference's i0 = i1 = NumTau does -- no integer clamp here

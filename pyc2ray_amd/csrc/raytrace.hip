@@ -1250,10 +1250,17 @@ static int patch_sphere_cells(State &st, double R, double dr)
     }
     // (a blocking copy from pageable memory: `pairs` may go out of scope right after; the kernel is stream-ordered)
     ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    for (int q = 0; q < 2; ++q) if (st.side[q]) ASORA_HIP_TRY(hipStreamSynchronize(st.side[q]));   // (traces of an earlier pipelined call)
     ASORA_HIP_TRY(hipMemcpy(st.geom_patch_dev, pairs.data(), 2 * n * sizeof(unsigned long long), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(patch_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st.stream,
                        (const unsigned long long *)st.geom_patch_dev, (int)n);
     ASORA_HIP_TRY(hipGetLastError());
+    // a pipelined call (asora_raytrace_begin) traces on the side streams, which only wait for what the main stream had
+    // done when the call began: they must not read the patched words before the patch has run
+    if (st.main_ready) {
+        ASORA_HIP_TRY(hipEventRecord(st.main_ready, st.stream));
+        for (int q = 0; q < 2; ++q) if (st.side[q]) ASORA_HIP_TRY(hipStreamWaitEvent(st.side[q], st.main_ready, 0));
+    }
     return 0;
 }
 
@@ -1838,6 +1845,19 @@ __global__ void __launch_bounds__(ZERO_PROBE_SLOTS) zero_probe_sum_kernel(const 
     if (threadIdx.x == 0) { out[0] = r[0][0]; out[1] = r[1][0]; }
 }
 
+// How the radius behaves from call to call (a call = one raytrace of the library's API, one time step of the evolve loop):
+// the eight-fold line-aligned tables only pay when they are reused (see launch_raytrace)
+bool note_call_radius(State &st, double R)
+{
+    if (R != st.rt_last_R) {
+        if (st.rt_last_R >= 0.0) st.rt_R_has_changed = true;
+        st.rt_last_R = R;
+        st.rt_same_R_calls = 0;
+    }
+    st.rt_same_R_calls += 1;
+    return !st.rt_R_has_changed || st.rt_same_R_calls > 32;
+}
+
 int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t side)
 {
     int units, threads;   // one workgroup per (source, octant) or per (source, octant, sector)
@@ -1857,20 +1877,15 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
     // ... and, left to the library, a radius that stays: building eight forms costs eight times as long (12 ms instead of
     // 2.5 at r = 30), which a run whose r_RT changes with every time step (R_max_LLS in cells under cosmological expansion,
     // ref: c2ray_base.py:460; a dozen launches per step) would pay every step for 0.3 ms saved.  So: aligned from the first
-    // launch on until the radius changes for the first time, afterwards only once a radius has served 32 launches in a row.
-    if (p.R != st.rt_last_R) {
-        if (st.rt_last_R >= 0.0) st.rt_R_has_changed = true;
-        st.rt_last_R = p.R;
-        st.rt_same_R_launches = 0;
-    }
-    st.rt_same_R_launches += 1;
+    // call on until the radius changes for the first time, afterwards only once a radius has served 32 calls in a row.
+    // Decided ONCE PER CALL (note_call_radius, from fill_rt_params), never per launch: every range of a pipelined or chunked
+    // call and every iteration of an evolve batch sees the same tables.
     bool aligned = false;
     {
         const int want = st.opt[ASORA_OPT_ALIGNED_ROWS];
         const double r = std::min(p.R, 0.87 * p.N);
         const bool possible = (units == 6 || units == 12) && !dump && p.N % 8 == 0 && p.z_transposed && host_pos != nullptr && r <= 110.0;
-        const bool radius_stays = !st.rt_R_has_changed || st.rt_same_R_launches > 32;
-        aligned = possible && (want == 2 || (want == 0 && r < 52.5 && radius_stays));
+        aligned = possible && (want == 2 || (want == 0 && r < 52.5 && p.radius_stays));
     }
     if (int rc = ensure_geometry(st, p, threads, units, nullptr, aligned)) return rc;
     p.lut_k1 = 0.30102999566398119521 / p.dlogtau;      // log10(2)/dlogtau

@@ -236,6 +236,51 @@ class _DevicePointer:
         }
 
 
+class _Phases:
+    """Where one multi-rank iteration spends its time (``TorchComm.phase_timing``; bench.py's ``phases_ms``).
+
+    With RCCL everything an iteration does is ordered on the library's stream, transfers included (the stream waits for
+    them, not the host), so a phase is the span between two events recorded on that stream: time the GPU spent on it
+    INCLUDING what it waited for -- `wait_rates_add` is the part of the rate exchange the trace did not hide.  The events
+    are resolved later (``TorchComm.phase_report``), never inside an iteration.  With gloo (CPU rehearsals) the planes go
+    through the host and every phase ends with a host synchronisation and a wall-clock reading."""
+
+    def __init__(self, comm, libasora):
+        import time
+        self._comm, self._lib, self._clock = comm, libasora, time.perf_counter
+        self._device = comm._backend() == "nccl"
+        if self._device:
+            import torch
+            self._torch = torch
+            self._stream = comm._library_stream(libasora)
+            self._events = [("", self._record())]
+        else:
+            libasora.synchronize()
+            self._t = self._clock()
+
+    def _record(self):
+        e = self._torch.cuda.Event(enable_timing=True)
+        e.record(self._stream)
+        return e
+
+    def mark(self, name):
+        """The phase `name` ends here."""
+        if self._device:
+            self._events.append((name, self._record()))
+        else:
+            self._lib.synchronize()
+            t = self._clock()
+            self._comm._phase_add(name, (t - self._t) * 1e3)
+            self._t = t
+
+    def close(self):
+        self._comm._phase_n += 1
+        if self._device:
+            self._comm._phase_pending.append(self._events)
+            if len(self._comm._phase_pending) >= 512:
+                self._comm._phase_resolve()
+
+
 class TorchComm:
     """Communicator over a torch.distributed process group."""
 
@@ -266,6 +311,9 @@ class TorchComm:
         self.slab_chunks = int(os.environ.get("PYC2RAY_AMD_SLAB_CHUNKS", "2" if self._dist.get_world_size(group) == 2 else "1"))
         #: every rank derives the convergence decision from the SAME all-reduced scalars (no broadcast of the decision needed)
         self.identical_scalars = True
+        #: True: every iteration books where its time went (``_Phases``); read with ``phase_report``
+        self.phase_timing = False
+        self._phase_ms, self._phase_n, self._phase_pending = {}, 0, []
         # Bring the communicator up with a collective EVERY rank takes part in.  The slab exchange is point-to-point
         # and a rank with nothing to send or receive skips it; if that were the first operation on the process group,
         # the ranks that do take part would wait for the others in the communicator's set-up.
@@ -345,6 +393,100 @@ class TorchComm:
             self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
             libasora.grid_to_device(which, host)
 
+
+    # -- diagnostics: per-phase times of an iteration, measured link rates ----------------------------------------
+    def _phase_add(self, name, ms):
+        self._phase_ms[name] = self._phase_ms.get(name, 0.0) + ms
+
+    def _phase_resolve(self):
+        if not self._phase_pending:
+            return
+        import torch
+        torch.cuda.synchronize()
+        for events in self._phase_pending:
+            for (_, e0), (name, e1) in zip(events[:-1], events[1:]):
+                self._phase_add(name, e0.elapsed_time(e1))
+        self._phase_pending = []
+
+    def phase_reset(self):
+        self._phase_resolve()
+        self._phase_ms, self._phase_n = {}, 0
+
+    def phase_report(self, reduce_max=True):
+        """Mean milliseconds per iteration of every phase booked since ``phase_reset`` -- the MAXIMUM over the ranks when
+        `reduce_max` (a collective: every rank must call it), plus "iterations".  Phase names: slab exchange -- prepare,
+        trace_fold_post, wait_rates_add, slab_chemistry, xh_av_exchange, scalar_allreduce; all-reduce path -- trace,
+        rate_allreduce, chemistry."""
+        import torch
+        self._phase_resolve()
+        names = sorted(self._phase_ms)
+        n = max(self._phase_n, 1)
+        vals = [self._phase_ms[k] / n for k in names]
+        if reduce_max and self.Get_size() > 1:
+            # (ranks on different exchange paths would book different names: the caller keeps them on one path)
+            t = torch.tensor(vals, dtype=torch.float64)
+            if self._backend() == "nccl":
+                t = t.cuda()
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self._group)
+            vals = t.cpu().tolist()
+        out = dict(zip(names, vals))
+        out["iterations"] = self._phase_n
+        return out
+
+    def measure_links(self, p2p_bytes=16 << 20, allreduce_bytes=128 << 20, reps=3):
+        """What the links of THIS job deliver, through the calls the data path uses: a ring of point-to-point transfers of
+        `p2p_bytes` (every rank sends to its right neighbour and receives from its left one with ``batch_isend_irecv``, as the
+        slab exchange does) and an in-place sum all-reduce of `allreduce_bytes` (the full-grid exchange).  One untimed round
+        each, then the fastest of `reps`; times are the MAXIMUM over the ranks, so every rank returns the same numbers and
+        derives the same choice from them.  Returns {"p2p_bytes", "p2p_ms", "p2p_GBs" (per link and direction),
+        "allreduce_bytes", "allreduce_ms", "allreduce_busbw_GBs" (2 (P-1)/P bytes / time, the ring's per-link rate)}."""
+        import time
+        import torch
+        dist = self._dist
+        P, me = self.Get_size(), self.Get_rank()
+        nccl = self._backend() == "nccl"
+        dev = "cuda" if nccl else "cpu"
+
+        def fence():
+            if nccl:
+                torch.cuda.synchronize()
+
+        def timed(fn):
+            best = None
+            for rep in range(reps + 1):
+                dist.barrier(self._group)
+                fence()
+                t0 = time.perf_counter()
+                fn()
+                fence()
+                dt = time.perf_counter() - t0
+                if rep > 0:
+                    best = dt if best is None else min(best, dt)
+            t = torch.tensor([best], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._group)
+            return float(t.item())
+
+        out = {"p2p_bytes": int(p2p_bytes), "allreduce_bytes": int(allreduce_bytes), "ranks": P, "backend": self._backend()}
+        if P < 2:
+            out.update(p2p_ms=None, p2p_GBs=None, allreduce_ms=None, allreduce_busbw_GBs=None)
+            return out
+        n1 = max(1, int(p2p_bytes) // 8)
+        snd = torch.full((n1,), float(me + 1), dtype=torch.float64, device=dev)
+        rcv = torch.zeros((n1,), dtype=torch.float64, device=dev)
+
+        def ring():
+            ops = [dist.P2POp(dist.isend, snd, (me + 1) % P, group=self._group),
+                   dist.P2POp(dist.irecv, rcv, (me - 1) % P, group=self._group)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        t_p2p = timed(ring)
+        n2 = max(1, int(allreduce_bytes) // 8)
+        buf = torch.zeros((n2,), dtype=torch.float64, device=dev)
+        t_ar = timed(lambda: dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self._group))
+        del buf, snd, rcv
+        out.update(p2p_ms=t_p2p * 1e3, p2p_GBs=8.0 * n1 / t_p2p / 1e9,
+                   allreduce_ms=t_ar * 1e3, allreduce_busbw_GBs=2.0 * (P - 1) / P * 8.0 * n2 / t_ar / 1e9)
+        return out
 
     def preflight_p2p(self, nelem=65536):
         """One small point-to-point round (every rank sends to its right neighbour and receives from its left one) through
@@ -495,11 +637,13 @@ class TorchComm:
         # every rank walks through the same number of rounds and derives every other rank's schedule: the chunk count is a
         # function of the plan, never of this rank alone
         K = plan.common_chunks(getattr(self, "slab_chunks", 1))
+        ph = _Phases(self, libasora) if self.phase_timing else None
         if first:
             libasora.raytrace_begin_planes(R, sig, dr, minlogtau, dlogtau, NumTau, [(0, N)])
         else:
             libasora.raytrace_begin_planes(R, sig, dr, minlogtau, dlogtau, NumTau,
                                            [(a, b - a) for a, b in plan.work_runs(me)])
+        if ph: ph.mark("prepare")
         sched, rsched = plan.send_schedule(me, K), plan.recv_schedule(me, K)
         bounds = plan.chunk_bounds(num_src_local, K)
         handles = []
@@ -511,9 +655,12 @@ class TorchComm:
         a, b = plan.own[me]
         if b > a:
             libasora.raytrace_fold(a, b - a)
+        if ph: ph.mark("trace_fold_post")
         for h in handles:                                               # chunk order, then rank order: a fixed order of additions
             self._complete(libasora, _capi.GRID_PHI_ION, N, h)
+        if ph: ph.mark("wait_rates_add")
         libasora.chemistry_range(*chemistry, a, b - a, True)
+        if ph: ph.mark("slab_chemistry")
         # xh_av back: the owner q of a run sends it to the rank r that traces through it
         back = plan.__dict__.setdefault("_back_cache", {})
         if me not in back:
@@ -521,7 +668,12 @@ class TorchComm:
                         [(q, s0, s1) for q in range(plan.P) if q != me for s0, s1 in plan.runs[me][q]])
         sends, recvs = back[me]
         self._complete(libasora, _capi.GRID_XH_AV, N, self._post(libasora, _capi.GRID_XH_AV, N, sends, recvs, False, "xh_av"))
-        return self._sum_scalars(libasora)
+        if ph: ph.mark("xh_av_exchange")
+        res = self._sum_scalars(libasora)
+        if ph:
+            ph.mark("scalar_allreduce")
+            ph.close()
+        return res
 
     def slab_gather(self, libasora, plan, which, N):
         """Every rank gets every owner's slab of grid `which` (end of a time step: xh_intermed, phi_ion)."""
@@ -592,9 +744,25 @@ class TorchComm:
         rates are summed, under the remaining trace and all-reduces."""
         from . import _capi
         if not self.overlap or src_i0 is None:
+            if not self.phase_timing:
+                libasora.raytrace_device(R, sig, dr, 0, num_src_local, minlogtau, dlogtau, NumTau)
+                self.allreduce_device_grid(libasora, _capi.GRID_PHI_ION, N)
+                return libasora.chemistry_device(*chemistry) if chemistry is not None else None
+            # the same three calls between wall-clock readings (each of them ends with a host synchronisation anyway)
+            import time
+            t0 = time.perf_counter()
             libasora.raytrace_device(R, sig, dr, 0, num_src_local, minlogtau, dlogtau, NumTau)
+            libasora.synchronize()
+            t1 = time.perf_counter()
             self.allreduce_device_grid(libasora, _capi.GRID_PHI_ION, N)
-            return libasora.chemistry_device(*chemistry) if chemistry is not None else None
+            t2 = time.perf_counter()
+            res = libasora.chemistry_device(*chemistry) if chemistry is not None else None
+            t3 = time.perf_counter()
+            self._phase_add("trace", (t1 - t0) * 1e3)
+            self._phase_add("rate_allreduce", (t2 - t1) * 1e3)
+            self._phase_add("chemistry", (t3 - t2) * 1e3)
+            self._phase_n += 1
+            return res
         import torch
         src_i0 = np.asarray(src_i0)
         if src_i0.size and np.any(np.diff(src_i0) < 0):

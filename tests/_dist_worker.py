@@ -157,11 +157,32 @@ def main():
         comm.Barrier()
         _shutdown()
         return
+    diag = "phases" in spec[1:]
+    if diag:                      # bench.py's diagnostics: where an iteration's time goes, what the links deliver
+        comm.phase_timing = True
+        if "allreduce" in spec[1:]:
+            comm.exchange = "allreduce"
     xh_new, phi = ev.evolve3D_MPI(dt, dr, flux, pos, not cpu_semantics, 1000, 3, 1e-2, use_mpi, the_comm, rank, world,
                                   temp, nd, xh, thin, thick, cases.MINLOGTAU, dlog, R, 1e-4, cases.SIG,
                                   cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C,
                                   logfile=None, quiet=True)
-    np.savez(out, xh=xh_new, phi=phi, niter=ev._evolve.last_niter, nsrc=(fake.flux.shape[0] if fake.flux is not None else -1))
+    extra = {}
+    if diag:
+        import json
+        if comm.exchange == "allreduce":
+            # evolve3D_MPI makes the three calls itself on this path; bench.py goes through raytrace_and_allreduce: two steps of it
+            lib_ = ev.load_asora()
+            NumTau = thin.shape[0]
+            lib_.source_data_to_device(*__import__("pyc2ray_amd.utils.sourceutils", fromlist=["format_sources"]).format_sources(pos, flux), ns)
+            comm.phase_reset()
+            for _ in range(2):
+                comm.raytrace_and_allreduce(lib_, N, R, cases.SIG, dr, ns, cases.MINLOGTAU, dlog, NumTau,
+                                            chemistry=(dt, cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C))
+        extra["phases"] = json.dumps(comm.phase_report())
+        extra["links"] = json.dumps(comm.measure_links(p2p_bytes=1 << 16, allreduce_bytes=1 << 18, reps=2))
+        comm.phase_reset()
+        extra["phases_after_reset"] = json.dumps(comm.phase_report())
+    np.savez(out, xh=xh_new, phi=phi, niter=ev._evolve.last_niter, nsrc=(fake.flux.shape[0] if fake.flux is not None else -1), **extra)
     comm.Barrier()
     _shutdown()
 

@@ -250,6 +250,32 @@ def test_slab_exchange_matches_single_process(tmp_path, world, N, ns, R):
     np.testing.assert_allclose(res[0]["phi"], phi_ref, rtol=1e-10, atol=0)
 
 
+@pytest.mark.parametrize("world,exchange", [(2, "slab"), (3, "slab"), (2, "allreduce")])
+def test_phase_times_and_link_rates_of_a_multi_rank_run(tmp_path, world, exchange):
+    """What bench.py --gpus N prints beside its value: per-phase milliseconds of an iteration -- booked by
+    TorchComm.slab_iteration / raytrace_and_allreduce when `phase_timing` is set, maximum over the ranks -- and the rates a
+    point-to-point ring and an all-reduce reach in this job (TorchComm.measure_links).  Every rank reports the same numbers
+    (they drive `--exchange auto`, which all ranks must decide alike); switching the timers on changes no result."""
+    import json
+    res = _run_workers(tmp_path, world, f"slab:16:5:6.0:phases" + (":allreduce" if exchange == "allreduce" else ""))
+    x_ref, phi_ref, niter_ref, _ = _slab_reference(16, 5, 6.0)
+    for r in res:
+        assert int(r["niter"]) == niter_ref
+        np.testing.assert_allclose(r["xh"], x_ref, rtol=1e-10, atol=0)
+    ph = [json.loads(str(r["phases"])) for r in res]
+    ln = [json.loads(str(r["links"])) for r in res]
+    assert all(q == ph[0] for q in ph[1:]) and all(q == ln[0] for q in ln[1:])
+    want = ({"prepare", "trace_fold_post", "wait_rates_add", "slab_chemistry", "xh_av_exchange", "scalar_allreduce"}
+            if exchange == "slab" else {"trace", "rate_allreduce", "chemistry"})
+    assert set(ph[0]) == want | {"iterations"}
+    assert ph[0]["iterations"] == (niter_ref if exchange == "slab" else 2)
+    assert all(ph[0][k] >= 0.0 for k in want) and sum(ph[0][k] for k in want) > 0.0
+    for key in ("p2p_ms", "p2p_GBs", "allreduce_ms", "allreduce_busbw_GBs"):
+        assert ln[0][key] > 0.0
+    assert ln[0]["ranks"] == world and ln[0]["p2p_bytes"] == 1 << 16 and ln[0]["allreduce_bytes"] == 1 << 18
+    assert json.loads(str(res[0]["phases_after_reset"])) == {"iterations": 0}
+
+
 def test_mpi4py_shaped_communicator_takes_the_host_staged_branch(tmp_path):
     """A communicator that only offers mpi4py's Reduce / Bcast on numpy buffers (what evolve3D_MPI gets from a real
     mpi4py run; mpi4py itself is not installed here): Reduce to rank 0 + Bcast of the rate grid, Bcast of the

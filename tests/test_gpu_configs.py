@@ -383,6 +383,109 @@ def test_config4_512_all_1e5_sources_evolve_loop_and_reference_subset(asora, ben
     p.device_close()
 
 
+# ---- meshes beyond the buffer descriptors' range -----------------------------------------------------------------------
+def test_mesh_576_global_atomic_family_at_real_size(asora):
+    """N > 512: [phi | phi_t] no longer fits the 2 GiB a raw buffer descriptor spans, so the rates go through
+    global_atomic_add_f64 with one 32-bit cell index over both layouts (2 x 576^3 = 3.8e8 < 2^32) formed by two 24-bit
+    multiply-adds (raytrace.hip, nhi_address), and neither the paired-sources variant nor the line-aligned tables exist.
+    Until round 4 that family only ran at N <= 96 behind an option switch; the reference works up to
+    N = 645 (src/asora/raytracing.cu:95).  Here at N = 576 (1.5 GB grids, the [k][j][i] twins end 3.06e9 bytes in):
+    a corner source whose sphere wraps onto all eight corners against the oracle, superposition of five sources, exact pair
+    counts, and one iteration of the device-resident loop (fused pass on 1.5 GB grids, both accumulator pairs) against
+    raytrace_device + chemistry_device called separately."""
+    p, lib, capi = asora
+    N, R = 576, 20.0
+    thin, thick, dlog = cases.soft_tables(20000)
+    rng = np.random.default_rng(576)
+    nd = 1e-3 * np.exp(0.8 * rng.standard_normal((N, N, N), dtype=np.float32).astype(np.float64) - 0.32)
+    xh = np.full((N, N, N), 2e-4)
+    temp = np.full((N, N, N), 1e4)
+    dr = 0.03 / (cases.SIG * 1e-3)
+    pos = np.array([[576, 576, 576], [1, 1, 1], [288, 300, 17], [576, 400, 1], [530, 576, 575]]).T
+    flux = np.array([1.0e3, 2.0e3, 3.0e3, 1.5e3, 0.5e3])
+    NS = flux.shape[0]
+    _fresh(p, N)
+    p.photo_table_to_device(thin, thick)
+    p0, f0 = cases.flat_sources(pos, flux)
+    lib.grid_to_device(capi.GRID_NDENS, nd)
+    lib.grid_to_device(capi.GRID_XH_AV, xh)
+    numtau = thin.shape[0] - 1
+
+    def trace(sel):
+        q0, g0 = cases.flat_sources(pos[:, sel], flux[sel])
+        lib.source_data_to_device(q0, g0, g0.shape[0])
+        lib.raytrace_device(R, cases.SIG, dr, 0, g0.shape[0], cases.MINLOGTAU, dlog, numtau)
+        return lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+
+    full = trace(np.arange(NS))
+    gam, ev = lib.last_raytrace_counts()
+    assert gam == NS * _lattice_points_within(R) and ev >= gam
+    assert np.isfinite(full).all() and (full >= 0).all()
+    assert full[N - 1, N - 1, N - 1] > 0 and full[0, 0, 0] > 0        # the largest index of both layouts is a source cell
+    one = trace(np.array([0]))
+    ref = O.asora_do_all_sources(R, cases.SIG, dr, nd, xh, p0[:3], f0[:1], thin, thick, cases.MINLOGTAU, dlog,
+                                 NumTau=numtau, flags=O.ASORA_MODE)["phi_ion"]
+    w = ref != 0
+    assert np.array_equal(one != 0, w) and int(w.sum()) == _lattice_points_within(R)
+    np.testing.assert_allclose(one[w], ref[w], rtol=1e-8, atol=0)
+    for corner in [(0, 0, 0), (N - 1, 0, 0), (0, N - 1, N - 1), (N - 1, N - 1, N - 1), (N - 12, 5, N - 8)]:
+        assert one[corner] > 0
+    del ref, w
+    acc = one
+    for s in range(1, NS):
+        acc += trace(np.array([s]))
+    np.testing.assert_allclose(acc, full, rtol=1e-11, atol=0)
+    del acc, one, full
+
+    # many sources: the launch shapes of a full chip (whole spheres x 512 threads at this radius; one source per workgroup,
+    # dense tables) against the oracle on the host
+    NM = 600
+    mpos = 1 + rng.integers(0, N, size=(3, NM))
+    mflux = rng.uniform(0.5e3, 2.0e3, size=NM)
+    m0, mf0 = cases.flat_sources(mpos, mflux)
+    lib.source_data_to_device(m0, mf0, NM)
+    lib.raytrace_device(R, cases.SIG, dr, 0, NM, cases.MINLOGTAU, dlog, numtau)
+    many = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+    gam, ev = lib.last_raytrace_counts()
+    assert gam == NM * _lattice_points_within(R)
+    ref = O.asora_do_all_sources(R, cases.SIG, dr, nd, xh, m0, mf0, thin, thick, cases.MINLOGTAU, dlog,
+                                 NumTau=numtau, flags=O.ASORA_MODE)["phi_ion"]
+    w = ref != 0
+    assert np.array_equal(many != 0, w)
+    np.testing.assert_allclose(many[w], ref[w], rtol=1e-8, atol=0)
+    del many, ref, w
+
+    # one iteration of the device-resident loop against the separate calls
+    lib.source_data_to_device(p0, f0, NS)
+    lib.grid_to_device(capi.GRID_TEMP, temp)
+    lib.grid_to_device(capi.GRID_XH, xh)
+    chem = (3.15576e13, cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C)
+    lib.grid_copy(capi.GRID_XH_AV, capi.GRID_XH)
+    lib.grid_copy(capi.GRID_XH_INTERMED, capi.GRID_XH)
+    sep = []
+    for it in range(2):
+        lib.raytrace_device(R, cases.SIG, dr, 0, NS, cases.MINLOGTAU, dlog, numtau)
+        sep.append(lib.chemistry_device(*chem))
+    x_sep = lib.grid_to_host(capi.GRID_XH_INTERMED, np.empty((N, N, N)))
+    phi_sep = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+    assert np.isfinite(x_sep).all() and x_sep.max() > 10 * 2e-4          # the sources ionise their surroundings
+    lib.evolve_begin(*chem, R, cases.SIG, dr, cases.MINLOGTAU, dlog, numtau, 0, NS, -1.0, 1e-4)
+    lib.evolve_enqueue(2)
+    n_done, done, rows = lib.evolve_poll()
+    assert n_done == 2 and len(rows) == 2
+    for it in range(2):
+        assert int(rows[it][0]) == sep[it][0]
+        np.testing.assert_allclose(rows[it][1:3], sep[it][1:3], rtol=1e-12)
+    x_fused = lib.grid_to_host(capi.GRID_XH_INTERMED, np.empty((N, N, N)))
+    np.testing.assert_allclose(x_fused, x_sep, rtol=1e-10, atol=0)
+    del x_fused, x_sep
+    phi_fused = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+    w = phi_sep != 0
+    assert np.array_equal(phi_fused != 0, w)
+    np.testing.assert_allclose(phi_fused[w], phi_sep[w], rtol=1e-10, atol=0)
+    p.device_close()
+
+
 # ---- a-7 at the benchmark's size ----------------------------------------------------------------------------------------
 def test_c2ray_do_all_sources_256_uniform_1000_sources_against_reference_fortran(asora, bench_tables):
     """libc2ray.raytracing.do_all_sources -- the reference's CPU function, evaluated by the sub-box kernels -- on the

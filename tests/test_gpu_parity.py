@@ -827,6 +827,56 @@ def test_beyond_the_last_table_entry_rates_are_exactly_zero(asora):
     assert not (phi_f < 0).any() and np.array_equal(phi_f == 0, ref_f == 0)
 
 
+def test_infinite_optical_depth_reads_the_last_table_entry(asora):
+    """A cell so dense that its outgoing optical depth overflows to +inf: the reference's log10(inf) = inf is clamped to the
+    LAST table entry (min(NumTau, .), rates.cu:79 / photorates.f90:141).  The kernel's logarithm is built from the mantissa
+    and exponent of its argument, which is only defined for finite values: the argument is clamped on both sides
+    (rates_device.hpp).  Both sets of constants, every kind of unit, one and two sources per workgroup."""
+    p, lib, capi = asora
+    N = 16
+    thin, thick, dlog = cases.soft_tables(400)
+    nd = np.full((N, N, N), 1e-15)
+    xh = np.full((N, N, N), 0.1)
+    # (walls on the last shells inside the sphere: every cell that would read one lies beyond the radius.  A cell BEHIND such
+    #  a wall is outside what either code is made for -- the reference's weight s/max(0.6, inf) is 0 there, the kernel's
+    #  multiplied-through form of the same quotient has inf/inf -- and is not part of this test.)
+    walls = [(8, 8, 14), (2, 8, 8), (8, 14, 8), (10, 3, 6)]
+    for w in walls:
+        nd[w] = 1e300                      # column density 1e300 x sigma 1e10 = +inf
+    pos = np.array([[9, 9], [9, 9], [9, 9]])
+    flux = np.array([2.0, 3.0])
+    p0, f0 = cases.flat_sources(pos, flux)
+    sig, dr, R = 1e10, 1.0, 6.0
+    numtau = thin.shape[0]
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 8)
+    p.photo_table_to_device(thin, thick)
+    lib.source_data_to_device(p0, f0, 2)
+    lib.grid_to_device(capi.GRID_NDENS, nd)
+    lib.grid_to_device(capi.GRID_XH_AV, xh)
+    try:
+        for fortran in (0, 1):
+            flags = O.PER_SOURCE_FLUX if fortran else O.ASORA_MODE
+            ref = O.asora_do_all_sources(R, sig, dr, nd, xh, p0, f0, thin, thick, cases.MINLOGTAU, dlog, NumTau=numtau,
+                                         flags=flags)["phi_ion"]
+            assert np.isfinite(ref).all() and all(ref[w] > 0 for w in walls)
+            lib.set_option(capi.OPT_FORTRAN_CONSTANTS, fortran)
+            for mode, pairs in ((0, 0), (1, 1), (3, 1), (6, 1), (6, 2), (9, 2)):
+                lib.set_option(capi.OPT_SECTORS, mode)
+                lib.set_option(capi.OPT_PAIR_SOURCES, pairs)
+                lib.raytrace_device(R, sig, dr, 0, 2, cases.MINLOGTAU, dlog, numtau)
+                phi = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+                assert np.isfinite(phi).all(), (fortran, mode, pairs)
+                assert np.array_equal(phi != 0, ref != 0), (fortran, mode, pairs, np.argwhere((phi != 0) != (ref != 0))[:8].tolist())
+                np.testing.assert_allclose(phi, ref, rtol=GAMMA_RTOL, atol=0, err_msg=str((fortran, mode, pairs)))
+    finally:
+        lib.set_option(capi.OPT_FORTRAN_CONSTANTS, 0)
+        lib.set_option(capi.OPT_SECTORS, 0)
+        lib.set_option(capi.OPT_PAIR_SOURCES, 0)
+    p.device_close()
+
+
 def test_fully_ionised_and_empty_cells_behave_like_the_reference(asora):
     """Cells with nHI = 0 (x = 1 exactly, or no gas): the reference divides the cell's rate by nHI unguarded
     (raytracing.cu:324, raytracing.f90:531), so such a cell ends up with NaN while the column density passes through

@@ -1,6 +1,6 @@
 """When does the library build the eight-fold (line-aligned) geometry tables?  Run with ASORA_GEOM_TIMING=1: every build prints its
 size to stderr.  Expected: aligned for the first radius, dense right after a change of radius, aligned again once a radius has
-served 32 launches (launch_raytrace, ASORA_OPT_ALIGNED_ROWS = 0).  usage (GPU box): ASORA_GEOM_TIMING=1 python tools/check_aligned_heuristic.py"""
+served 32 CALLS (note_call_radius: one per raytrace call or evolve time step; ASORA_OPT_ALIGNED_ROWS = 0).  usage (GPU box): ASORA_GEOM_TIMING=1 python tools/check_aligned_heuristic.py"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,7 +25,7 @@ def run(R, n):
         lib.raytrace_device(R, bench.SIG, dr, 0, ns, bench.MINLOGTAU, dlog, thin.shape[0] - 1)
     lib.synchronize()
 print("first radius 30", file=sys.stderr); run(30.0, 3)
-print("radius 31 (changed): 10 launches", file=sys.stderr); run(31.0, 10)
-print("radius 32 (changed): 40 launches", file=sys.stderr); run(32.0, 40)
+print("radius 31 (changed): 10 calls", file=sys.stderr); run(31.0, 10)
+print("radius 32 (changed): 40 calls", file=sys.stderr); run(32.0, 40)
 print("done", file=sys.stderr)
 p.device_close()

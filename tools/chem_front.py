@@ -37,31 +37,7 @@ N = a.N
 CHEM = (bench.MYR, bench.BH00, bench.ALBPOW, bench.COLH0, bench.TEMPH0, bench.ABU_C)
 
 
-def trip_counts(dt, n, T, x0, xav, gamma, bh00, albpow, colh0, temph0, abu_c):
-    """do_chemistry's trip count per cell (chemistry.f90:146-203 with doric :279-311), vectorised."""
-    brech0 = bh00 * (T / 1e4) ** albpow
-    acolh0 = colh0 * np.sqrt(T) * np.exp(-temph0 / T)
-    nit = np.zeros(n.shape, dtype=np.int32)
-    live = np.ones(n.shape, dtype=bool)
-    xav = xav.copy()
-    for it in range(1, 402):
-        idx = np.flatnonzero(live)
-        if idx.size == 0:
-            break
-        nn, xa, g = n.flat[idx], xav.flat[idx], gamma.flat[idx]
-        de = nn * (xa + abu_c)
-        aih0 = g + de * acolh0.flat[idx]
-        delth = aih0 + de * brech0.flat[idx]
-        eqxh = aih0 / delth
-        deltht = delth * dt
-        ee = np.exp(-deltht)
-        avg = np.where(deltht < 1.0e-8, 1.0, (1.0 - ee) / np.where(deltht == 0, 1.0, deltht))
-        new = np.maximum(eqxh + (x0.flat[idx] - eqxh) * avg, 1e-14)
-        nit.flat[idx] = it
-        done = (np.abs((new - xa) / (1.0 - new)) < 1.0e-3) | (1.0 - new < 1.0e-8) | (it > 400)
-        xav.flat[idx] = new
-        live.flat[idx[done]] = False
-    return nit
+trip_counts = bench.trip_counts       # do_chemistry's trip count per cell, vectorised on the host
 
 
 def one_time_step(lib, dr, dlog, numtau, nsrc, conv_fraction=1e-4, histogram=False):
