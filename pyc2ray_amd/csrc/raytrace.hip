@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
 {
     extern __shared__ double lds_raw[];
     static_assert(NSRC == 1 || (ASORA_LATE_LOOKUP && !GLOBAL_SCRATCH && !DUMP && BUFATOM), "paired sources: production variant only");
-    static_assert(!SUBBOX || (NSRC == 1 && ASORA_LATE_LOOKUP && !GLOBAL_SCRATCH && !DUMP && !SKIP_ZERO && !GREY), "sub-box sweep: table rates, shells in LDS");
+    static_assert(!SUBBOX || (ASORA_LATE_LOOKUP && !GLOBAL_SCRATCH && !DUMP && !SKIP_ZERO && !GREY), "sub-box sweep: table rates, shells in LDS");
 
     if (p.done_flag && *p.done_flag) return;   // evolve loop: an iteration enqueued beyond convergence does nothing
     const int blk = blockIdx.x;
@@ -276,7 +276,6 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     const int face_type = ((uinfo >> 8) & 3) == 3 ? 1 : 0;          // 1: z-sector (rows along i), 0: x- / y-sector (rows along k)
     const bool listed = by_class && NSRC == 2;
     if (listed ? src_local >= p.npairs[face_type] : src_local * NSRC >= p.src_count) return;
-    if (SUBBOX) { if (!p.sb_active[src_local]) return; }            // this source stopped growing after an earlier box
 
     const int N = p.N;
     int i0[NSRC], j0[NSRC], k0[NSRC];
@@ -294,6 +293,9 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
         } else {
             have[q] = src_local * NSRC + q < p.src_count;
             ns = p.src_begin + (have[q] ? src_local * NSRC + q : src_local * NSRC);
+            // SUBBOX: a source that stopped growing after an earlier box is swept along with its partner, its rates and its
+            // photon loss dropped like those of the copy that fills an odd count; a workgroup without a live source ends here
+            if (SUBBOX) have[q] = have[q] && p.sb_active[src_local * NSRC + q] != 0;
         }
         i0[q] = p.src_pos[3 * ns + 0];
         j0[q] = p.src_pos[3 * ns + 1];
@@ -301,6 +303,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
         flux[q] = p.src_flux[(SUBBOX && p.flux_src >= 0) ? p.flux_src : ns];
         nreal += have[q] ? 1u : 0u;
     }
+    if (SUBBOX && nreal == 0) return;
     const int table = by_class ? unit + p.units * ((face_type ? i0[0] : k0[0]) & 7) : unit;
     const uint4 *__restrict__ cellA = p.geom[table].cellA;
     const uint4 *__restrict__ cellB = p.geom[table].cellB;
@@ -379,9 +382,13 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
 
     // ---- SUBBOX, a later box of the source: continue from the trailing shell of the box before ------------
     const bool continues = SUBBOX && !p.sb_first;
-    double *trail = SUBBOX ? p.sb_trail + ((size_t)src_local * p.units + unit) * (size_t)slots : nullptr;
+    // (one trailing shell per source of the batch and unit)
+    double *trail = SUBBOX ? p.sb_trail + ((size_t)src_local * NSRC * p.units + unit) * (size_t)slots : nullptr;
+    const size_t trail_stride = (size_t)p.units * (size_t)slots;          // from a source's shell to its partner's
     if (continues) {
-        for (int t = threadIdx.x; t < p.max_cells; t += RT_THREADS) prev[t] = trail[t];
+#pragma unroll
+        for (int q = 0; q < NSRC; ++q)
+            if (have[q]) for (int t = threadIdx.x; t < p.max_cells; t += RT_THREADS) prev[q * src_stride + t] = trail[q * trail_stride + t];
     }
     // ---- shell 0: the source cell (raytracing.cu:285-294) -----------------------------------
     if (threadIdx.x == 0 && !continues) {
@@ -461,9 +468,11 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
 
     // SUBBOX: photons through the faces of the current sub-box (f90:541-543), per lane; the faces on the unit's own side
     // and on the mirrored side of each axis
-    double loss = 0.0;
-    bool pend_edge = false, cur_edge = false;
-    double pend_pv = 0.0;                 // flux / volume of the pending cell (pref without the division by nHI)
+    double loss[NSRC];
+    bool pend_edge = false, cur_edge = false;     // (geometry only: the same for every source of the workgroup)
+    double pend_pv[NSRC];                 // flux / volume of the pending cell (pref without the division by nHI)
+#pragma unroll
+    for (int q = 0; q < NSRC; ++q) { loss[q] = 0.0; pend_pv[q] = 0.0; }
     const int edge_own[3] = {sa > 0 ? p.sb_edge_r : p.sb_edge_l, sb > 0 ? p.sb_edge_r : p.sb_edge_l, sc > 0 ? p.sb_edge_r : p.sb_edge_l};
     const int edge_mir[3] = {sa > 0 ? p.sb_edge_l : p.sb_edge_r, sb > 0 ? p.sb_edge_l : p.sb_edge_r, sc > 0 ? p.sb_edge_l : p.sb_edge_r};
 
@@ -537,6 +546,9 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
         n_eval += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid)) * nreal;
 
         // ---- per source: the medium-dependent arithmetic ----------------------------------------------------------------
+        // (round 4: loading the corner values of EVERY source before the first source's shell-buffer store -- the compiler
+        //  cannot know that the store does not feed the other source's loads, so it orders them behind it -- was measured:
+        //  0 at R = 16 ... 32, -1 % at R = 48, and 130 instead of 128 VGPRs, i.e. three waves per SIMD instead of four: not kept)
 #pragma unroll
         for (int q = 0; q < NSRC; ++q) {
             const double *pq = prev + q * src_stride;
@@ -692,23 +704,29 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
                 }
                 if (SUBBOX) {
                     // what leaves the PREVIOUS step's cell through the far side, if that cell lies on a face of the box
-                    const bool lost = (BUFATOM ? late_off[0] != ASORA_OOB_OFFSET : late_ok[0]) && pend_edge;
-                    if (__builtin_amdgcn_ballot_w64(lost) != 0ull) {
-                        const double ta = lookup_value(pend_A[0]), tb = lookup_value(pend_B[0]);
-                        const double po = pend_thick[0] ? pend_pv * tb : pend_pv * (tb - pend_dtau[0] * ta);
-                        if (lost) loss += po;
+                    if (__builtin_amdgcn_ballot_w64(pend_edge) != 0ull) {
+#pragma unroll
+                        for (int q = 0; q < NSRC; ++q) {
+                            const bool lost = (BUFATOM ? late_off[q] != ASORA_OOB_OFFSET : late_ok[q]) && pend_edge;
+                            const double ta = lookup_value(pend_A[q]), tb = lookup_value(pend_B[q]);
+                            const double po = pend_thick[q] ? pend_pv[q] * tb : pend_pv[q] * (tb - pend_dtau[q] * ta);
+                            if (lost) loss[q] += po;
+                        }
                     }
                     // flux / volume of this step's cell, should it lie on a face: pref * nHI, or the quotient itself where
                     // nHI = 0 (pref = inf)
                     if (__builtin_amdgcn_ballot_w64(cur_edge) != 0ull) {
-                        double pv = pref[0] * cur_nhi[0];
-                        if (__builtin_amdgcn_ballot_w64(cur_nhi[0] == 0.0) != 0ull) {
-                            const double n2s = (double)((cur_A.x & 1023) * (cur_A.x & 1023) + ((cur_A.x >> 10) & 1023) * ((cur_A.x >> 10) & 1023) +
-                                                        ((cur_A.x >> 20) & 1023) * ((cur_A.x >> 20) & 1023));
-                            const double vol = n2s * (dr * dr * FOURPI) * (__hiloint2double((int)cur_A.w, (int)cur_A.z) * dr);
-                            if (cur_nhi[0] == 0.0) pv = flux[0] / vol;
+#pragma unroll
+                        for (int q = 0; q < NSRC; ++q) {
+                            double pv = pref[q] * cur_nhi[q];
+                            if (__builtin_amdgcn_ballot_w64(cur_nhi[q] == 0.0) != 0ull) {
+                                const double n2s = (double)((cur_A.x & 1023) * (cur_A.x & 1023) + ((cur_A.x >> 10) & 1023) * ((cur_A.x >> 10) & 1023) +
+                                                            ((cur_A.x >> 20) & 1023) * ((cur_A.x >> 20) & 1023));
+                                const double vol = n2s * (dr * dr * FOURPI) * (__hiloint2double((int)cur_A.w, (int)cur_A.z) * dr);
+                                if (cur_nhi[q] == 0.0) pv = flux[q] / vol;
+                            }
+                            pend_pv[q] = pv;
                         }
-                        pend_pv = pv;
                     }
                     pend_edge = cur_edge;
                 }
@@ -835,17 +853,22 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     }
 
     if (SUBBOX) {
-        // the pending cell of the last step
-        {
-            const double ta = lookup_value(pend_A[0]), tb = lookup_value(pend_B[0]);
-            const double po = pend_thick[0] ? pend_pv * tb : pend_pv * (tb - pend_dtau[0] * ta);
-            if ((BUFATOM ? late_off[0] != ASORA_OOB_OFFSET : late_ok[0]) && pend_edge) loss += po;
+#pragma unroll
+        for (int q = 0; q < NSRC; ++q) {
+            // the pending cell of the last step
+            {
+                const double ta = lookup_value(pend_A[q]), tb = lookup_value(pend_B[q]);
+                const double po = pend_thick[q] ? pend_pv[q] * tb : pend_pv[q] * (tb - pend_dtau[q] * ta);
+                if ((BUFATOM ? late_off[q] != ASORA_OOB_OFFSET : late_ok[q]) && pend_edge) loss[q] += po;
+            }
+            if (!have[q]) continue;
+            // hand the last shell swept to the next sub-box's launch (the step that closed it ended with the barrier and the
+            // swap: it is `prev`, complete)
+            for (int t = threadIdx.x; t < p.max_cells; t += RT_THREADS) trail[q * trail_stride + t] = prev[q * src_stride + t];
+            double l = loss[q];
+            for (int o = 32; o > 0; o >>= 1) l += __shfl_down(l, o);
+            if ((threadIdx.x & 63) == 0 && l != 0.0) unsafeAtomicAdd(p.sb_loss + src_local * NSRC + q, l * (dr * dr * dr));
         }
-        // hand the last shell swept to the next sub-box's launch (the step that closed it ended with the barrier and the
-        // swap: it is `prev`, complete)
-        for (int t = threadIdx.x; t < p.max_cells; t += RT_THREADS) trail[t] = prev[t];
-        for (int o = 32; o > 0; o >>= 1) loss += __shfl_down(loss, o);
-        if ((threadIdx.x & 63) == 0 && loss != 0.0) unsafeAtomicAdd(p.sb_loss + src_local, loss * (dr * dr * dr));
     }
 
     // work accounting: one atomic per wave and counter
@@ -2056,12 +2079,12 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
 // that are rated or add to the photon loss; a source whose column densities go back to the caller needs the whole cube and
 // stays with the on-the-fly kernel of subbox.hip.
 // ---------------------------------------------------------------------------------------------
-template <int T, bool HT>
+template <int T, bool HT, int NS = 1>
 static int launch_subbox_tables_variant(const RtParams &q, unsigned grid, size_t lds_bytes, hipStream_t stream)
 {
-    ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, HT, 256, false, false, true, 1, true>,
+    ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, HT, 256, false, false, true, NS, true>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, HT, 256, false, false, true, 1, true>), dim3(grid), dim3(T), lds_bytes,
+    hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, HT, 256, false, false, true, NS, true>), dim3(grid), dim3(T), lds_bytes,
                        stream, q);
     ASORA_HIP_TRY(hipGetLastError());
     return 0;
@@ -2109,6 +2132,15 @@ int subbox_tables_prepare(State &st, RtParams &p, int ext_r, int ext_l, int subb
     }
     p.sb_trail = st.sb_trail;
     out.units = units; out.threads = threads; out.S = p.S; out.max_batch = max_batch; out.ok = true;
+    // two sources per workgroup (the kernel's NSRC = 2, round 4): as for the ASORA sweep -- table entry decoded once, tables
+    // streamed once, two dependency chains per wave -- where four shell buffers fit and enough workgroups remain; not with
+    // heating (two more lookups per source in flight)
+    {
+        const int want = st.opt[ASORA_OPT_PAIR_SOURCES];
+        const bool possible = !heat && src_count >= 2 && 4 * slots * sizeof(double) + lds_table_bytes(256, 2) <= LDS_LIMIT_BYTES;
+        const bool pays = r >= 15.5 && (long)(src_count / 2) * units * (threads / 64) >= 8L * st.cu_count;
+        out.nsrc = (possible && (want == 2 || (want == 0 && pays))) ? 2 : 1;
+    }
     return 0;
 }
 
@@ -2127,11 +2159,14 @@ int subbox_tables_sweep(State &st, const RtParams &p, const SubboxTables &tab, i
     if (!any) return 0;                       // the box lies beyond the radius: nothing is rated, nothing is lost
     q.sb_first = s_begin == 0 ? 1 : 0;
     const size_t slots = ((size_t)p.max_cells + 2) & ~(size_t)1;
-    const size_t lds_bytes = 2 * slots * sizeof(double) + lds_table_bytes(256);
-    const int groups = q.src_count;
+    const bool pairs = tab.nsrc == 2 && !heat;
+    const size_t lds_bytes = (pairs ? 4 : 2) * slots * sizeof(double) + lds_table_bytes(256, pairs ? 2 : 1);
+    const int groups = pairs ? (q.src_count + 1) / 2 : q.src_count;
     q.spread = (long)groups * tab.units <= 2L * st.cu_count ? 1 : 0;
     const unsigned grid = q.spread ? (unsigned)tab.units * (unsigned)groups : 8u * (unsigned)tab.units * (unsigned)((groups + 7) / 8);
     KernelTimer kt(ASORA_KERNEL_RAYTRACE);
+    if (pairs) return tab.threads == 512 ? launch_subbox_tables_variant<512, false, 2>(q, grid, lds_bytes, st.stream)
+                                         : launch_subbox_tables_variant<256, false, 2>(q, grid, lds_bytes, st.stream);
     if (tab.threads == 512) return heat ? launch_subbox_tables_variant<512, true>(q, grid, lds_bytes, st.stream)
                                         : launch_subbox_tables_variant<512, false>(q, grid, lds_bytes, st.stream);
     return heat ? launch_subbox_tables_variant<256, true>(q, grid, lds_bytes, st.stream)

@@ -1289,6 +1289,40 @@ def test_cells_on_the_sphere_follow_dr_without_a_rebuild(asora):
     p.device_close()
 
 
+def test_column_density_dump_of_cells_on_the_sphere_follows_dr(asora):
+    """asora_debug_coldens writes the outgoing column density of the cells that receive a rate.  A lattice point exactly ON
+    the sphere (R = 9: (1,4,8), (4,4,7), (3,6,6), (0,0,9) ...) is always tabulated and evaluated, but whether it is RATED -- and
+    so whether it appears in the dump -- is the reference's floating-point distance test, which depends on dr; the tables are
+    patched in place when dr changes (the dump must follow the patched RATE bit, not the evaluation)."""
+    p, lib, capi = asora
+    N, R = 32, 9.0
+    thin, thick, dlog = cases.soft_tables(400)
+    nd, xh, dr0 = cases.grid(N, "lognormal", 31, 0.05, xlo=1e-4, xhi=1e-2)
+    pos = np.array([[16, 3], [16, 30], [16, 16]])
+    flux = np.array([2.0, 1.0])
+    p0, f0 = cases.flat_sources(pos, flux)
+    numtau = thin.shape[0]
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 8)
+    p.photo_table_to_device(thin, thick)
+    lib.source_data_to_device(p0, f0, 2)
+    lib.grid_to_device(capi.GRID_NDENS, nd)
+    lib.grid_to_device(capi.GRID_XH_AV, xh)
+    patterns = set()
+    for dr in (dr0, dr0 * 1.37, dr0 * 0.731, dr0 * 3.3e-7, dr0):
+        for src in (0, 1):
+            cd = lib.debug_coldens(R, cases.SIG, dr, src, N)
+            one = O.asora_do_all_sources(R, cases.SIG, dr, nd, xh, p0[3 * src:3 * src + 3], f0[src:src + 1], thin, thick,
+                                         cases.MINLOGTAU, dlog, NumTau=numtau, flags=O.ASORA_MODE, want_coldens=True)
+            w = one["phi_ion"] != 0
+            assert np.array_equal(cd != 0, w), (dr, src, np.argwhere((cd != 0) != w)[:8].tolist())
+            np.testing.assert_allclose(cd[w], one["coldens"][w], rtol=1e-12)
+            patterns.add((src, int(w.sum())))
+    assert len(patterns) > 2          # the set of rated cells did change with dr
+    p.device_close()
+
+
 def test_two_sources_per_workgroup_give_the_same_rates(asora):
     """ASORA_OPT_PAIR_SOURCES: one workgroup sweeps its unit for two consecutive sources at once.  Sources whose spheres do
     not overlap (no summation-order freedom) -> grids IDENTICAL to the one-source-per-workgroup kernel, for every

@@ -391,9 +391,13 @@ def test_tabulated_sweep_randomised_against_oracle_and_on_the_fly_kernel(libs):
         zeros = np.zeros(thin.shape[0])
         _fresh(p, N)
         out = {}
-        for tables in (1, 2):
+        # 1: the on-the-fly kernel; 2: the tabulated sweep, one source per workgroup; 3: the tabulated sweep with TWO sources
+        # per workgroup (round 4; sources that stop growing after different numbers of boxes share workgroups, odd counts
+        # leave one alone; with heating the library keeps one source per workgroup)
+        for variant in (1, 2, 3):
             phi = np.zeros((N, N, N), order="F"); heat = np.zeros((N, N, N), order="F"); cd = np.zeros((N, N, N), order="F")
-            asora.set_option(capi.OPT_SUBBOX_TABLES, tables)
+            asora.set_option(capi.OPT_SUBBOX_TABLES, min(variant, 2))
+            asora.set_option(capi.OPT_PAIR_SOURCES, 2 if variant == 3 else 1)
             asora.set_option(capi.OPT_C2RAY_OWN_FLUX, 1 if own_flux else 0)
             try:
                 nbox, loss = c2ray.raytracing.do_all_sources(flux, pos, max_subbox, subboxsize, cd, cases.SIG, dr, nd, xh, phi, heat,
@@ -401,9 +405,16 @@ def test_tabulated_sweep_randomised_against_oracle_and_on_the_fly_kernel(libs):
                                                              cases.MINLOGTAU, dlog, R)
             finally:
                 asora.set_option(capi.OPT_SUBBOX_TABLES, 0)
+                asora.set_option(capi.OPT_PAIR_SOURCES, 0)
                 asora.set_option(capi.OPT_C2RAY_OWN_FLUX, 0)
-            out[tables] = (phi, heat, cd, nbox, loss)
+            out[variant] = (phi, heat, cd, nbox, loss)
         tag = f"trial {trial}: N={N} ns={ns} max_subbox={max_subbox} subboxsize={subboxsize} lf={lf} tau={tau_cell:.3g} R={R} heat={use_heat}"
+        phi3, heat3, cd3, nbox3, loss3 = out[3]
+        assert nbox3 == out[2][3], tag
+        np.testing.assert_allclose(loss3, out[2][4], rtol=1e-12, err_msg=tag)
+        assert np.array_equal(cd3, out[2][2]), tag
+        _close(phi3, out[2][0], 1e-12)                              # (same arithmetic per source; sums in another order)
+        _close(heat3, out[2][1], 1e-12)
         (phi1, heat1, cd1, nbox1, loss1), (phi2, heat2, cd2, nbox2, loss2) = out[1], out[2]
         assert nbox1 == nbox2, tag
         np.testing.assert_allclose(loss2, loss1, rtol=RATE_RTOL, err_msg=tag)
@@ -446,6 +457,25 @@ def test_tabulated_sweep_in_several_batches(libs, monkeypatch):
         finally:
             asora.set_option(capi.OPT_SUBBOX_TABLES, 0)
             monkeypatch.delenv("ASORA_SUBBOX_TRAIL_BUDGET", raising=False)
+    # the same without heating and with two sources per workgroup, whole and in batches of five (odd: a source sweeps alone)
+    c_noheat = dict(c, heat_thin=np.zeros_like(thin), heat_thick=np.zeros_like(thick))
+    paired = []
+    for pairs, budget in ((1, None), (2, None), (2, "60000")):
+        if budget:
+            monkeypatch.setenv("ASORA_SUBBOX_TRAIL_BUDGET", budget)
+        asora.set_option(capi.OPT_SUBBOX_TABLES, 2)
+        asora.set_option(capi.OPT_PAIR_SOURCES, pairs)
+        try:
+            paired.append(_call(c2ray, c_noheat, 1000, 3, 2e-2, 7.0))
+        finally:
+            asora.set_option(capi.OPT_SUBBOX_TABLES, 0)
+            asora.set_option(capi.OPT_PAIR_SOURCES, 0)
+            monkeypatch.delenv("ASORA_SUBBOX_TRAIL_BUDGET", raising=False)
+    for phi_p, _, cd_p, nbox_p, loss_p in paired[1:]:
+        assert nbox_p == paired[0][3] and np.array_equal(cd_p, paired[0][2])
+        np.testing.assert_allclose(loss_p, paired[0][4], rtol=1e-12)
+        _close(phi_p, paired[0][0], 1e-12)
+    _close(paired[0][0], out[0][0], 1e-12)          # (the rates do not depend on the heating tables)
     (phi0, heat0, cd0, nbox0, loss0), (phi1, heat1, cd1, nbox1, loss1) = out
     assert nbox0 == nbox1 and nbox0 > 23
     np.testing.assert_allclose(loss1, loss0, rtol=1e-12)

@@ -26,6 +26,7 @@ ap.add_argument("--loss-fraction", type=float, default=1e-2)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--global-shells", type=int, default=0, help="1: ASORA_OPT_SUBBOX_GLOBAL_SHELLS (shell buffers in global memory)")
 ap.add_argument("--tables", type=int, default=0, help="ASORA_OPT_SUBBOX_TABLES: 0 auto, 1 on-the-fly geometry only (round 2), 2 tabulated whenever possible")
+ap.add_argument("--pair-sources", type=int, default=0, help="ASORA_OPT_PAIR_SOURCES for the tabulated sweep: 0 auto, 1 never, 2 always")
 a = ap.parse_args()
 
 N, ns = a.N, a.nsrc
@@ -38,6 +39,7 @@ zeros = np.zeros(thin.shape[0])
 
 asora.set_option(9, a.global_shells)      # ASORA_OPT_SUBBOX_GLOBAL_SHELLS
 asora.set_option(14, a.tables)            # ASORA_OPT_SUBBOX_TABLES
+asora.set_option(13, a.pair_sources)      # ASORA_OPT_PAIR_SOURCES
 for R in a.R:
     sub = int(R)
     phi = np.zeros((N, N, N), order="F")
@@ -66,7 +68,7 @@ for R in a.R:
                                      "achieved_GBs": algo_bytes / (k_ms / a.reps * 1e-3) / 1e9, "peak_GBs": 8000.0,
                                      "frac": algo_bytes / (k_ms / a.reps * 1e-3) / 1e9 / 8000.0}, "shell_buffers": "global memory" if a.global_shells else "LDS when they fit",
            "geometry": {0: "auto", 1: "on the fly (subbox.hip)", 2: "tabulated (raytrace.hip SUBBOX) + on the fly for the dumped source"}[a.tables],
-           "sources": ns, "R": R, "subboxsize": sub, "loss_fraction": a.loss_fraction, "s_per_call": t_gpu,
+           "pair_sources_option": a.pair_sources, "sources": ns, "R": R, "subboxsize": sub, "loss_fraction": a.loss_fraction, "s_per_call": t_gpu,
            "sweep_kernels_ms_per_call": k_ms / a.reps, "sweep_launches_per_call": k_n / a.reps,
            "nsubbox": nbox, "photon_loss": loss}
     try:
