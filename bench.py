@@ -108,11 +108,11 @@ def workload_label(kind, N, nsrc_total, R, world, strong):
             "raytrace + one chemistry pass per step")
 
 
-PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.txt")
+PMC_SUMMARY = os.path.join("profiles", "r04_pmc_summary.txt")
 # 64-B atomic requests per second the memory side takes from no-return global_atomic_add_f64 (rows of 8 ... 4096 doubles at any
 # alignment, scattered over 2 x 256^3 doubles): tools/micro/atomic_rate.hip, measured on MI355X
 ATOMIC_REQUEST_CEILING = 2.28e10
-ATOMIC_CEILING_SOURCE = os.path.join("profiles", "r03_atomic_rate_microbench.txt")
+ATOMIC_CEILING_SOURCE = os.path.join("profiles", "r04_atomic_rate_microbench.txt")
 
 
 def pmc_counters(kernel):

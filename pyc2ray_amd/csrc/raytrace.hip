@@ -243,6 +243,16 @@ constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_RATE = 1u <
 // that are still growing; it starts from the trailing shell the previous sub-box's launch left in global memory and leaves
 // its own there; cells on the faces of the box add what passes through them (phi_out, photorates.f90:120-125) to the
 // source's photon loss; every source is rated with the flux of `flux_src` (f90:500,503).  Fortran-flavoured constants.
+//
+// Which combinations exist (the two static_asserts below admit exactly these; DESIGN.md 4.1 has the same table with the launch
+// shapes that select them):
+//   family                         THREADS x TABCAP                               GS   DUMP HEAT SKIP_ZERO GREY BUFATOM NSRC SUBBOX   launcher
+//   paired production              {64,128,256,512}x256 {64,128,256}x64 256x32     f    f    f    f/t       f    t       2    f        launch_variant_pairs
+//   single source, buffer atomics  {64..1024}x256 {64,128}x64 {256,512,1024}x1024  f    f    f/t  f/t       f/t  t       1    f        launch_variant
+//   single source, global atomics  same (N > 512, option, shells in global memory) f/t  f    f/t  f (t: GS=f) f/t f       1    f        launch_variant
+//   column-density dump            256 x {256,1024}                                f/t  t    f    f         f/t  f       1    f        launch_variant
+//   sub-box sweep                  {256,512} x 256                                 f    f    f/t  f         f    t       1|2  t        launch_subbox_tables_variant
+//   (SKIP_ZERO with HEAT or GREY, NSRC = 2 with HEAT, DUMP, GREY or global atomics, SUBBOX with NSRC = 2 and HEAT: not built)
 template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP, bool HEAT, int TABCAP, bool SKIP_ZERO = false, bool GREY = false,
           bool BUFATOM = false, int NSRC = 1, bool SUBBOX = false>
 __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? ASORA_PAIR_MIN_WAVES : ASORA_MIN_WAVES) : 1)) raytrace_octant_kernel(const RtParams p)

@@ -10,12 +10,12 @@ for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VA
          "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_LEVEL_WAVES SQ_IFETCH SQ_INSTS_VALU_TRANS_F64 SQ_BUSY_CU_CYCLES SQ_INSTS_BRANCH" \
          "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_${TAG}_$i -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sources 0 "$@" > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1 || echo "pmc pass $i failed"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_${TAG}_$i -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sources 0 --evolving-state 0 "$@" > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1 || echo "pmc pass $i failed"
 done
 python3 - <<PY
 import csv,glob,collections
 out=open("$R/gpurun_out/pmc_${TAG}_summary.txt","w")
-out.write("# rocprofv3 --kernel-trace --pmc <group> -- python3 bench.py --steps 2 --warmup 1 --cpu-sources 0 $*\n")
+out.write("# rocprofv3 --kernel-trace --pmc <group> -- python3 bench.py --steps 2 --warmup 1 --cpu-sources 0 --evolving-state 0 $*\n")
 out.write("# kernel  counter  launches  mean per launch (FETCH_SIZE / WRITE_SIZE in KiB)\n")
 for d in sorted(glob.glob("$R/gpurun_out/pmc_${TAG}_[0-9]*/")):
     for f in glob.glob(d+"*/*counter_collection.csv"):

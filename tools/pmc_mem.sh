@@ -14,12 +14,12 @@ for C in "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_LA
          "TCC_TAG_STALL_sum TCC_BUSY_sum TCC_CYCLE_sum TCC_ATOMIC_sum" \
          "TCP_LFIFO_STALL_CYCLES_sum TCP_RFIFO_STALL_CYCLES_sum TCP_TCP_TA_ADDR_STALL_CYCLES_sum TCP_GATE_EN2_sum"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmcmem_${TAG}_$i -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sources 0 "$@" > $R/gpurun_out/pmcmem_${TAG}_$i.log 2>&1 || echo "pmc pass $i failed"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmcmem_${TAG}_$i -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sources 0 --evolving-state 0 "$@" > $R/gpurun_out/pmcmem_${TAG}_$i.log 2>&1 || echo "pmc pass $i failed"
 done
 python3 - <<PY
 import csv,glob,collections
 out=open("$R/gpurun_out/pmcmem_${TAG}_summary.txt","w")
-out.write("# rocprofv3 --kernel-trace --pmc <group> -- python3 bench.py --steps 2 --warmup 1 --cpu-sources 0 $*\n")
+out.write("# rocprofv3 --kernel-trace --pmc <group> -- python3 bench.py --steps 2 --warmup 1 --cpu-sources 0 --evolving-state 0 $*\n")
 out.write("# kernel  counter  launches  mean per launch (FETCH_SIZE / WRITE_SIZE in KiB)\n")
 for d in sorted(glob.glob("$R/gpurun_out/pmcmem_${TAG}_[0-9]*/")):
     for f in glob.glob(d+"*/*counter_collection.csv"):
