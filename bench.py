@@ -785,7 +785,7 @@ def main():
                                  "(TCC_EA0_ATOMIC %.3g per launch, %s: %.2f doubles each; 6.41 is what whole rows of the sphere give), and "
                                  "the memory side takes %.3g of them per second (%s); `atomic_requests.frac` in roofline_kernels is this "
                                  "launch against that ceiling.  Next the FP64/integer VALU stream (%.3g wave-instructions per launch, "
-                                 "`valu_issue`); HBM bytes are not close (`traffic`).  DESIGN.md 8.0"
+                                 "`valu_issue`); HBM bytes are not close (`traffic`).  DESIGN.md 7"
                                  % (rt_counters.get("TCC_EA0_ATOMIC_sum", float("nan")), PMC_SUMMARY,
                                     gamma_cells / rt_counters.get("TCC_EA0_ATOMIC_sum", float("nan")), ATOMIC_REQUEST_CEILING,
                                     ATOMIC_CEILING_SOURCE, rt_counters.get("SQ_INSTS_VALU", float("nan"))))
