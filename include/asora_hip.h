@@ -298,7 +298,9 @@ enum {
     /* raytrace: one workgroup sweeps its unit for TWO consecutive sources at once (the source-independent geometry is
      * decoded once per lane-step, two dependency chains per wave).  0 = the library decides from the radius and the
      * number of sources (default), 1 = never, 2 = whenever the variant exists (table rates, no heating, shell buffers
-     * in LDS, buffer atomics).  Same rates either way, up to the order in which the atomics add them up. */
+     * in LDS, buffer atomics).  Same rates either way, up to the order in which the atomics add them up.  Since round 4
+     * the option also governs the tabulated sub-box sweep (ASORA_OPT_SUBBOX_TABLES): photon loss, trailing shell and
+     * activity are kept per source, a source that stopped growing is swept along with its partner. */
     ASORA_OPT_PAIR_SOURCES = 13,
     /* c2ray_do_all_sources / asora_subbox_raytrace_device: sweep the sub-boxes on the tabulated geometry of the ASORA
      * kernel (cells within R_max_LLS only: what is rated or lost) instead of generating the cube's geometry on the fly.
@@ -307,7 +309,7 @@ enum {
     ASORA_OPT_SUBBOX_TABLES = 14,
     /* 15: rows of the rate grid cut at 64-byte lines: 0 = the library decides (units of one face, i.e. six sectors or twelve
      * sector pairs per source, mesh a multiple of 8, r_RT < 52.5 cells, and a radius that does not change from call to call: after the first change only
-     * once a radius has served 32 launches in a row), 1 = never, 2 = whenever possible (r_RT <= 110).  The geometry
+     * once a radius has served 32 CALLS in a row -- decided once per call, never per launch), 1 = never, 2 = whenever possible (r_RT <= 110).  The geometry
      * tables then exist in eight forms, by the source's position modulo 8 along the axis that is contiguous in memory for
      * the unit's face; in each, the cells of one row that fall into one 64-byte line of the rate grid never straddle two
      * waves, so every wave's rate atomics leave as whole-line requests (about 8 % fewer requests; the memory side's

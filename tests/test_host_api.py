@@ -182,3 +182,26 @@ def test_printlog_lines_writes_what_printlog_would(tmp_path, capsys):
     printlog_lines([], str(b), quiet=True)
     printlog_lines(lines, None, quiet=True)
     assert capsys.readouterr().out == ""
+
+
+def test_bench_trip_counts_equal_the_oracles_do_chemistry():
+    """bench.py's `evolving_state` prints a histogram of do_chemistry trip counts per cell, recomputed on the host with a
+    vectorised restatement of chemistry.f90:146-203; here that restatement against the oracle's do_chemistry (which returns its
+    trip count) on random cells, Gamma from 0 to huge, temperatures from 1e3 to 5e4 K."""
+    import bench
+    from oracle import oracle as O
+    rng = np.random.default_rng(11)
+    n = 400
+    nd = 1e-3 * np.exp(rng.normal(size=n))
+    T = 10 ** rng.uniform(3.0, 4.7, size=n)
+    x0 = 10 ** rng.uniform(-4, -0.01, size=n)
+    xav = np.clip(x0 * rng.uniform(0.5, 1.5, size=n), 1e-10, 1 - 1e-10)
+    g = 10 ** rng.uniform(-20, -8, size=n)
+    g[rng.uniform(size=n) < 0.2] = 0.0
+    g[rng.uniform(size=n) < 0.05] = 1e-2
+    dt = 3.15576e13
+    mine = bench.trip_counts(dt, nd, T, x0, xav, g, bench.BH00, bench.ALBPOW, bench.COLH0, bench.TEMPH0, bench.ABU_C)
+    ref = np.array([O.do_chemistry(dt, nd[q], T[q], x0[q], xav[q], g[q], bench.BH00, bench.ALBPOW, bench.COLH0, bench.TEMPH0,
+                                   bench.ABU_C)[2] for q in range(n)])
+    assert np.array_equal(mine, ref)
+    assert ref.max() >= 3 and ref.min() == 1
