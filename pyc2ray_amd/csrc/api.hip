@@ -2,6 +2,7 @@
 // The reference counterparts are src/asora/memory.cu (state) and
 // src/asora/python_module.cu (CPython wrappers); see include/asora_hip.h for the mapping.
 #include "asora_internal.hpp"
+#include "rates_device.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -841,16 +842,10 @@ int asora_photo_table_to_device(const double *thin_table, const double *thick_ta
     State &st = g_state;
     st.zero_since_probe = std::max(st.zero_since_probe, 48);
     if (st.tables) { (void)hipFree(st.tables); st.tables = nullptr; }
-    // device layout: pairs {T[i], T[i+1]-T[i]} so that one 16-byte load serves the linear interpolation
-    // of photo_lookuptable (rates.cu:82); the last pair is {T[last], 0}
+    // device layout: rates_device.hpp (one 16-byte load serves the linear interpolation of photo_lookuptable, rates.cu:82)
     std::vector<double2> pairs(4 * (size_t)NumTau, double2{0.0, 0.0});   // [thick | thin | heat thick | heat thin]
-    for (int t = 0; t < 2; ++t) {
-        const double *src = t == 0 ? thick_table : thin_table;
-        for (int i = 0; i < NumTau; ++i) {
-            pairs[(size_t)t * NumTau + i].x = src[i];
-            pairs[(size_t)t * NumTau + i].y = (i + 1 < NumTau) ? src[i + 1] - src[i] : 0.0;
-        }
-    }
+    pack_rate_table(pairs.data(), 0, thick_table, NumTau);
+    pack_rate_table(pairs.data(), 1, thin_table, NumTau);
     ASORA_HIP_TRY(hipMalloc(&st.tables, pairs.size() * sizeof(double2)));
     ASORA_HIP_TRY(hipMemcpy(st.tables, pairs.data(), pairs.size() * sizeof(double2), hipMemcpyHostToDevice));
     st.table_len = NumTau;
@@ -868,15 +863,11 @@ int asora_heat_table_to_device(const double *heat_thin_table, const double *heat
         return fail(3, "heat_table_to_device: the heating tables must have the length of the photo tables (" +
                            std::to_string(st.table_len) + ")");
     if (int rc = ensure_heat_grid()) return rc;
-    std::vector<double2> pairs(2 * (size_t)NumTau);
-    for (int t = 0; t < 2; ++t) {
-        const double *src = t == 0 ? heat_thick_table : heat_thin_table;
-        for (int i = 0; i < NumTau; ++i) {
-            pairs[(size_t)t * NumTau + i].x = src[i];
-            pairs[(size_t)t * NumTau + i].y = (i + 1 < NumTau) ? src[i + 1] - src[i] : 0.0;
-        }
-    }
-    ASORA_HIP_TRY(hipMemcpy(st.tables + 2 * (size_t)NumTau, pairs.data(), pairs.size() * sizeof(double2),
+    std::vector<double2> pairs(4 * (size_t)NumTau, double2{0.0, 0.0});
+    pack_rate_table(pairs.data(), 2, heat_thick_table, NumTau);
+    pack_rate_table(pairs.data(), 3, heat_thin_table, NumTau);
+    const size_t lo = rate_table_byte_offset(2, NumTau), hi = rate_table_byte_offset(4, NumTau);
+    ASORA_HIP_TRY(hipMemcpy(reinterpret_cast<char *>(st.tables) + lo, reinterpret_cast<const char *>(pairs.data()) + lo, hi - lo,
                             hipMemcpyHostToDevice));
     st.have_heat_tables = true;
     return 0;
@@ -1198,13 +1189,8 @@ int c2ray_do_all_sources(const double *normflux, const int32_t *srcpos, int max_
         std::vector<double2> pairs(4 * (size_t)len, double2{0.0, 0.0});
         const double *src[4] = {photo_thick_table, photo_thin_table, heat ? heat_thick_table : nullptr,
                                 heat ? heat_thin_table : nullptr};
-        for (int t = 0; t < 4 && !grey; ++t) {
-            if (!src[t]) continue;
-            for (int i = 0; i < len; ++i) {
-                pairs[(size_t)t * len + i].x = src[t][i];
-                pairs[(size_t)t * len + i].y = (i + 1 < len) ? src[t][i + 1] - src[t][i] : 0.0;
-            }
-        }
+        for (int t = 0; t < 4 && !grey; ++t)
+            if (src[t]) pack_rate_table(pairs.data(), t, src[t], len);
         if (int rc = tmp.alloc(d_tables, pairs.size())) return rc;
         ASORA_HIP_TRY(hipMemcpy(d_tables, pairs.data(), pairs.size() * sizeof(double2), hipMemcpyHostToDevice));
     }

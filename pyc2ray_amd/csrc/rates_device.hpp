@@ -64,8 +64,22 @@ __device__ __forceinline__ double log2_pos(double x, const double2 *__restrict__
 // 1 + (log10(tau) - minlogtau)/dlogtau; here that is one fused multiply-add on log2(tau) with
 // k1 = log10(2)/dlogtau, k0 = 1 - minlogtau/dlogtau.  Indices are clamped to the last table
 // element (the reference reads one past the end when NumTau == len(table), tau >= 10^maxlogtau).
-// The device tables hold pairs {T[i], T[i+1] - T[i]} (last pair {T[last], 0}): one 16-byte load per lookup.
-struct Lookup { double2 t; double2 h; double residual; };   // h: the heating-table pair at the same index
+// Device layout of the rate tables (ASORA_DENSE_TABLES):
+//   1 (round 4): each table as it is, T[0 .. len-1] plus one more element T[len] = T[len-1]; a lookup is ONE 16-byte load of
+//     {T[i], T[i+1]} from an 8-byte-aligned address and the difference is formed in the kernel (one more v_add_f64).  The entries a
+//     wave's 64 lanes need then span half as many cache lines as with
+//   0 (rounds 1-3): pairs {T[i], T[i+1] - T[i]} (last pair {T[last], 0}), 16 bytes per entry.
+// The lookups are the loop's only divergent accesses (LABNOTES round 4: 14 % of the trace on the quiet benchmark medium, 25 % on a
+// field with ionisation fronts).  Same bits either way: the host formed T[i+1] - T[i] with the same IEEE subtraction.
+// The four tables of an allocation (thick, thin, heating thick, heating thin) follow each other at table_stride(len) entries.
+#ifndef ASORA_DENSE_TABLES
+#define ASORA_DENSE_TABLES 1
+#endif
+constexpr int TABLE_ENTRY_SHIFT = ASORA_DENSE_TABLES ? 3 : 4;          // log2 of the bytes per entry
+__host__ __device__ constexpr int table_stride(int table_len) { return ASORA_DENSE_TABLES ? table_len + 1 : table_len; }
+typedef double double2_a8 __attribute__((ext_vector_type(2), aligned(8)));      // a 16-byte load that may start on any double
+
+struct Lookup { double2 t; double2 h; double residual; };   // h: the heating table at the same index
 template <bool HEAT = false, typename Params = RtParams>
 __device__ __forceinline__ Lookup lookup_issue(const double2 *__restrict__ table, double tau, const Params &p,
                                                const double2 *__restrict__ logtab, int offset = 0)
@@ -78,8 +92,8 @@ __device__ __forceinline__ Lookup lookup_issue(const double2 *__restrict__ table
 #else
     const double l2 = log2_pos(fmin(fmax(1.0e-20, tau), 1.0e300), logtab);
 #endif
-    // numtau_f is clamped to table_len - 1 on the host (lut_index_limit): real_i >= table_len - 1 reads the last pair
-    // {T[last], 0} whatever the residual, as the reference's i0 = i1 = NumTau does -- no integer clamp here
+    // numtau_f is clamped to table_len - 1 on the host (lut_index_limit): real_i >= table_len - 1 reads the last entry
+    // (slope 0) whatever the residual, as the reference's i0 = i1 = NumTau does -- no integer clamp here
     const double real_i = fmin(p.numtau_f, fmax(0.0, fma(l2, p.lut_k1, p.lut_k0)));
     const int i0 = (int)real_i;
     Lookup L;
@@ -90,12 +104,39 @@ __device__ __forceinline__ Lookup lookup_issue(const double2 *__restrict__ table
 #endif
     // a 32-bit byte offset from the (wave-uniform) table base: one shift, and the load takes base + offset by itself
     const char *base = reinterpret_cast<const char *>(table);
-    L.t = *reinterpret_cast<const double2 *>(base + (i << 4));
-    if (HEAT) L.h = *reinterpret_cast<const double2 *>(base + ((i + 2u * (unsigned)p.table_len) << 4)); else L.h = L.t;
+    auto load16 = [](const char *q) -> double2 {
+        const double2_a8 v = *reinterpret_cast<const double2_a8 *>(q);
+        return double2{v.x, v.y};
+    };
+    L.t = load16(base + (i << TABLE_ENTRY_SHIFT));
+    if (HEAT) L.h = load16(base + ((i + 2u * (unsigned)table_stride(p.table_len)) << TABLE_ENTRY_SHIFT)); else L.h = L.t;
     return L;
 }
+#if ASORA_DENSE_TABLES
+__device__ __forceinline__ double lookup_value(const Lookup &L) { return fma(L.residual, L.t.y - L.t.x, L.t.x); }
+__device__ __forceinline__ double lookup_heat(const Lookup &L) { return fma(L.residual, L.h.y - L.h.x, L.h.x); }
+#else
 __device__ __forceinline__ double lookup_value(const Lookup &L) { return fma(L.residual, L.t.y, L.t.x); }
 __device__ __forceinline__ double lookup_heat(const Lookup &L) { return fma(L.residual, L.h.y, L.h.x); }
+#endif
+
+// Host: table t (0 thick, 1 thin, 2 heating thick, 3 heating thin) of `len` entries into a buffer of 4 * len double2 (the
+// allocation keeps that size in both layouts)
+inline void pack_rate_table(double2 *buffer, int t, const double *src, int len)
+{
+#if ASORA_DENSE_TABLES
+    double *d = reinterpret_cast<double *>(buffer) + (size_t)t * table_stride(len);
+    for (int i = 0; i < len; ++i) d[i] = src[i];
+    d[len] = src[len - 1];
+#else
+    for (int i = 0; i < len; ++i) {
+        buffer[(size_t)t * len + i].x = src[i];
+        buffer[(size_t)t * len + i].y = (i + 1 < len) ? src[i + 1] - src[i] : 0.0;
+    }
+#endif
+}
+// byte range of the tables [t0, t1) inside such a buffer
+inline size_t rate_table_byte_offset(int t, int len) { return (size_t)t * table_stride(len) * ((size_t)1 << TABLE_ENTRY_SHIFT); }
 
 // Products and sums that must NOT be contracted into a fused multiply-add, where the reference's result depends on
 // each operation being rounded on its own (device code is compiled with -ffp-contract=fast, and HIP's __dmul_rn /

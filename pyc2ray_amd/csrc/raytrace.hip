@@ -74,9 +74,9 @@ __device__ __forceinline__ RateJob rate_issue(double flux, double cd_in, double 
     const double tau_thin = p.fortran_consts ? tau_in : tau_out;
     // one code path for both kinds of cell: per-lane table and arguments
     // thick table at [0, table_len), thin table at [table_len, 2*table_len) of one allocation
-    const double2 *tab = p.tables + (J.thick ? 0 : p.table_len);
-    J.A = lookup_issue(tab, J.thick ? tau_in : tau_thin, p, logtab);
-    J.B = lookup_issue(tab, J.thick ? tau_out : tau_thin, p, logtab);
+    const int toff = J.thick ? 0 : table_stride(p.table_len);
+    J.A = lookup_issue(p.tables, J.thick ? tau_in : tau_thin, p, logtab, toff);
+    J.B = lookup_issue(p.tables, J.thick ? tau_out : tau_thin, p, logtab, toff);
     return J;
 }
 __device__ __forceinline__ double rate_value(const RateJob &J)
@@ -108,9 +108,9 @@ __device__ __forceinline__ double heat_rate_per_atom(double flux, double cd_in, 
     const double pref = flux / vol_nhi;
     const bool thick = fabs(tau_out - tau_in) > limit;
     const double tau_thin = p.fortran_consts ? tau_in : tau_out;
-    const double2 *tab = p.tables + (thick ? 0 : p.table_len);
-    const Lookup A = lookup_issue<true>(tab, thick ? tau_in : tau_thin, p, logtab);
-    const Lookup B = lookup_issue<true>(tab, thick ? tau_out : tau_thin, p, logtab);
+    const int toff = thick ? 0 : table_stride(p.table_len);
+    const Lookup A = lookup_issue<true>(p.tables, thick ? tau_in : tau_thin, p, logtab, toff);
+    const Lookup B = lookup_issue<true>(p.tables, thick ? tau_out : tau_thin, p, logtab, toff);
     return thick ? pref * (lookup_heat(A) - lookup_heat(B)) : pref * (tau_out - tau_in) * lookup_heat(A);
 }
 
@@ -661,7 +661,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
                 thick[q] = fabs(dtau[q]) > limit;
                 // one code path for both kinds of cell: per-lane table offset and arguments.  A thin cell looks its tau_thin up
                 // twice: tau_in with the Fortran's constants (photorates.f90:121), tau_out with the CUDA library's (rates.cu:37)
-                toff[q] = thick[q] ? 0 : p.table_len;
+                toff[q] = thick[q] ? 0 : table_stride(p.table_len);
                 arg_A[q] = (thick[q] || p.fortran_consts) ? tau_in : tau_out;
                 arg_B[q] = (thick[q] || !p.fortran_consts) ? tau_out : tau_in;
             }

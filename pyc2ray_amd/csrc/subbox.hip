@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(SB_THREADS) subbox_sweep_kernel(const SubboxPa
                 const double pref = flux / vol;
                 const Lookup A = lookup_issue<HEAT>(p.tables, tau_in, p, logtab);     // thick table at tau_in
                 const Lookup B = thick ? lookup_issue<HEAT>(p.tables, tau_out, p, logtab)
-                                       : lookup_issue<HEAT>(p.tables + p.table_len, tau_in, p, logtab);   // thin, tau_in
+                                       : lookup_issue<HEAT>(p.tables, tau_in, p, logtab, table_stride(p.table_len));   // thin, tau_in
                 const double phi_in = pref * lookup_value(A);
                 if (thick) {
                     // (pref*(T_in - T_out): phi_in - phi_out would be fused into fma(pref, T_in, -phi_out) and leave the
