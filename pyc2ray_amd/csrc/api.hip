@@ -843,7 +843,8 @@ int asora_photo_table_to_device(const double *thin_table, const double *thick_ta
     st.zero_since_probe = std::max(st.zero_since_probe, 48);
     if (st.tables) { (void)hipFree(st.tables); st.tables = nullptr; }
     // device layout: rates_device.hpp (one 16-byte load serves the linear interpolation of photo_lookuptable, rates.cu:82)
-    std::vector<double2> pairs(4 * (size_t)NumTau, double2{0.0, 0.0});   // [thick | thin | heat thick | heat thin]
+    // (at least 16 elements: the kernels' pipeline-priming loads read a few fixed small offsets whatever the table's length)
+    std::vector<double2> pairs(std::max<size_t>(4 * (size_t)NumTau, 16), double2{0.0, 0.0});   // [thick | thin | heat thick | heat thin]
     pack_rate_table(pairs.data(), 0, thick_table, NumTau);
     pack_rate_table(pairs.data(), 1, thin_table, NumTau);
     ASORA_HIP_TRY(hipMalloc(&st.tables, pairs.size() * sizeof(double2)));
@@ -1186,7 +1187,7 @@ int c2ray_do_all_sources(const double *normflux, const int32_t *srcpos, int max_
     }
     const int len = grey ? 1 : NumTau;
     {   // [thick | thin | heat thick | heat thin] as pairs {T[i], T[i+1]-T[i]} (see asora_photo_table_to_device)
-        std::vector<double2> pairs(4 * (size_t)len, double2{0.0, 0.0});
+        std::vector<double2> pairs(std::max<size_t>(4 * (size_t)len, 16), double2{0.0, 0.0});
         const double *src[4] = {photo_thick_table, photo_thin_table, heat ? heat_thick_table : nullptr,
                                 heat ? heat_thin_table : nullptr};
         for (int t = 0; t < 4 && !grey; ++t)
