@@ -265,6 +265,16 @@ struct KernelTimer {
 // Raytracing (raytrace.hip)
 // ---------------------------------------------------------------------------------------------
 
+// flag bits of a geometry-table entry (cellA.y; raytrace.hip describes the tables, geometry.hip builds them)
+constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_RATE = 1u << 29,
+                   CELL_SPHERE = 1u << 28,            // host bookkeeping: the cell sits on the sphere, RATE depends on dr (the kernel ignores it)
+                   CELL_ZERO_SHIFT = 25,              // bits 25..27: which of the offsets (a, b, c) are zero
+                   CELL_NEG_SHIFT = 22,               // bits 22..24: the cell lies on the mirrored side of axis 0 / 1 / 2 (axes the unit merges)
+                   CELL_SLOT_MASK = (1u << 22) - 1;
+
+struct SubboxGeometry { int ext_r, ext_l, boxsize; };     // sub-box tables: the traversal range of raytracing.f90:174-175, the box size
+// Build (or reuse) the geometry tables for (N, R, dr, threads, units): geometry.hip
+int ensure_geometry(State &st, RtParams &p, int threads, int units, const SubboxGeometry *sbg = nullptr, bool aligned = false);
 void release_geometry(State &st);
 bool note_call_radius(State &st, double R);   // once per call: may the eight-fold aligned tables be built for this radius?
 void release_pair_lists(State &st);     // with every change of the source lists

@@ -1,0 +1,186 @@
+// grid_kernels.hip -- the N^3 helper passes around the raytrace: nHI = ndens (1 - xh_av) in both layouts, the [i][j][k] <-> [k][j][i]
+// transposes, the folds of the z-faces' transposed rate accumulator.  All streaming, tiled 32 x 32 through LDS.
+#include "asora_internal.hpp"
+
+namespace asora {
+
+// ---------------------------------------------------------------------------------------------
+// N^3 helper kernels
+// ---------------------------------------------------------------------------------------------
+
+// nhi[i][j][k] = ndens*(1-xh_av);  nhi_t[k][j][i] = same (tiled transpose of the (i,k) planes), for the planes
+// [i_begin, i_end).  block (32,8): tile 32(i) x 32(k) of one j.  ZERO: also zero both layouts of an accumulator
+// on those planes (a multi-GPU rank only touches the planes its sources reach).
+template <bool WITH_T, bool ZERO>
+__global__ void __launch_bounds__(256) prepare_nhi_kernel(const double *__restrict__ nd, const double *__restrict__ xh,
+                                                          double *__restrict__ nhi, double *__restrict__ nhi_t, int N,
+                                                          int i_begin, int i_end, double *__restrict__ acc, size_t ncell)
+{
+    __shared__ double tile[32][33];
+    const int j = blockIdx.y;
+    const int ib = i_begin + blockIdx.z * 32, kb = blockIdx.x * 32;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int i = ib + r, k = kb + threadIdx.x;
+        if (i < i_end && k < N) {
+            const size_t idx = ((size_t)i * N + j) * N + k;
+            const double v = nd[idx] * (1.0 - xh[idx]);       // raytracing.cu:276
+            nhi[idx] = v;
+            if (ZERO) acc[idx] = 0.0;
+            if (WITH_T) tile[r][threadIdx.x] = v;
+        }
+    }
+    if (!WITH_T) return;
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int k = kb + r, i = ib + threadIdx.x;
+        if (i < i_end && k < N) {
+            const size_t o = ((size_t)k * N + j) * N + i;
+            nhi_t[o] = tile[threadIdx.x][r];
+            if (ZERO) acc[ncell + o] = 0.0;
+        }
+    }
+}
+
+// dst[k][j][i] (op)= src[i][j][k]
+template <bool ACCUMULATE>
+__global__ void __launch_bounds__(256) transpose_ik_kernel(const double *__restrict__ src, double *__restrict__ dst, int N)
+{
+    __shared__ double tile[32][33];
+    const int j = blockIdx.y;
+    const int ib = blockIdx.z * 32, kb = blockIdx.x * 32;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int i = ib + r, k = kb + threadIdx.x;
+        if (i < N && k < N) tile[r][threadIdx.x] = src[((size_t)i * N + j) * N + k];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int k = kb + r, i = ib + threadIdx.x;
+        if (i < N && k < N) {
+            const size_t o = ((size_t)k * N + j) * N + i;
+            if (ACCUMULATE) dst[o] += tile[threadIdx.x][r];
+            else dst[o] = tile[threadIdx.x][r];
+        }
+    }
+}
+
+static dim3 tile_grid(int N) { const unsigned t = (N + 31) / 32; return dim3(t, N, t); }
+
+int launch_prepare_nhi_from(State &st, const double *xh_av, bool need_transposed)
+{
+    KernelTimer kt(ASORA_KERNEL_PREP);
+    const int N = st.N;
+    if (need_transposed)
+        hipLaunchKernelGGL((prepare_nhi_kernel<true, false>), tile_grid(N), dim3(32, 8), 0, st.stream,
+                           st.grid[ASORA_GRID_NDENS], xh_av, st.nhi, st.nhi_t, N, 0, N, (double *)nullptr, st.ncell);
+    else
+        hipLaunchKernelGGL((prepare_nhi_kernel<false, false>), tile_grid(N), dim3(32, 8), 0, st.stream,
+                           st.grid[ASORA_GRID_NDENS], xh_av, st.nhi, st.nhi_t, N, 0, N, (double *)nullptr, st.ncell);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_prepare_nhi(State &st, bool need_transposed)
+{
+    return launch_prepare_nhi_from(st, st.grid[ASORA_GRID_XH_AV], need_transposed);
+}
+
+// nHI in both layouts on the planes [i_begin, i_begin + i_count) only; zero_acc: also zero both layouts of `acc` there
+int launch_prepare_range(State &st, int i_begin, int i_count, bool zero_acc, double *acc)
+{
+    if (i_count <= 0) return 0;
+    KernelTimer kt(ASORA_KERNEL_PREP);
+    const int N = st.N;
+    const unsigned t = (N + 31) / 32;
+    const dim3 grid(t, N, (i_count + 31) / 32);
+    if (zero_acc)
+        hipLaunchKernelGGL((prepare_nhi_kernel<true, true>), grid, dim3(32, 8), 0, st.stream, st.grid[ASORA_GRID_NDENS],
+                           st.grid[ASORA_GRID_XH_AV], st.nhi, st.nhi_t, N, i_begin, i_begin + i_count, acc, st.ncell);
+    else
+        hipLaunchKernelGGL((prepare_nhi_kernel<true, false>), grid, dim3(32, 8), 0, st.stream, st.grid[ASORA_GRID_NDENS],
+                           st.grid[ASORA_GRID_XH_AV], st.nhi, st.nhi_t, N, i_begin, i_begin + i_count, acc, st.ncell);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_finish_phi(State &st)
+{
+    KernelTimer kt(ASORA_KERNEL_FINISH);
+    // phi[i][j][k] += phi_t[k][j][i]  (the transpose is an involution on the index pair)
+    hipLaunchKernelGGL(transpose_ik_kernel<true>, tile_grid(st.N), dim3(32, 8), 0, st.stream,
+                       (const double *)st.phi_t, st.grid[ASORA_GRID_PHI_ION], st.N);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_fold_transposed(State &st, const double *src_t, double *dst)
+{
+    KernelTimer kt(ASORA_KERNEL_FINISH);
+    hipLaunchKernelGGL(transpose_ik_kernel<true>, tile_grid(st.N), dim3(32, 8), 0, st.stream, src_t, dst, st.N);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// dst[i][j][k] += src_t[k][j][i] for i in [i_begin, i_begin + i_count): the slab's share of the fold
+__global__ void __launch_bounds__(256) fold_range_kernel(const double *__restrict__ src_t, double *__restrict__ dst, int N,
+                                                         int i_begin, int i_end)
+{
+    __shared__ double tile[32][33];
+    const int j = blockIdx.y;
+    const int kb = blockIdx.z * 32, ib = i_begin + blockIdx.x * 32;       // src_t tile: rows k, columns i
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int k = kb + r, i = ib + threadIdx.x;
+        if (k < N && i < i_end) tile[r][threadIdx.x] = src_t[((size_t)k * N + j) * N + i];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int i = ib + r, k = kb + threadIdx.x;
+        if (i < i_end && k < N) dst[((size_t)i * N + j) * N + k] += tile[threadIdx.x][r];
+    }
+}
+
+int launch_fold_range(State &st, const double *src_t, double *dst, int i_begin, int i_count)
+{
+    if (i_count <= 0) return 0;
+    KernelTimer kt(ASORA_KERNEL_FINISH);
+    const unsigned tk = (st.N + 31) / 32, ti = (i_count + 31) / 32;
+    hipLaunchKernelGGL(fold_range_kernel, dim3(ti, st.N, tk), dim3(32, 8), 0, st.stream, src_t, dst, st.N, i_begin,
+                       i_begin + i_count);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// dst[i][j][k] = a[i][j][k] + b_t[k][j][i] (the two accumulators of the device loop, left intact, into the rate grid)
+__global__ void __launch_bounds__(256) fold_sum_kernel(const double *__restrict__ a, const double *__restrict__ b_t,
+                                                       double *__restrict__ dst, int N)
+{
+    __shared__ double tile[32][33];
+    const int j = blockIdx.y;
+    const int kb = blockIdx.z * 32, ib = blockIdx.x * 32;       // b_t tile: rows k, columns i
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int k = kb + r, i = ib + threadIdx.x;
+        if (k < N && i < N) tile[r][threadIdx.x] = b_t[((size_t)k * N + j) * N + i];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int i = ib + r, k = kb + threadIdx.x;
+        if (i < N && k < N) { const size_t o = ((size_t)i * N + j) * N + k; dst[o] = a[o] + tile[threadIdx.x][r]; }
+    }
+}
+
+int launch_fold_sum(State &st, const double *a, const double *b_t, double *dst)
+{
+    KernelTimer kt(ASORA_KERNEL_FINISH);
+    hipLaunchKernelGGL(fold_sum_kernel, tile_grid(st.N), dim3(32, 8), 0, st.stream, a, b_t, dst, st.N);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_transpose(State &st, const double *src, double *dst, int N)
+{
+    hipLaunchKernelGGL(transpose_ik_kernel<false>, tile_grid(N), dim3(32, 8), 0, st.stream, src, dst, N);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+
+} // namespace asora
