@@ -144,6 +144,7 @@ static int release_all()
     auto drop = [](auto *&ptr) { if (ptr) { (void)hipFree(ptr); ptr = nullptr; } };
     for (int g = 0; g < ASORA_GRID_COUNT; ++g) { drop(st.grid[g]); st.grid_valid[g] = false; }
     drop(st.nhi); drop(st.staging); drop(st.acc); st.ev_clean[0] = st.ev_clean[1] = false; st.ev_sets_known = false;
+    drop(st.reach_mask); drop(st.reach_count_dev); st.reach_bytes = 0; st.reach_valid = false; st.reach_in_use = false; st.reach_pays = false;
     st.ev_open = false;
     st.temp_probe_valid = false;
     st.nhi_t = st.phi_t = st.heat_t = nullptr;    // second halves of nhi / phi_ion / phi_heat
@@ -928,6 +929,7 @@ int asora_source_data_to_device(const int32_t *pos, const double *flux, int NumS
     }
     st.src_pos_host.assign(pos, pos + 3 * (size_t)NumSrc);
     st.num_src = NumSrc;
+    st.src_generation += 1;
     return 0;
 }
 
@@ -1296,6 +1298,40 @@ int asora_evolve_begin(double dt, double bh00, double albpow, double colh0, doub
         st.ev_clean[0] = st.ev_clean[1] = true;
         st.ev_sets_known = true;
     }
+    // Which lines of the accumulators this step's sources can touch (State::reach_mask): rebuilt when the sources, their range
+    // or the radius change, and USED while at least 45 % of the lines are out of reach (counted then).  Measured at 256^3 with 1000
+    // sources (profiles/r04_ab_reach_mask.txt): r_RT = 8 (20 % of the lines reached) pass -12 ... -19 %, 12 (46 %) -3 ... -7 %,
+    // 16 (74 %) +2 ... +5 %, 32 (100 %) +10 %: where the spheres cover the box the two mask bytes per cell only cost -- none of the
+    // BASELINE configurations gains, sparse runs (few sources, small radii) do.  Whenever the set of lines the
+    // passes zero changes, BOTH pairs are zeroed once: the dirty pair of the previous step may hold rates where the new
+    // sources do not reach.  Not for traces that cover (nearly) the whole box, nor with ASORA_REACH_MASK=0 (2: whenever built).
+    {
+        static const int mode = []() { const char *v = getenv("ASORA_REACH_MASK"); return v ? atoi(v) : 1; }();
+        const bool possible = mode != 0 && std::isfinite(R) && 2.0 * R + 2.0 < (double)st.N && st.opt[ASORA_OPT_Z_TRANSPOSED] != 0;
+        const bool same = st.reach_valid && st.reach_src_generation == st.src_generation && st.reach_src_begin == src_begin &&
+                          st.reach_src_count == src_count && st.reach_R == R;
+        if (possible && !same) {
+            const size_t one = (size_t)st.N * st.N * ((st.N + 7) / 8);
+            if (!st.reach_mask) { ASORA_HIP_TRY(hipMalloc(&st.reach_mask, 2 * one)); st.reach_bytes = one; }
+            if (!st.reach_count_dev) ASORA_HIP_TRY(hipMalloc(&st.reach_count_dev, sizeof(unsigned long long)));
+            if (int rc = launch_reach_mask(st, st.src_pos, src_begin, src_count, R, st.reach_mask, one)) return rc;
+            if (int rc = launch_reach_count(st, st.reach_mask, 2 * one, st.reach_count_dev)) return rc;
+            unsigned long long marked = 0;
+            ASORA_HIP_TRY(hipMemcpyAsync(&marked, st.reach_count_dev, sizeof marked, hipMemcpyDeviceToHost, st.stream));
+            ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+            st.reach_pays = (double)marked <= 0.55 * (double)(2 * one);
+            st.reach_valid = true; st.reach_src_generation = st.src_generation; st.reach_src_begin = src_begin;
+            st.reach_src_count = src_count; st.reach_R = R;
+        }
+        const bool wanted = possible && (st.reach_pays || mode == 2);
+        if ((wanted && !same) || (wanted != st.reach_in_use)) {      // the set of lines the passes zero changes: start from zeroed pairs
+            if (!(st.ev_clean[0] && st.ev_clean[1])) {
+                ASORA_HIP_TRY(hipMemsetAsync(st.acc, 0, 4 * bytes, st.stream));
+                st.ev_clean[0] = st.ev_clean[1] = true;
+            }
+        }
+        st.reach_in_use = wanted;
+    }
     if (!st.ev_clean[0] && !st.ev_clean[1]) return fail(11, "evolve_begin: no clean accumulator pair (internal error)");
     st.ev_base = st.ev_clean[0] ? 0 : 1;
     st.ev_folded_iter = 0;
@@ -1364,6 +1400,7 @@ int asora_evolve_enqueue(int iterations)
             if (store_always) c.phi_out = st.grid[ASORA_GRID_PHI_ION];
         }
         c.zero_a = acc_next; c.zero_t = acc_next + st.ncell;
+        if (st.reach_in_use) { c.reach_a = st.reach_mask; c.reach_t = st.reach_mask + st.reach_bytes; }
         c.xh_av = st.grid[ASORA_GRID_XH_AV]; c.xh_intermed = st.grid[ASORA_GRID_XH_INTERMED];
         c.nhi = st.nhi; c.nhi_t = st.nhi_t;
         c.red_partial = st.red_partial; c.red_final = st.red_final;

@@ -229,6 +229,19 @@ struct State {
     double ev_chem[6] = {0, 0, 0, 0, 0, 0}; // dt, bh00, albpow, colh0, temph0, abu_c
     int ev_src_begin = 0, ev_src_count = 0;
     RtParams ev_rt;
+    // Which 64-byte lines of the rate accumulators the sources of the current step can touch at all (round 4): one byte per
+    // line of 8 cells, [i][j][k >> 3] for the plain layout and, behind it, [k][j][i >> 3] for the transposed one.  The fused
+    // pass neither reads nor zeroes the lines no source reaches (they are zero and stay zero): 32 of its 88 bytes per cell.
+    // Valid for (source upload, source range, R); nullptr in the pass = every line is reachable.
+    unsigned char *reach_mask = nullptr;
+    size_t reach_bytes = 0;                 // of ONE layout
+    bool reach_valid = false, reach_in_use = false;
+    bool reach_pays = false;                // enough lines out of reach for the mask to pay (counted when the mask is built)
+    unsigned long long *reach_count_dev = nullptr;
+    long reach_src_generation = -1;
+    int reach_src_begin = 0, reach_src_count = 0;
+    double reach_R = -1.0;
+    long src_generation = 0;                // counts asora_source_data_to_device calls
 
     hipStream_t stream = nullptr;
     struct PendingTimer { int which; hipEvent_t e0, e1; };
@@ -357,6 +370,7 @@ struct ChemTileParams {
     int red_stride = 0;                              // number of workgroups of the launch (set by the launcher)
     int accumulate = 0;
     EvolveStatus *status = nullptr;
+    const unsigned char *reach_a = nullptr, *reach_t = nullptr;   // fold + emit: lines of the accumulators any source reaches (State::reach_mask), or nullptr
     bool fold = false, emit = false;
     // the grid has one temperature (launch_temp_probe): its factors, evaluated on the device, travel with the parameters
     int uniform = 0, uniform_t_ok = 0;
@@ -369,5 +383,8 @@ int launch_chemistry_tiles(State &st, ChemTileParams &p, hipStream_t stream);
 size_t chemistry_tile_blocks(const State &st, int N, int planes);
 int launch_prepare_nhi_from(State &st, const double *xh_av, bool need_transposed);
 int launch_prepare_range(State &st, int i_begin, int i_count, bool zero_acc, double *acc);
+// mask[0 .. N*N*NL) for [i][j][k >> 3], mask[N*N*NL .. ) for [k][j][i >> 3], NL = (N + 7) / 8: 1 where a source of the range reaches
+int launch_reach_mask(State &st, const int32_t *src_pos, int src_begin, int src_count, double R, unsigned char *mask, size_t bytes_one_layout);
+int launch_reach_count(State &st, const unsigned char *mask, size_t bytes_both_layouts, unsigned long long *out_dev);
 
 } // namespace asora

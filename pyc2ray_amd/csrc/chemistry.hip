@@ -204,6 +204,7 @@ __global__ void __launch_bounds__(CH_THREADS, ASORA_CHEM_MIN_WAVES) chemistry_ti
     __shared__ unsigned int rc[CH_THREADS];
 
     const int N = p.N;
+    const int NL = (N + 7) >> 3;                                   // lines of 8 cells per row (ChemTileParams::reach_a / reach_t)
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
     const int kb = blockIdx.x * 32, ib = p.i_begin + blockIdx.z * 32;
     ChemParams cp;
@@ -223,8 +224,10 @@ __global__ void __launch_bounds__(CH_THREADS, ASORA_CHEM_MIN_WAVES) chemistry_ti
                 const int k = kb + r, i = ib + tx;
                 if (k < N && i < p.i_end) {
                     const size_t o = ((size_t)k * N + j) * N + i;
-                    tile_g[r][tx] = p.gamma_t[o];
-                    if (EMIT) p.zero_t[o] = 0.0;
+                    // a line no source reaches holds zeros in both accumulator pairs and keeps them: neither read nor zeroed
+                    const bool reached = !p.reach_t || p.reach_t[((size_t)k * N + j) * NL + (i >> 3)] != 0;
+                    tile_g[r][tx] = reached ? p.gamma_t[o] : 0.0;
+                    if (EMIT && reached) p.zero_t[o] = 0.0;
                 }
             }
             __syncthreads();
@@ -233,9 +236,10 @@ __global__ void __launch_bounds__(CH_THREADS, ASORA_CHEM_MIN_WAVES) chemistry_ti
             const int i = ib + r, k = kb + tx;
             if (i < p.i_end && k < N) {
                 const size_t idx = ((size_t)i * N + j) * N + k;
-                double g = p.gamma[idx];
+                const bool reached = !FOLD || !p.reach_a || p.reach_a[((size_t)i * N + j) * NL + (k >> 3)] != 0;
+                double g = reached ? p.gamma[idx] : 0.0;
                 if (FOLD) { g += tile_g[tx][r]; if (p.phi_out) p.phi_out[idx] = g; }
-                if (EMIT) p.zero_a[idx] = 0.0;
+                if (EMIT && reached) p.zero_a[idx] = 0.0;
                 const double n = p.ndens[idx];
                 double xav = p.xh_av_in[idx], xint;
                 if (!UNIFORM_T) temperature_factors(cp, p.temp[idx], tf);

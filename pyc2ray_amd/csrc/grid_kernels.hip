@@ -2,6 +2,9 @@
 // transposes, the folds of the z-faces' transposed rate accumulator.  All streaming, tiled 32 x 32 through LDS.
 #include "asora_internal.hpp"
 
+#include <algorithm>
+#include <cmath>
+
 namespace asora {
 
 // ---------------------------------------------------------------------------------------------
@@ -182,5 +185,69 @@ int launch_transpose(State &st, const double *src, double *dst, int N)
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Lines of the rate accumulators the sources can touch (State::reach_mask)
+// ---------------------------------------------------------------------------------------------
+// One thread per (source, transverse offset pair (u, v) of the square [-S, S]^2, layout): the chord of the sphere |d|^2 <= R2hi
+// along the layout's contiguous axis at that (u, v), marked line by line.  A SUPERSET of what the raytrace rates (no periodic
+// window, no octahedron bound, the generous radius of the geometry tables): a line marked in vain only costs its 32 bytes.
+__global__ void __launch_bounds__(256) reach_mask_kernel(const int32_t *__restrict__ src_pos, int src_begin, int src_count, int N, int NL,
+                                                         int S, double R2hi, unsigned char *__restrict__ mask, size_t bytes_one_layout)
+{
+    const int side = 2 * S + 1;
+    const long per_src = 2L * side * side;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= per_src * src_count) return;
+    const int s = src_begin + (int)(t / per_src);
+    const int r = (int)(t % per_src);
+    const int layout = r / (side * side);
+    const int u = (r % (side * side)) / side - S, v = (r % side) - S;         // u: offset along the slowest axis of the layout, v: along j
+    const double rest = R2hi - (double)u * u - (double)v * v;
+    if (rest < 0.0) return;
+    int half = (int)floor(sqrt(rest));
+    if (half > N / 2) half = N / 2;                                           // (the whole axis)
+    const int i0 = src_pos[3 * s], j0 = src_pos[3 * s + 1], k0 = src_pos[3 * s + 2];
+    // layout 0: line (i, j, k >> 3), chord along k;  layout 1: line (k, j, i >> 3), chord along i
+    const int outer0 = layout == 0 ? i0 : k0, fast0 = layout == 0 ? k0 : i0;
+    int outer = (outer0 + u) % N; if (outer < 0) outer += N;
+    int j = (j0 + v) % N; if (j < 0) j += N;
+    unsigned char *row = mask + (size_t)layout * bytes_one_layout + ((size_t)outer * N + j) * NL;
+    for (int c = -half; c <= half; ++c) {
+        int f = (fast0 + c) % N; if (f < 0) f += N;
+        row[f >> 3] = 1;                                                       // (every writer writes 1)
+    }
+}
+
+// number of marked lines (both layouts)
+__global__ void __launch_bounds__(256) reach_count_kernel(const unsigned char *__restrict__ mask, size_t n, unsigned long long *out)
+{
+    unsigned int c = 0;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) c += mask[q];
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
+int launch_reach_count(State &st, const unsigned char *mask, size_t bytes_both_layouts, unsigned long long *out_dev)
+{
+    ASORA_HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(unsigned long long), st.stream));
+    hipLaunchKernelGGL(reach_count_kernel, dim3(1024), dim3(256), 0, st.stream, mask, bytes_both_layouts, out_dev);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_reach_mask(State &st, const int32_t *src_pos, int src_begin, int src_count, double R, unsigned char *mask, size_t bytes_one_layout)
+{
+    ASORA_HIP_TRY(hipMemsetAsync(mask, 0, 2 * bytes_one_layout, st.stream));
+    if (src_count <= 0) return 0;
+    const int N = st.N, NL = (N + 7) / 8;
+    const double R2hi = R * R * (1.0 + 1e-9) + 1e-9;                          // as the geometry tables' outer bound (geometry.hip)
+    const int S = (int)std::min((double)(N / 2), std::floor(std::sqrt(R2hi)));
+    const long threads = 2L * (2 * S + 1) * (2 * S + 1) * src_count;
+    hipLaunchKernelGGL(reach_mask_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st.stream, src_pos, src_begin, src_count, N, NL,
+                       S, R2hi, mask, bytes_one_layout);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
 
 } // namespace asora

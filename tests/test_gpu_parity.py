@@ -1105,6 +1105,81 @@ def test_device_resident_loop_equals_the_step_by_step_loop(asora, N, ns, R, monk
     assert open(tmp_path / "log8").read().count("Number of non-converged points") == niter_ref
 
 
+def test_fused_pass_skips_only_lines_no_source_reaches(asora):
+    """Round 4: the fused pass neither reads nor zeroes the 64-byte lines of the rate accumulators that no source of the step can
+    touch (State::reach_mask, built per (source upload, source range, R)).  A sequence of time steps ON ONE DEVICE STATE that
+    walks through every transition -- same sources again (mask and accumulators reused as they stand), another source range, another
+    radius, a radius that covers the box (mask off), back to a small one, a new upload, sources at the corners (wrap) -- each
+    step through the device-resident loop against raytrace_device + chemistry_device called separately from the same start:
+    iteration by iteration the same convergence numbers, at the end the same fields and rates.  A line left dirty by an
+    earlier step, or a line of the sphere the mask misses, shows up as a wrong rate."""
+    p, lib, capi = asora
+    N = 40
+    thin, thick, dlog = cases.soft_tables(600)
+    nd, xh0, dr = cases.grid(N, "lognormal", 91, 0.4, xlo=1e-4, xhi=2e-3)
+    temp = np.full((N, N, N), 1e4)
+    rng = np.random.default_rng(92)
+    numtau = thin.shape[0]
+    chem = (3.15576e13 * 2, cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C)
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 8)
+    p.photo_table_to_device(thin, thick)
+    lib.grid_to_device(capi.GRID_NDENS, nd)
+    lib.grid_to_device(capi.GRID_TEMP, temp)
+
+    def upload(ns, corners=False):
+        pos = 1 + rng.integers(0, N, size=(3, ns))
+        if corners:
+            pos[:, 0] = [1, 1, 1]; pos[:, 1] = [N, N, N]; pos[:, 2] = [1, N, 20]
+        flux = rng.uniform(0.5, 2.0, size=ns) * 2e-3
+        p0, f0 = cases.flat_sources(pos, flux)
+        lib.source_data_to_device(p0, f0, ns)
+
+    def separate(x_start, R, begin, count, iters):
+        lib.grid_to_device(capi.GRID_XH, x_start)
+        lib.grid_copy(capi.GRID_XH_AV, capi.GRID_XH)
+        lib.grid_copy(capi.GRID_XH_INTERMED, capi.GRID_XH)
+        rows = []
+        for _ in range(iters):
+            lib.raytrace_device(R, cases.SIG, dr, begin, count, cases.MINLOGTAU, dlog, numtau)
+            rows.append(lib.chemistry_device(*chem))
+        return (rows, lib.grid_to_host(capi.GRID_XH_INTERMED, np.empty((N, N, N))), lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N))))
+
+    def fused(x_start, R, begin, count, iters):
+        lib.grid_to_device(capi.GRID_XH, x_start)
+        lib.evolve_begin(*chem, R, cases.SIG, dr, cases.MINLOGTAU, dlog, numtau, begin, count, -1.0, 0.0)
+        lib.evolve_enqueue(iters)
+        n_done, _, rows = lib.evolve_poll(iters)
+        assert n_done == iters
+        return (rows, lib.grid_to_host(capi.GRID_XH_INTERMED, np.empty((N, N, N))), lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N))))
+
+    upload(9)
+    x = xh0
+    plan = [(3.0, 0, 9, 3, None), (3.0, 0, 9, 2, None),          # the same sources twice: everything reused
+            (3.0, 2, 4, 3, None),                                # a sub-range: other lines
+            (6.5, 0, 9, 2, None),                                # a larger radius
+            (1000.0, 0, 9, 2, None),                             # the whole box: mask off
+            (2.0, 0, 9, 3, None),                                # back to a small radius
+            (4.0, 0, 5, 3, (5, True)),                           # new upload, sources on the corners (periodic wrap)
+            (4.0, 0, 5, 1, None), (1.0, 1, 3, 2, None)]
+    for step, (R, begin, count, iters, new_sources) in enumerate(plan):
+        if new_sources:
+            upload(*new_sources)
+        f_rows, f_x, f_phi = fused(x, R, begin, count, iters)
+        s_rows, s_x, s_phi = separate(x, R, begin, count, iters)
+        tag = f"step {step}: R={R} sources [{begin},{begin + count}) iterations {iters}"
+        for it in range(iters):
+            assert int(f_rows[it][0]) == s_rows[it][0], tag
+            np.testing.assert_allclose(f_rows[it][1:3], s_rows[it][1:3], rtol=1e-12, err_msg=tag)
+        np.testing.assert_allclose(f_x, s_x, rtol=1e-10, atol=0, err_msg=tag)
+        w = s_phi != 0
+        assert np.array_equal(f_phi != 0, w), (tag, np.argwhere((f_phi != 0) != w)[:6].tolist())
+        np.testing.assert_allclose(f_phi[w], s_phi[w], rtol=1e-10, atol=0, err_msg=tag)
+        x = s_x
+    p.device_close()
+
+
 def test_uniform_temperature_form_of_the_chemistry_pass_is_bit_identical(asora):
     """A temperature grid found uniform at upload is not read again and its pow/sqrt/exp factors are evaluated once on
     the device; the general form (forced by ASORA_OPT_NO_UNIFORM_T) must give the same bits.  And a grid that is uniform
