@@ -217,33 +217,8 @@ extern "C" __device__ double asora_buffer_atomic_fadd_f64(double, __amdgpu_buffe
 #define ASORA_PAIR_MIN_WAVES 1
 #endif
 
-// Cache hints on the kernel's STREAMS (round 4).  A step's table entries (32 B per lane, read once per workgroup) and nHI (read
-// once per source that reaches the cell) pass through the CU's 32 KB L1 on their way and push out the lines of the rate tables,
-// whose lookups are the only divergent accesses of the loop.  1: the table entries are loaded non-temporally (`nt`: served from the
-// L2, not allocated in the L1); 2: nHI as well.
-#ifndef ASORA_NT_STREAMS
-#define ASORA_NT_STREAMS 0
-#endif
-__device__ __forceinline__ uint4 load_table_entry(const uint4 *__restrict__ p)
-{
-#if ASORA_NT_STREAMS >= 1
-    // (four dwords: clang's nontemporal builtin takes scalars and vectors of them)
-    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-    const u4 v = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(p));
-    return uint4{v.x, v.y, v.z, v.w};
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ double load_nhi(const double *__restrict__ p)
-{
-#if ASORA_NT_STREAMS >= 2
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
-
+// (round 4: non-temporal loads for the table-entry and nHI streams were measured and are slower -- the workgroups of a CU and of an
+//  XCD share those lines through the L1 and L2: LABNOTES.md)
 // (the flag bits of a table entry, CELL_*: asora_internal.hpp)
 
 // GREY (ASORA_OPT_GREY_NOTABLES) is a compile-time variant although its branch is wave-uniform: the compiler counts the
@@ -517,8 +492,8 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
 #if ASORA_STEP_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);      // nothing of this step is scheduled into the previous one (see the macro)
 #endif
-        pf_A = load_table_entry(cellA + e_pf);                      // two steps ahead
-        pf_B = load_table_entry(cellB + e_pf);
+        pf_A = cellA[e_pf];                      // two steps ahead
+        pf_B = cellB[e_pf];
 #ifdef ASORA_DIAG_EXTRA_TABLE_LOAD      // diagnostic build only: 16 more bytes per lane and step from ANOTHER unit's table (equal sizes: octants)
         {
             const uint4 extra = p.geom[(unit + 1) % p.units].cellA[e_pf];
@@ -526,7 +501,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
         }
 #endif
 #pragma unroll
-        for (int q = 0; q < NSRC; ++q) nxt_nhi[q] = load_nhi(nhi_address(q, nxt_A.x, nxt_A.y, nxt_idx[q]));          // one step ahead
+        for (int q = 0; q < NSRC; ++q) nxt_nhi[q] = *nhi_address(q, nxt_A.x, nxt_A.y, nxt_idx[q]);          // one step ahead
 
         const bool valid = (cur_A.y & CELL_VALID) != 0;
         // waves whose 64 entries are all padding skip the arithmetic (wave-uniform branch)
@@ -816,15 +791,15 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     // SUBBOX: the steps of this launch's sub-box only (whole triples: the tables are padded at every box boundary)
     const int k_first = SUBBOX ? p.sb_k0[unit] : 0, k_last = SUBBOX ? p.sb_k1[unit] : nsteps;
     unsigned e = (unsigned)k_first * RT_THREADS + threadIdx.x;
-    uint4 A0 = load_table_entry(cellA + e), B0 = load_table_entry(cellB + e);
-    uint4 A1 = load_table_entry(cellA + e + RT_THREADS), B1 = load_table_entry(cellB + e + RT_THREADS);
+    uint4 A0 = cellA[e], B0 = cellB[e];
+    uint4 A1 = cellA[e + RT_THREADS], B1 = cellB[e + RT_THREADS];
     uint4 A2, B2;
     unsigned idx0[NSRC], idx1[NSRC], idx2[NSRC];
     double nhi0[NSRC], nhi1[NSRC], nhi2[NSRC];
 #pragma unroll
     for (int q = 0; q < NSRC; ++q) {
         idx1[q] = idx2[q] = 0; nhi1[q] = nhi2[q] = 0.0;
-        nhi0[q] = load_nhi(nhi_address(q, A0.x, A0.y, idx0[q]));
+        nhi0[q] = *nhi_address(q, A0.x, A0.y, idx0[q]);
     }
 #if ASORA_LATE_LOOKUP && ASORA_PRIME_PIPELINE
     // The loop is entered with the loads in flight that a step leaves behind, in the same order (tables, nHI, two lookups):
