@@ -3,6 +3,8 @@
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1, no launcher: bench.py starts the line above as a CHILD process
+                                                        before it touches the GPU, relays the JSON line and the exit code)
 
 One "step" = one outer iteration of evolve3D (pyc2ray/evolve.py:168-240) on device-resident inputs, in its steady
 state: raytrace all of this rank's sources, [N>1: exchange the rates between ranks,] one chemistry pass with its
@@ -108,33 +110,61 @@ def workload_label(kind, N, nsrc_total, R, world, strong):
             "raytrace + one chemistry pass per step")
 
 
-PMC_SUMMARY = os.path.join("profiles", "r04_pmc_summary.txt")
 # 64-B atomic requests per second the memory side takes from no-return global_atomic_add_f64 (rows of 8 ... 4096 doubles at any
 # alignment, scattered over 2 x 256^3 doubles): tools/micro/atomic_rate.hip, measured on MI355X
 ATOMIC_REQUEST_CEILING = 2.28e10
 ATOMIC_CEILING_SOURCE = os.path.join("profiles", "r04_atomic_rate_microbench.txt")
 
 
-def pmc_counters(kernel):
-    """Mean per launch of every counter the committed PMC summary of this round holds for `kernel` (rocprofv3 --pmc
-    passes of this same command, one counter group per pass; tools/pmc.sh)."""
-    path = os.path.join(ROOT, PMC_SUMMARY)
+def find_pmc_summary(build_id):
+    """(path relative to the repository, None) of the newest committed counter summary collected ON THIS BUILD of the library
+    (profiles/rNN_pmc_summary*.txt whose header holds `# build_id <asora_build_id()>`; tools/pmc.sh writes it), or
+    (None, reason).  A summary of another build is never paired with this run's timings: editing a kernel without re-running
+    tools/pmc.sh makes `traffic` null, with the reason in the JSON."""
+    import glob
+    import re
+    cands = []
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_pmc_summary*.txt")):
+        ident = None
+        with open(path) as f:
+            for line in f:
+                if not line.startswith("#"):
+                    break
+                m = re.match(r"#\s*build_id\s+(\S+)", line)
+                if m:
+                    ident = m.group(1)
+        rnd = int(re.match(r"r(\d+)", os.path.basename(path)).group(1))
+        cands.append((rnd, os.path.getmtime(path), path, ident))
+    match = sorted(c for c in cands if c[3] == build_id)
+    if match:
+        return os.path.relpath(match[-1][2], ROOT), None
+    if not cands:
+        return None, "no counter summary under profiles/"
+    newest = sorted(cands)[-1]
+    return None, (f"no committed counter summary was collected on this build of the library (asora_build_id {build_id}); the newest, "
+                  f"{os.path.relpath(newest[2], ROOT)}, names build {newest[3] or 'none (collected before build ids existed)'}: "
+                  "re-run tools/pmc.sh on the current library")
+
+
+def pmc_counters(kernel, summary):
+    """Mean per launch of every counter the counter summary `summary` holds for `kernel` (rocprofv3 --pmc passes of this same
+    command, one counter group per pass; tools/pmc.sh)."""
     out = {}
-    if not os.path.exists(path):
+    if not summary:
         return out
-    for line in open(path):
+    for line in open(os.path.join(ROOT, summary)):
         parts = line.split()
         if len(parts) >= 4 and parts[0].startswith(kernel):
             out[parts[1]] = float(parts[-1].split("=")[1])
     return out
 
 
-def pmc_traffic_bytes(kernel):
+def pmc_traffic_bytes(kernel, summary):
     """HBM bytes per launch of `kernel`: FETCH_SIZE and WRITE_SIZE collected in separate passes; the counters are in
     KiB and FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes for gfx950 -- the doubling was
     checked on this repository's streaming chemistry kernel, whose 2*FETCH_SIZE equals its N^3 float64 loads exactly.
     None when the summary does not hold the counters."""
-    c = pmc_counters(kernel)
+    c = pmc_counters(kernel, summary)
     if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         return None
     return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
@@ -165,50 +195,82 @@ def cpu_baseline(kind, N, ndens, xh, temp, dr, pos, flux, thin, thick, dlog, R, 
     return use_ref, ns, t_rt, t_chem
 
 
-# ---- all host cores: independent processes over sources (the reference is single-threaded, sources are independent)
+# ---- one socket's cores: independent single-threaded processes over sources (the reference is single-threaded,
+# raytracing.f90:177, and sources are independent)
 def _cpu_worker():
-    """`python bench.py --cpu-worker`: one host core's share of the CPU sample.  Reads its job (one JSON line),
-    prepares the inputs, reports "ready", waits for "go", then times the reference raytracer on its sources and
-    one global_pass on its slab of the grid.  Never touches the GPU."""
+    """`python bench.py --cpu-worker`: one host core's share of the CPU sample.  Reads its job (one JSON line), maps the
+    inputs -- ndens, xh, temp as READ-ONLY memory maps of the files the parent wrote once (shared by all workers: a worker
+    owns only the three N^3 output grids the reference's routine fills) --, reports "ready", waits for "go", then times the
+    reference raytracer on its sources and one global_pass on its slab of the grid.  Never touches the GPU."""
     job = json.loads(sys.stdin.readline())
     from oracle import ref_fortran as F
     from oracle import oracle as O
-    mod = F if F.available() else O
-    N = job["N"]
-    ndens, xh, temp, dr, pos, flux = make_workload(job["kind"], N, job["nsrc_total"])
-    t = np.load(job["tables"])
-    thin, thick, dlog = t["thin"], t["thick"], float(t["dlog"])
+    use_ref = F.available()
+    mod = F if use_ref else O
+    d = job["dir"]
+    ndens, xh, temp = (np.load(os.path.join(d, n + ".npy"), mmap_mode="r") for n in ("ndens", "xh", "temp"))
+    meta = np.load(os.path.join(d, "meta.npz"))
+    thin, thick, dlog, dr, pos, flux = meta["thin"], meta["thick"], float(meta["dlog"]), float(meta["dr"]), meta["pos"], meta["flux"]
     lo, hi = job["sources"]
     a, b = job["planes"]
-    nd_f, xh_f = np.asfortranarray(ndens), np.asfortranarray(xh)
     sl = lambda g: np.asfortranarray(g[a:b])
     Ri = int(np.ceil(job["R"]))
+    extra = {"copy_xh_av": False} if use_ref else {}
     print("ready", flush=True)
     sys.stdin.readline()
     t0 = time.time()
-    r = mod.do_all_sources(flux[lo:hi], pos[:, lo:hi], max_subbox=Ri, subboxsize=Ri, sig=SIG, dr=dr, ndens=nd_f,
-                           xh_av=xh_f, loss_fraction=0.0, thin=thin, thick=thick, minlogtau=MINLOGTAU, dlogtau=dlog,
-                           R_max_LLS=job["R"], NumTau=thin.shape[0] - 1)
+    r = mod.do_all_sources(flux[lo:hi], pos[:, lo:hi], max_subbox=Ri, subboxsize=Ri, sig=SIG, dr=dr, ndens=ndens,
+                           xh_av=xh, loss_fraction=0.0, thin=thin, thick=thick, minlogtau=MINLOGTAU, dlogtau=dlog,
+                           R_max_LLS=job["R"], NumTau=thin.shape[0] - 1, **extra)
     t1 = time.time()
-    mod.global_pass(MYR, sl(ndens), sl(temp), sl(xh), sl(xh), sl(xh), sl(r["phi_ion"]), BH00, ALBPOW, COLH0, TEMPH0, ABU_C)
+    if b > a:
+        mod.global_pass(MYR, sl(ndens), sl(temp), sl(xh), sl(xh), sl(xh), sl(r["phi_ion"]), BH00, ALBPOW, COLH0, TEMPH0, ABU_C)
     t2 = time.time()
-    print(json.dumps({"t_rt": t1 - t0, "t_chem": t2 - t1, "sources": hi - lo, "reference": bool(F.available())}), flush=True)
+    print(json.dumps({"t_rt": t1 - t0, "t_chem": t2 - t1, "sources": hi - lo, "reference": bool(use_ref)}), flush=True)
 
 
-def start_cpu_workers(cores, kind, N, nsrc_total, R, sample_sources, tables_path):
-    """Started BEFORE anything initialises the GPU in this process (no exec afterwards)."""
+def usable_memory_bytes():
+    """What this process may still allocate: MemAvailable, or less when the control group says so."""
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        cur = int(open("/sys/fs/cgroup/memory.current").read())
+        if lim != "max":
+            room = int(lim) - cur
+            avail = room if avail is None else min(avail, room)
+    except (OSError, ValueError):
+        pass
+    return avail
+
+
+def start_cpu_workers(cores, workload, N, R, sample_sources, tables):
+    """Started BEFORE anything initialises the GPU in this process (no exec afterwards).  `workload` = (ndens, xh, temp, dr, pos,
+    flux): written once, Fortran-ordered, to a directory in shared memory that every worker maps read-only."""
     import subprocess
+    import tempfile
+    ndens, xh, temp, dr, pos, flux = workload
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="pyc2ray_amd_bench_", dir=shm)
+    for name, g in (("ndens", ndens), ("xh", xh), ("temp", temp)):
+        np.save(os.path.join(d, name + ".npy"), np.asfortranarray(g))
+    np.savez(os.path.join(d, "meta.npz"), thin=tables[0], thick=tables[1], dlog=tables[2], dr=dr, pos=pos, flux=flux)
     procs = []
     for w in range(cores):
-        job = {"kind": kind, "N": N, "nsrc_total": nsrc_total, "R": R, "tables": tables_path,
+        job = {"dir": d, "N": N, "R": R,
                "sources": [w * sample_sources // cores, (w + 1) * sample_sources // cores],
                "planes": [w * N // cores, (w + 1) * N // cores]}
         pr = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker"], stdin=subprocess.PIPE,
-                              stdout=subprocess.PIPE, text=True, cwd=ROOT)
+                              stdout=subprocess.PIPE, text=True, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="1"))
         pr.stdin.write(json.dumps(job) + "\n")
         pr.stdin.flush()
         procs.append(pr)
-    return procs
+    return procs, d
 
 
 def run_cpu_workers(procs):
@@ -314,10 +376,155 @@ def evolving_state(lib, p, _capi, N, R, thin, thick, dlog, numtau, flux_scale=1e
     }
 
 
+def host_topology():
+    """What the host offers this process: logical CPUs and sockets of the machine (/proc/cpuinfo), physical cores per socket,
+    the CPUs this process may run on (affinity) and the CPU share its control group grants (cgroup quota), whichever is
+    tighter -- a container on a big host sees all of the host's CPUs in /proc/cpuinfo but is throttled to its share."""
+    logical, sockets, cores = 0, {}, set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                logical += 1
+                phys = core = None
+            elif line.startswith("physical id"):
+                phys = int(line.split(":")[1])
+                sockets[phys] = sockets.get(phys, 0) + 1
+            elif line.startswith("core id") and phys is not None:
+                cores.add((phys, int(line.split(":")[1])))
+    except OSError:
+        pass
+    logical = logical or (os.cpu_count() or 1)
+    n_sock = max(1, len(sockets))
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = logical
+    quota = None
+    try:                                   # cgroup v2, then v1
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = q / per if q > 0 else None
+        except (OSError, ValueError):
+            pass
+    share = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
+    phys_per_socket = (len(cores) // n_sock) if cores else max(1, logical // n_sock)
+    return {"logical_cpus": logical, "sockets": n_sock, "logical_cpus_per_socket": max(1, logical // n_sock),
+            "physical_cores_per_socket": max(1, phys_per_socket), "affinity_cpus": affinity, "cgroup_cpu_quota": quota,
+            "usable_cpus": share}
+
+
+def self_launch(gpus, argv, timeout_s):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment): start
+    `python -m torch.distributed.run --standalone --nnodes=1 --nproc-per-node N bench.py <same arguments>` as a CHILD process --
+    before this process has imported anything that touches the GPU, and never by replacing this process --, pass rank 0's
+    single JSON line through to stdout, and exit with the child's return code.  A child that fails or prints no JSON line
+    gives a non-zero exit with the tail of its stderr; a child that outlives `timeout_s` is killed (its whole process
+    group) and the exit code is 124.  (pyc2ray's own multi-rank test needs an external mpirun,
+    test/unit_tests_hackathon/4_multiple_sources_mpi/run_test.py:30-34; this one does not.)"""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, PYC2RAY_AMD_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print("bench: --gpus %d without a launcher: starting %s" % (gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env,
+                             start_new_session=True)
+    tail, lines = [], []
+
+    def pump_err():
+        for line in child.stderr:
+            sys.stderr.write(line)
+            sys.stderr.flush()
+            tail.append(line)
+            del tail[:-60]
+
+    def pump_out():
+        for line in child.stdout:
+            lines.append(line)
+    threads = [threading.Thread(target=pump_err, daemon=True), threading.Thread(target=pump_out, daemon=True)]
+    for t in threads:
+        t.start()
+    try:
+        rc = child.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        child.wait()
+        print(f"bench: the {gpus}-rank child did not finish within {timeout_s:g} s and was killed", file=sys.stderr, flush=True)
+        return 124
+    for t in threads:
+        t.join(timeout=10)
+    found = None
+    for line in lines:
+        try:
+            d = json.loads(line)
+        except ValueError:
+            continue
+        if isinstance(d, dict) and ("metric" in d or "launch_check" in d):
+            found = line.strip()
+    if rc != 0:
+        print(f"bench: the {gpus}-rank child exited with code {rc}; last lines of its stderr:\n" + "".join(tail[-25:]),
+              file=sys.stderr, flush=True)
+        return rc
+    if found is None:
+        print("bench: the child exited with code 0 but printed no JSON line; its stdout was:\n" + "".join(lines[-20:]),
+              file=sys.stderr, flush=True)
+        return 1
+    print(found, flush=True)
+    return 0
+
+
+def launch_check(fail_rank):
+    """`--launch-check [RANK]`: every rank brings the process group up (the backend bench.py would use), sums one number over
+    the ranks and rank 0 prints one JSON line -- the launch path of an N-rank run without its measurement (CPU test of the
+    self-launch: tests/test_dist_gloo.py).  With RANK >= 0 that rank raises instead, to show how a failing rank ends the run."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("PYC2RAY_AMD_BENCH_BACKEND", "nccl")
+    if rank == fail_rank:
+        raise SystemExit(f"bench --launch-check: rank {rank} fails on request")
+    if os.environ.get("PYC2RAY_AMD_BENCH_TEST_HANG") == "1":        # (tests: a child that never finishes)
+        time.sleep(3600)
+    import torch
+    import torch.distributed as dist
+    from pyc2ray_amd.dist import init_process_group_from_env
+    os.environ.setdefault("PYC2RAY_AMD_DIST_TIMEOUT_S", "60")
+    init_process_group_from_env(backend)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(t)
+    ok = float(t.item()) == world * (world + 1) / 2.0
+    if rank == 0:
+        print(json.dumps({"launch_check": bool(ok), "world_size_reported_by_backend": dist.get_world_size(), "backend": backend,
+                          "self_launched": os.environ.get("PYC2RAY_AMD_BENCH_SELF_LAUNCHED", "0") == "1",
+                          "visible_gpus": torch.cuda.device_count(), "host": host_topology()}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
+
+
 def main():
     if "--cpu-worker" in sys.argv:
         return _cpu_worker()
     ap = argparse.ArgumentParser()
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="--gpus N > 1 started without a launcher: seconds the self-launched N-rank child may take")
+    ap.add_argument("--launch-check", type=int, nargs="?", const=-1, default=None, metavar="FAILING_RANK",
+                    help="only bring the ranks up, sum one number over them and print one JSON line (the launch path without the "
+                         "measurement); with a rank number that rank fails on purpose")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -337,9 +544,11 @@ def main():
     ap.add_argument("--R", type=float, default=32.0)
     ap.add_argument("--workload", choices=["uniform", "cosmo"], default=None,
                     help="default: uniform (configs[2]) on one GPU, cosmo (configs[3]) on several")
-    ap.add_argument("--cpu-sources", type=int, default=64, help="sources in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sources", type=int, default=512,
+                    help="sources in the single-core CPU-baseline sample (0 = skip): 512 = ~11 s of the reference Fortran + 1 s for its pass")
     ap.add_argument("--cpu-cores", type=int, default=0,
-                    help="host cores for the all-cores CPU figure (0 = min(8, cores available); 1 = skip it)")
+                    help="worker processes of the one-socket CPU figure (0 = the physical cores of one socket, as far as this "
+                         "process may use them; 1 = skip it)")
     ap.add_argument("--z-transposed", type=int, default=1)
     ap.add_argument("--block-threads", type=int, default=0, help="raytrace workgroup size (0 = auto)")
     ap.add_argument("--overlap", type=int, default=-1,
@@ -358,33 +567,46 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around this process: be the launcher (nothing has touched the GPU yet; the N ranks are children)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:], args.launch_timeout))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.launch_check is not None:
+        return launch_check(args.launch_check)
     N, K, W = args.N, args.steps, args.warmup
     if args.workload is None:
         args.workload = "uniform" if world == 1 else "cosmo"
     strong = world > 1 and args.scaling == "strong"
     nsrc_total = args.nsrc if (strong or world == 1) else args.nsrc * world
 
-    # the all-cores CPU sample runs in worker processes that are started now, before this process touches the GPU,
-    # and sit idle until the GPU measurement is over
-    cpu_workers, cpu_cores, tables_path = None, 1, None
+    # the one-socket CPU sample runs in worker processes that are started now, before this process touches the GPU,
+    # and sit idle until the GPU measurement is over.  Worker count: the physical cores of ONE socket of this host
+    # (north_star: "single-socket Fortran CPU"), or fewer when this process may not use that many CPUs (affinity, cgroup
+    # quota) or when the host's free memory does not hold that many copies of the reference routine's three output grids
+    # -- the figure for the whole socket is then extrapolated linearly and labelled so.
+    cpu_workers, cpu_cores, cpu_dir = None, 1, None
     tables = None
+    workload = None
+    topo = host_topology()
+    cpu_note = None
     if world == 1 and args.cpu_sources > 0 and args.cpu_cores != 1:
         try:
-            avail = len(os.sched_getaffinity(0))
-            cpu_cores = args.cpu_cores if args.cpu_cores > 1 else min(8, avail)
+            socket_cores = topo["physical_cores_per_socket"]
+            cpu_cores = args.cpu_cores if args.cpu_cores > 1 else min(socket_cores, topo["usable_cpus"])
+            per_worker = 3.3 * 8.0 * N ** 3 + 3.0e8            # phi_ion, coldensh_out, touched part of phi_heat + the interpreter
+            room = usable_memory_bytes()
+            if room is not None and cpu_cores * per_worker > 0.5 * room:
+                capped = max(1, int(0.5 * room / per_worker))
+                cpu_note = f"{cpu_cores} workers wanted, {capped} fit half of the {room / 2**30:.0f} GiB this process may use"
+                cpu_cores = capped
             if cpu_cores > 1:
-                import tempfile
                 tables = make_tables()
-                fd, tables_path = tempfile.mkstemp(suffix=".npz")
-                os.close(fd)
-                np.savez(tables_path, thin=tables[0], thick=tables[1], dlog=tables[2])
-                cpu_workers = start_cpu_workers(cpu_cores, args.workload, N, args.nsrc, args.R,
-                                                max(args.cpu_sources, cpu_cores), tables_path)
+                workload = make_workload(args.workload, N, nsrc_total)
+                cpu_workers, cpu_dir = start_cpu_workers(cpu_cores, workload, N, args.R,
+                                                         min(nsrc_total, max(args.cpu_sources, 16 * cpu_cores)), tables)
         except Exception as e:
-            print(f"bench: all-cores CPU sample not started: {type(e).__name__}: {e}", file=sys.stderr)
+            print(f"bench: one-socket CPU sample not started: {type(e).__name__}: {e}", file=sys.stderr)
             cpu_workers = None
 
     import pyc2ray_amd as p
@@ -410,23 +632,59 @@ def main():
         os.environ.setdefault("PYC2RAY_AMD_DIST_TIMEOUT_S", "180")     # a collective that never completes ends the run after 3 minutes
         init_process_group_from_env(backend)
         comm = TorchComm()
-        # what the links of THIS job deliver, through the calls the two exchange schemes use (16 MiB point-to-point ring, all-reduce
-        # of one N^3 grid): `--exchange auto` decides from these, not from assumed rates; identical numbers on every rank
+
+        def all_ranks_ok(ok):
+            """MIN over the ranks of a yes/no: every rank takes the same branch afterwards."""
+            flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return float(flag.item()) != 0.0
+
+        # Gate 1, before anything else uses the point-to-point path: the slab exchange has never run between real GPUs on the
+        # build box (it has one).  One small ring of sends and receives through the same torch call; any rank that fails or
+        # receives a wrong payload sends EVERY rank to the all-reduce path (MIN vote).
+        p2p_ok = True
+        try:
+            p2p_ok = comm.preflight_p2p(N * N)
+        except Exception as e:
+            print(f"bench: point-to-point preflight failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
+            p2p_ok = False
+        p2p_ok = all_ranks_ok(p2p_ok)
+        # What the links of THIS job deliver, through the calls the two exchange schemes use (16 MiB point-to-point ring -- only
+        # if the preflight went through --, all-reduce of one N^3 grid): `--exchange auto` decides from these, not from assumed
+        # rates.  A failure on ANY rank makes every rank drop the measurement (vote), and rank 0's numbers are broadcast, so
+        # every rank derives the same exchange choice from the same numbers.
         links = None
         try:
-            links = comm.measure_links(p2p_bytes=16 << 20, allreduce_bytes=8 * N ** 3)
+            links = comm.measure_links(p2p_bytes=16 << 20, allreduce_bytes=8 * N ** 3, p2p=p2p_ok)
         except Exception as e:
             print(f"bench: link measurement failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
+        if not all_ranks_ok(links is not None):
+            links = None
+        else:
+            box = [links]
+            dist.broadcast_object_list(box, src=0)
+            links = box[0]
 
+    visible_gpus, backend_world = None, None
+    try:
+        import torch as _t
+        visible_gpus = _t.cuda.device_count()
+        if comm is not None:
+            backend_world = dist.get_world_size()
+    except Exception:
+        pass
     lib = load_asora()
     p.device_init(N, 64, device_id=int(os.environ.get("PYC2RAY_AMD_BENCH_DEVICE", local_rank)))
     thin, thick, dlog = tables if tables is not None else make_tables()
     p.photo_table_to_device(thin, thick)
     numtau = thin.shape[0] - 1                  # as raytracing_benchmark/run_test.py:85 passes it
 
-    ndens, xh, temp, dr, pos, flux = make_workload(args.workload, N, nsrc_total)
+    ndens, xh, temp, dr, pos, flux = workload if workload is not None else make_workload(args.workload, N, nsrc_total)
     overlap = comm is not None and (args.overlap == 1 or (args.overlap < 0 and comm.overlap))
     slab = comm is not None and args.exchange in ("slab", "auto") and not overlap
+    fell_back = None
+    if slab and not p2p_ok:
+        slab, fell_back = False, "point-to-point preflight"
     exchange_model = None
     src_i0 = None
     plan = None
@@ -515,22 +773,43 @@ def main():
     # N>1: the SAME workload -- the whole source list on the same density -- on ONE GPU, inside this job: rank 0 alone, through
     # the one-GPU loop, while the other ranks wait at a barrier.  The denominator of `speedup_vs_one_gpu` (a `--gpus 1` run
     # of this script measures configs[2], another workload).
-    one_gpu_ms = None
+    one_gpu_ms, one_gpu_how = None, None
     if comm is not None and args.one_gpu_reference:
         if rank == 0:
             try:
+                # bounded: the other ranks wait at a barrier whose timeout is PYC2RAY_AMD_DIST_TIMEOUT_S.  One iteration is timed
+                # first; the full protocol (warm-up + `repeats` regions of K steps) runs only if it fits a fifth of that
+                # timeout, else one region of min(K, 3) steps, else that single iteration is the figure.
+                budget = 0.2 * float(os.environ.get("PYC2RAY_AMD_DIST_TIMEOUT_S", "180"))
                 pa, fa = format_sources(pos, flux)
                 lib.source_data_to_device(pa, fa, flux.shape[0])
                 lib.evolve_begin(*chem, args.R, SIG, dr, MINLOGTAU, dlog, numtau, 0, flux.shape[0], -1.0, 0.0)
-                one_gpu_region(flux.shape[0], 1 + W)
-                regs = []
-                for _ in range(max(1, args.repeats)):
-                    lib.synchronize()
-                    t0 = time.perf_counter()
-                    one_gpu_region(flux.shape[0], K)
-                    lib.synchronize()
-                    regs.append(time.perf_counter() - t0)
-                one_gpu_ms = float(np.median(regs)) / K * 1e3
+                one_gpu_region(flux.shape[0], 1)
+                lib.synchronize()
+                t0 = time.perf_counter()
+                one_gpu_region(flux.shape[0], 1)
+                lib.synchronize()
+                t_one = time.perf_counter() - t0
+                reps_ = max(1, args.repeats)
+                if t_one * (W + K * reps_) <= budget:
+                    plan_, how = (W, K, reps_), f"{reps_} regions of {K} steps after {W} warm-up steps, median"
+                elif t_one * min(K, 3) <= budget:
+                    plan_, how = (0, min(K, 3), 1), f"one region of {min(K, 3)} steps (the full protocol would not fit {budget:.0f} s)"
+                else:
+                    plan_, how = None, "a single iteration (one iteration takes %.1f s)" % t_one
+                if plan_ is None:
+                    one_gpu_ms = t_one * 1e3
+                else:
+                    one_gpu_region(flux.shape[0], plan_[0]) if plan_[0] else None
+                    regs = []
+                    for _ in range(plan_[2]):
+                        lib.synchronize()
+                        t0 = time.perf_counter()
+                        one_gpu_region(flux.shape[0], plan_[1])
+                        lib.synchronize()
+                        regs.append((time.perf_counter() - t0) / plan_[1])
+                    one_gpu_ms = float(np.median(regs)) * 1e3
+                one_gpu_how = how
             except Exception as e:
                 print(f"bench: one-GPU reference run failed: {type(e).__name__}: {e}", file=sys.stderr)
         comm.Barrier()
@@ -565,39 +844,23 @@ def main():
             comm.Barrier()
             torch.cuda.synchronize()
 
-    fell_back = None
     if comm is not None and state["slab"]:
-        # The point-to-point exchange has never run between real GPUs (the build box has one).  Two gates, each followed by
-        # a vote (MIN over the ranks): a one-plane ring of sends and receives through the same torch call, then the first
-        # full step.  If either raises or delivers a wrong payload on ANY rank, every rank takes the full-grid all-reduce
-        # (any partition of the sources is fine for it) instead of losing the run; which path ran, and why, is in the JSON
-        # (`config.parallelism`, `config.exchange_fallback`).  Nothing is re-executed: the process keeps its GPU context.
-        import torch
-        import torch.distributed as dist
-
-        def all_ranks_ok(ok):
-            flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            return float(flag.item()) != 0.0
-
-        for gate in ("point-to-point preflight", "first slab step"):
-            ok = True
-            try:
-                if gate == "point-to-point preflight":
-                    ok = comm.preflight_p2p(N * N)
-                else:
-                    begin_time_step(); step(); fence()
-            except Exception as e:
-                print(f"bench: {gate} failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
-                ok = False
-            if not all_ranks_ok(ok):
-                state["slab"] = False
-                slab = False
-                comm.exchange = "allreduce"
-                fell_back = gate
-                if exchange_model is not None:
-                    exchange_model["choice"] = "allreduce (fallback)"
-                break
+        # Gate 2: the first full slab step, followed by the same vote.  If it raises on ANY rank, every rank takes the full-grid
+        # all-reduce (any partition of the sources is fine for it) instead of losing the run; which path ran, and why, is in
+        # the JSON (`config.parallelism`, `config.exchange_fallback`).  Nothing is re-executed: the process keeps its GPU context.
+        ok = True
+        try:
+            begin_time_step(); step(); fence()
+        except Exception as e:
+            print(f"bench: first slab step failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
+            ok = False
+        if not all_ranks_ok(ok):
+            state["slab"] = False
+            slab = False
+            comm.exchange = "allreduce"
+            fell_back = "first slab step"
+            if exchange_model is not None:
+                exchange_model["choice"] = "allreduce (fallback)"
     # the FIRST iteration of a time step additionally forms nHI from xh and zeroes the accumulators on the whole grid
     begin_time_step(); step(); fence()
     t0 = time.perf_counter()
@@ -704,7 +967,11 @@ def main():
     achieved_all32 = RT_BYTES_PER_UPDATE * gamma_cells / rt_launch_s / 1e9 if rt_n else None
     insphere = 4.0 * np.pi * args.R ** 3 / 3.0
     default_job = (args.workload == "uniform" and args.R == 32.0 and N == 256 and args.nsrc == 1000 and world == 1)
-    rt_counters = pmc_counters("raytrace_octant_kernel") if default_job else {}
+    # counters: only from a committed summary collected on THIS build of the library (find_pmc_summary)
+    build_id = lib.build_id()
+    pmc_summary, pmc_missing = find_pmc_summary(build_id) if default_job else (None, "counters are committed for the default job only")
+    PMC_SUMMARY = pmc_summary or "(no counter summary of this build)"
+    rt_counters = pmc_counters("raytrace_octant_kernel", pmc_summary)
     ch_launch_s = (ch_ms / max(ch_n, 1)) * 1e-3
     chem_cells = N ** 3 if (comm is None or not slab) else (plan.own[0][1] - plan.own[0][0]) * N * N
     ch_achieved = CHEM_BYTES_PER_UPDATE * chem_cells / ch_launch_s / 1e9 if ch_n else None
@@ -736,6 +1003,11 @@ def main():
         "config": {
             "workload": workload_label(args.workload, N, nsrc_total, args.R, world, strong),
             "grid": N, "sources_total": nsrc_total, "sources_rank0": n_local, "R_cells": args.R, "numtau": NUMTAU,
+            "host_cores": topo["logical_cpus"], "host_cpus_this_process_may_use": topo["usable_cpus"],
+            "visible_gpus": visible_gpus, "world_size_reported_by_backend": backend_world,
+            "launched_by": ("bench.py itself (child torch.distributed.run)" if os.environ.get("PYC2RAY_AMD_BENCH_SELF_LAUNCHED") == "1"
+                            else "an external launcher" if "WORLD_SIZE" in os.environ else "plain python"),
+            "library_build_id": lib.build_id(),
             "ranks_agree_on_rates_and_ionised_fraction": ranks_agree,
             "parallelism": ("single GPU" if world == 1 else
                             f"sources sharded over {world} ranks by slab of the first coordinate; rates sent plane-wise to the "
@@ -771,10 +1043,13 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-            "traffic": pmc_traffic_bytes("raytrace_octant_kernel") if default_job else None,
+            "traffic": pmc_traffic_bytes("raytrace_octant_kernel", pmc_summary),
             "traffic_source": (PMC_SUMMARY + ": (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch, separate rocprofv3 --pmc "
-                               "passes of this command on this workload (a committed measurement, not collected in this run)")
-                              if default_job else None,
+                               "passes of this command on this workload, collected on the build of the library that ran here "
+                               f"(asora_build_id {build_id}); a committed measurement, not collected in this run")
+                              if pmc_summary else None,
+            "traffic_unavailable": pmc_missing,
+            "library_build_id": build_id,
             "algorithmic_bytes_per_launch": rt_bytes,
             "frac_if_every_pair_counted_32B": (achieved_all32 / HBM_PEAK_GBS) if achieved_all32 else None,
             "bytes_accounting": "32 B per rate-receiving pair; 16 B for a pair whose exactly-zero rate is not added "
@@ -789,13 +1064,13 @@ def main():
                                  % (rt_counters.get("TCC_EA0_ATOMIC_sum", float("nan")), PMC_SUMMARY,
                                     gamma_cells / rt_counters.get("TCC_EA0_ATOMIC_sum", float("nan")), ATOMIC_REQUEST_CEILING,
                                     ATOMIC_CEILING_SOURCE, rt_counters.get("SQ_INSTS_VALU", float("nan"))))
-                                if default_job else None,
+                                if (default_job and "TCC_EA0_ATOMIC_sum" in rt_counters) else None,
         },
         "roofline_kernels": [
             {"kernel": "raytrace_octant_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "bytes_per_unit": RT_BYTES_PER_UPDATE,
              "units_per_launch": gamma_cells, "avg_launch_ms": rt_ms / max(rt_n, 1), "share_of_step": (rt_ms / n_timed) / (elapsed / K * 1e3),
-             "counter_bytes": pmc_traffic_bytes("raytrace_octant_kernel") if default_job else None,
+             "counter_bytes": pmc_traffic_bytes("raytrace_octant_kernel", pmc_summary),
              # secondary line ("FP64-vector utilisation ... may make the raytrace compute-bound before HBM"): VALU
              # wave-instructions per launch from the committed counters over this run's launch time, against one wave-instruction
              # per SIMD every 4 cycles (1024 SIMDs at the 2.4 GHz maximum clock, MI355X_MICROARCH.md)
@@ -813,7 +1088,7 @@ def main():
             {"kernel": "chemistry_tile_kernel", "bound": "hbm", "achieved": ch_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": (ch_achieved / HBM_PEAK_GBS) if ch_achieved else None, "bytes_per_unit": CHEM_BYTES_PER_UPDATE,
              "units_per_launch": chem_cells, "avg_launch_ms": ch_ms / max(ch_n, 1), "share_of_step": (ch_ms / n_timed) / (elapsed / K * 1e3),
-             "counter_bytes": pmc_traffic_bytes("chemistry_tile_kernel") if default_job else None,
+             "counter_bytes": pmc_traffic_bytes("chemistry_tile_kernel", pmc_summary),
              "bytes_moved_per_unit": CHEM_FUSED_BYTES_PER_UPDATE if comm is None else CHEM_BYTES_PER_UPDATE,
              "moved_GBs": ch_actual,
              "note": "the fused pass also folds the two rate accumulators, writes nHI in both layouts for the next raytrace and "
@@ -832,8 +1107,8 @@ def main():
         out["one_gpu_same_workload_ms_per_step"] = one_gpu_ms
         out["speedup_vs_one_gpu"] = (one_gpu_ms / ms_step) if one_gpu_ms else None
         out["one_gpu_same_workload_note"] = ("rank 0 alone, the whole source list of THIS workload through the one-GPU loop "
-                                             "(asora_evolve_enqueue + one poll per %d steps), same steps/repeats, while the other "
-                                             "ranks waited at a barrier; speedup = that / ms_per_step" % poll_every)
+                                             "(asora_evolve_enqueue + one poll per %d steps): %s, while the other "
+                                             "ranks waited at a barrier; speedup = that / ms_per_step" % (poll_every, one_gpu_how))
         out["phases_ms"] = phases_ms
         out["phases_note"] = ("mean per step over the timed regions, MAX over the ranks; slab exchange: spans between HIP events on the "
                               "library's stream (wait_rates_add = what the rate exchange left un-hidden + the adds; xh_av_exchange is "
@@ -864,6 +1139,10 @@ def main():
         except Exception as e:   # the baseline is reporting only; never let it hide the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "cell-updates/s", "cores": 1, "kind": "port",
                                    "sample": f"failed: {type(e).__name__}: {e}"}
+        if isinstance(out.get("cpu_baseline"), dict):
+            out["cpu_baseline"].update({"host_cores_total": topo["logical_cpus"], "sockets": topo["sockets"],
+                                        "physical_cores_per_socket": topo["physical_cores_per_socket"],
+                                        "cpus_this_process_may_use": topo["usable_cpus"]})
         if cpu_workers:
             try:
                 wall, res = run_cpu_workers(cpu_workers)
@@ -871,20 +1150,35 @@ def main():
                 wall_rt = max(r["t_rt"] for r in res)
                 wall_chem = max(r["t_chem"] for r in res)
                 t_job = wall_rt * (args.nsrc / ns_all) + wall_chem
+                socket_cores = topo["physical_cores_per_socket"]
+                whole = cpu_cores >= socket_cores
+                v = (gamma_cells + N ** 3) / t_job
                 out["cpu_baseline"]["all_cores"] = {
-                    "value": (gamma_cells + N ** 3) / t_job, "unit": "cell-updates/s", "cores": cpu_cores,
+                    "value": v, "unit": "cell-updates/s", "cores": cpu_cores,
                     "kind": "reference" if all(r["reference"] for r in res) else "port",
-                    "sample": (f"{cpu_cores} independent single-threaded processes, one per core: {ns_all} of {args.nsrc} "
-                               f"sources raytraced ({wall_rt:.2f} s for the slowest) and one global_pass over {N}^3 split "
-                               f"into {cpu_cores} slabs ({wall_chem:.2f} s); raytrace time scaled x{args.nsrc / ns_all:.1f}"),
+                    "socket_cores": socket_cores, "covers_one_socket": bool(whole),
+                    # fewer workers than the socket has cores (CPU share or memory of this process): the socket figure is the
+                    # measured one scaled by the core ratio -- an upper bound, memory bandwidth does not scale that well
+                    "one_socket_value": v if whole else v * socket_cores / cpu_cores,
+                    "one_socket_value_is": "measured" if whole else f"extrapolated x{socket_cores / cpu_cores:.2f} from {cpu_cores} cores",
+                    "gpu_over_one_socket": value / (v if whole else v * socket_cores / cpu_cores),
+                    "sample": (f"{cpu_cores} independent single-threaded processes (the reference is single-threaded, sources are "
+                               f"independent), one per physical core of ONE socket ({socket_cores} cores; host: {topo['sockets']} socket(s), "
+                               f"{topo['logical_cpus']} logical CPUs, this process may use {topo['usable_cpus']}"
+                               + (f"; {cpu_note}" if cpu_note else "") + f"): {ns_all} of {args.nsrc} "
+                               f"sources raytraced ({wall_rt:.2f} s for the slowest worker) and one global_pass over {N}^3 split "
+                               f"into {cpu_cores} slabs ({wall_chem:.2f} s); raytrace time scaled x{args.nsrc / ns_all:.1f}; inputs "
+                               "shared read-only between the workers"),
                 }
             except Exception as e:
                 out["cpu_baseline"]["all_cores"] = {"value": None, "sample": f"failed: {type(e).__name__}: {e}"}
-    if tables_path:
-        try:
-            os.unlink(tables_path)
-        except OSError:
-            pass
+    if cpu_workers:                       # never leave workers or their shared-memory files behind
+        for pr in cpu_workers:
+            if pr.poll() is None:
+                pr.kill()
+    if cpu_dir:
+        import shutil
+        shutil.rmtree(cpu_dir, ignore_errors=True)
     p.device_close()
     if saved_stdout is not None:
         sys.stdout.flush()

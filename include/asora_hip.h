@@ -344,6 +344,12 @@ int asora_last_raytrace_counts_ex(long long *gamma_cells, long long *evaluated_c
  * (the reference keeps it in cdh_dev, src/asora/memory.cu:20, and never downloads it). */
 int asora_debug_coldens(double R, double sig, double dr, int source_index, double *coldens_out, int N);
 
+/* Which build this is: a hash over every source and header of the library and the compiler flags (pyc2ray_amd/csrc/Makefile),
+ * and those flags.  Measurement hygiene, no reference counterpart: the committed counter summaries under profiles/ name the
+ * build they were collected on, and bench.py reports `traffic` only from a summary whose id equals this. */
+const char *asora_build_id(void);
+const char *asora_build_flags(void);
+
 #ifdef __cplusplus
 }
 #endif

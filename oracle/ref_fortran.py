@@ -47,11 +47,15 @@ def _i(x):
 
 def do_all_sources(normflux, srcpos, max_subbox, subboxsize, sig, dr, ndens, xh_av, loss_fraction,
                    thin, thick, minlogtau, dlogtau, R_max_LLS, heat_thin=None, heat_thick=None,
-                   NumTau=None):
-    """raytracing.f90:52 do_all_sources.  Same conventions as oracle.oracle.do_all_sources."""
+                   NumTau=None, copy_xh_av=True):
+    """raytracing.f90:52 do_all_sources.  Same conventions as oracle.oracle.do_all_sources.
+    copy_xh_av=False hands the caller's Fortran-ordered xh_av over as it is (the dummy is intent(inout), :68, but the
+    routine never writes it): bench.py's CPU workers share one read-only mapping of the grid that way."""
     N = ndens.shape[0]
     nd = np.asfortranarray(ndens, dtype=np.float64)
-    xh = np.asfortranarray(xh_av, dtype=np.float64).copy(order="F")
+    xh = np.asfortranarray(xh_av, dtype=np.float64)
+    if copy_xh_av or not xh.flags.f_contiguous:
+        xh = xh.copy(order="F")
     flux = np.ascontiguousarray(normflux, dtype=np.float64)
     pos = np.asfortranarray(np.asarray(srcpos).astype(np.int32))
     thin = np.ascontiguousarray(thin, dtype=np.float64)

@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libasora_hip.so")
+# PYC2RAY_AMD_LIBASORA selects another BUILD of the same HIP library (diagnostic variants made by
+# `make -C pyc2ray_amd/csrc EXTRA=... OUT=...`, tools/ab_prebuilt.sh): never a fallback -- a path that does not exist raises.
+LIB_PATH = os.environ.get("PYC2RAY_AMD_LIBASORA") or os.path.join(_HERE, "lib", "libasora_hip.so")
 
 # grid selectors / options / kernels, as in include/asora_hip.h
 GRID_NDENS, GRID_XH_AV, GRID_PHI_ION, GRID_TEMP, GRID_XH, GRID_XH_INTERMED, GRID_PHI_HEAT = range(7)
@@ -73,6 +75,8 @@ SIGNATURES = {
     "asora_last_raytrace_counts": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "asora_last_raytrace_counts_ex": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "asora_debug_coldens": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int, _dp, C.c_int]),
+    "asora_build_id": (C.c_char_p, []),
+    "asora_build_flags": (C.c_char_p, []),
 }
 
 _lib = None

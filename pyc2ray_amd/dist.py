@@ -433,12 +433,13 @@ class TorchComm:
         out["iterations"] = self._phase_n
         return out
 
-    def measure_links(self, p2p_bytes=16 << 20, allreduce_bytes=128 << 20, reps=3):
+    def measure_links(self, p2p_bytes=16 << 20, allreduce_bytes=128 << 20, reps=3, p2p=True):
         """What the links of THIS job deliver, through the calls the data path uses: a ring of point-to-point transfers of
         `p2p_bytes` (every rank sends to its right neighbour and receives from its left one with ``batch_isend_irecv``, as the
         slab exchange does) and an in-place sum all-reduce of `allreduce_bytes` (the full-grid exchange).  One untimed round
         each, then the fastest of `reps`; times are the MAXIMUM over the ranks, so every rank returns the same numbers and
-        derives the same choice from them.  Returns {"p2p_bytes", "p2p_ms", "p2p_GBs" (per link and direction),
+        derives the same choice from them.  p2p = False leaves the ring out (a caller whose point-to-point preflight failed:
+        the all-reduce time is still worth having).  Returns {"p2p_bytes", "p2p_ms", "p2p_GBs" (per link and direction),
         "allreduce_bytes", "allreduce_ms", "allreduce_busbw_GBs" (2 (P-1)/P bytes / time, the ring's per-link rate)}."""
         import time
         import torch
@@ -479,12 +480,12 @@ class TorchComm:
                    dist.P2POp(dist.irecv, rcv, (me - 1) % P, group=self._group)]
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-        t_p2p = timed(ring)
+        t_p2p = timed(ring) if p2p else None
         n2 = max(1, int(allreduce_bytes) // 8)
         buf = torch.zeros((n2,), dtype=torch.float64, device=dev)
         t_ar = timed(lambda: dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self._group))
         del buf, snd, rcv
-        out.update(p2p_ms=t_p2p * 1e3, p2p_GBs=8.0 * n1 / t_p2p / 1e9,
+        out.update(p2p_ms=t_p2p * 1e3 if p2p else None, p2p_GBs=8.0 * n1 / t_p2p / 1e9 if p2p else None,
                    allreduce_ms=t_ar * 1e3, allreduce_busbw_GBs=2.0 * (P - 1) / P * 8.0 * n2 / t_ar / 1e9)
         return out
 

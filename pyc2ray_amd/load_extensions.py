@@ -272,6 +272,10 @@ class _LibAsora:
         _capi.check(self._lib.asora_last_raytrace_counts_ex(C.byref(g), C.byref(e), C.byref(z)), "last_raytrace_counts_ex")
         return z.value
 
+    def build_id(self):
+        """Hash over the library's sources, headers and compiler flags (asora_build_id)."""
+        return self._lib.asora_build_id().decode()
+
     def debug_coldens(self, R, sig, dr, source_index, N):
         out = np.zeros((N, N, N))
         _capi.check(self._lib.asora_debug_coldens(float(R), float(sig), float(dr), int(source_index),

@@ -95,6 +95,54 @@ def test_two_ranks_match_single_process(tmp_path, mode):
     np.testing.assert_allclose(res[0]["phi"], phi_ref, rtol=rtol, atol=0)
 
 
+# ---- bench.py --gpus N without a launcher ----------------------------------------------------------
+def _bench(args, timeout=240, **env):
+    e = dict(os.environ, PYC2RAY_AMD_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env)
+    return subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py")] + args, env=e, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_launches_its_own_ranks(world):
+    """`python bench.py --gpus N` with no launcher around it starts its N ranks itself (a child torch.distributed.run), relays
+    rank 0's single JSON line and exits 0.  --launch-check runs the launch path without the measurement: process group up
+    over gloo, one sum over the ranks."""
+    import json
+    r = _bench(["--gpus", str(world), "--launch-check"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                       # ONE line on stdout, whatever the ranks and the launcher print
+    d = json.loads(lines[0])
+    assert d["launch_check"] is True and d["world_size_reported_by_backend"] == world and d["self_launched"] is True
+    assert d["host"]["logical_cpus"] >= 1 and d["host"]["sockets"] >= 1
+
+
+def test_bench_self_launch_reports_a_failing_rank():
+    """A rank that fails ends the run with a non-zero exit code and the child's stderr, well inside the timeout; nothing that
+    looks like a result reaches stdout."""
+    import time
+    t0 = time.time()
+    r = _bench(["--gpus", "2", "--launch-check", "1"], PYC2RAY_AMD_DIST_TIMEOUT_S="20")
+    assert r.returncode != 0 and time.time() - t0 < 120
+    assert "fails on request" in r.stderr and r.stdout.strip() == ""
+
+
+def test_bench_self_launch_kills_a_child_that_hangs():
+    """--launch-timeout bounds the child: rank 1 never joins the group here (it fails on request while rank 0 waits for it
+    with a long collective timeout), the launcher is killed with its ranks and the exit code is 124 or the child's own."""
+    r = _bench(["--gpus", "2", "--launch-check", "--launch-timeout", "8"], PYC2RAY_AMD_BENCH_TEST_HANG="1")
+    assert r.returncode == 124, (r.returncode, r.stderr[-2000:])
+    assert r.stdout.strip() == ""
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    r = _bench(["--gpus", "2", "--launch-check"], WORLD_SIZE="3", RANK="0")
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr
+
+
 # ---- slab exchange (pyc2ray_amd.dist.SlabPlan): rates to the owners of the planes, slab chemistry, xh_av back -------
 def test_slab_plan_covers_what_the_sources_reach():
     """Pure bookkeeping: for random source sets, radii and rank counts, every plane a rank's sources can rate lies in

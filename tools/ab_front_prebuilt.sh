@@ -1,9 +1,7 @@
 # A/B of prebuilt library variants on the EVOLVING field (tools/chem_front.py): bash tools/ab_front_prebuilt.sh "nt0 nt1 nt2"
 cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun exports it) to the repository root}" || exit 1
-cp pyc2ray_amd/lib/libasora_hip.so build/variants/libasora_default_saved.so
-trap 'cp build/variants/libasora_default_saved.so pyc2ray_amd/lib/libasora_hip.so' EXIT
 for ROUND in 1 2; do for V in $1; do
-  cp build/variants/libasora_$V.so pyc2ray_amd/lib/libasora_hip.so
+  export PYC2RAY_AMD_LIBASORA=$PWD/build/variants/libasora_$V.so
   timeout -k 10 300 python tools/chem_front.py --histogram 0 2>/dev/null | tail -1 > gpurun_out/abf.json
   python -c "
 import json,numpy as np;d=json.load(open('gpurun_out/abf.json'))

@@ -1,10 +1,8 @@
 # Scratch driver for one-off A/B runs on the GPU box (edited per experiment; results are recorded in profiles/r02_*.txt).
 # This version: prebuilt variants, 20 timed steps each, four rounds, radii as arguments after the variant list
-cp pyc2ray_amd/lib/libasora_hip.so build/variants/libasora_default_saved.so
-trap 'cp build/variants/libasora_default_saved.so pyc2ray_amd/lib/libasora_hip.so' EXIT
 NAMES=$1; shift
 for ROUND in 1 2 3 4; do for V in $NAMES; do
-  cp build/variants/libasora_$V.so pyc2ray_amd/lib/libasora_hip.so
+  export PYC2RAY_AMD_LIBASORA=$PWD/build/variants/libasora_$V.so
   for RR in "$@"; do
     python bench.py --steps 20 --warmup 5 --cpu-sources 0 --R $RR 2>/dev/null > gpurun_out/one.json
     python -c "

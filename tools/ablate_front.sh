@@ -2,9 +2,7 @@
 # the prebuilt diagnostic library (build/variants/libasora_abl.so; wrong results by design): what the incoherent table lookups, the
 # atomics and the nHI loads cost there.  usage (GPU box): bash tools/ablate_front.sh "0 1 8 9 128"
 cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun exports it) to the repository root}" || exit 1
-cp pyc2ray_amd/lib/libasora_hip.so build/variants/libasora_default_saved.so
-trap 'cp build/variants/libasora_default_saved.so pyc2ray_amd/lib/libasora_hip.so' EXIT
-cp build/variants/libasora_abl.so pyc2ray_amd/lib/libasora_hip.so
+export PYC2RAY_AMD_LIBASORA=$PWD/build/variants/libasora_abl.so
 for A in $1; do
   ASORA_ABLATE=$A timeout -k 10 300 python tools/chem_front.py --histogram 0 2>/dev/null | tail -1 > gpurun_out/abl_front.json
   python -c "

@@ -13,8 +13,12 @@ for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VA
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_${TAG}_$i -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sources 0 --evolving-state 0 "$@" > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1 || echo "pmc pass $i failed"
 done
 python3 - <<PY
-import csv,glob,collections
+import csv,glob,collections,ctypes,os
 out=open("$R/gpurun_out/pmc_${TAG}_summary.txt","w")
+# the build of the library these counters belong to (asora_build_id: hash of its sources, headers and flags); bench.py
+# only pairs a summary with timings of the same build
+_l=ctypes.CDLL(os.environ.get("PYC2RAY_AMD_LIBASORA") or "$R/pyc2ray_amd/lib/libasora_hip.so"); _l.asora_build_id.restype=ctypes.c_char_p
+out.write("# build_id %s\n" % _l.asora_build_id().decode())
 out.write("# rocprofv3 --kernel-trace --pmc <group> -- python3 bench.py --steps 2 --warmup 1 --cpu-sources 0 --evolving-state 0 $*\n")
 out.write("# kernel  counter  launches  mean per launch (FETCH_SIZE / WRITE_SIZE in KiB)\n")
 for d in sorted(glob.glob("$R/gpurun_out/pmc_${TAG}_[0-9]*/")):
