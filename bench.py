@@ -9,7 +9,7 @@
 One "step" = one outer iteration of evolve3D (pyc2ray/evolve.py:168-240) on device-resident inputs, in its steady
 state: raytrace all of this rank's sources, [N>1: exchange the rates between ranks,] one chemistry pass with its
 convergence reductions -- the same launches evolve3D makes per iteration (asora_evolve_enqueue on one GPU,
-TorchComm.slab_iteration on several).  The convergence test is evaluated but can never pass (criterion -1), so
+TorchComm.slab_enqueue on several).  The convergence test is evaluated but can never pass (criterion -1), so
 every step does its full work.  The FIRST iteration of a time step additionally forms nHI from xh and zeroes the
 accumulators; its time is reported beside (config.first_iteration_of_a_time_step_ms).
 
@@ -814,22 +814,34 @@ def main():
                 print(f"bench: one-GPU reference run failed: {type(e).__name__}: {e}", file=sys.stderr)
         comm.Barrier()
     lib.source_data_to_device(p0, f0, n_local)
-    state = {"first": True, "slab": slab}
+    state = {"slab": slab, "unpolled": 0, "rows": []}
 
     def begin_time_step():
         # conv_criterion = -1 and convergence_fraction = 0 can never be met: every enqueued iteration does its work
         if comm is None:
             lib.evolve_begin(*chem, args.R, SIG, dr, MINLOGTAU, dlog, numtau, 0, n_local, -1.0, 0.0)
+        elif state["slab"]:
+            poll_slab()
+            comm.slab_begin(lib, plan, N, args.R, SIG, dr, n_local, MINLOGTAU, dlog, numtau, chem, -1.0, 0.0)
         else:
             lib.grid_copy(_capi.GRID_XH_AV, _capi.GRID_XH)              # evolve.py:136-137
             lib.grid_copy(_capi.GRID_XH_INTERMED, _capi.GRID_XH)
-            state["first"] = True
+
+    def poll_slab():
+        """What evolve3D_MPI does once per batch of iterations: status read-back + fold of the own rates (asora_evolve_poll)."""
+        if state["unpolled"]:
+            _, _, r_ = comm.slab_poll(lib, poll_every)
+            state["unpolled"] = 0
+            if len(r_):
+                state["rows"] = r_
 
     def step():
-        if state["slab"]:              # what evolve3D_MPI does per outer iteration with a TorchComm
-            r = comm.slab_iteration(lib, plan, N, args.R, SIG, dr, n_local, MINLOGTAU, dlog, numtau, chem, state["first"])
-            state["first"] = False
-            return r
+        if state["slab"]:              # what evolve3D_MPI does per outer iteration with a TorchComm: the sharded device loop
+            comm.slab_enqueue(lib, 1)
+            state["unpolled"] += 1
+            if state["unpolled"] >= poll_every:
+                poll_slab()
+            return (state["rows"][-1][:3] if len(state["rows"]) else None)
         if comm is not None:           # full-grid all-reduce (optionally pipelined), chemistry on every rank
             return comm.raytrace_and_allreduce(lib, N, args.R, SIG, dr, n_local, MINLOGTAU, dlog, numtau,
                                                src_i0=src_i0, chemistry=chem)
@@ -837,6 +849,8 @@ def main():
         return None
 
     def fence():
+        if comm is not None and state["slab"]:
+            poll_slab()                # a region ends with the poll of its last batch, as on one GPU
         lib.synchronize()
         if comm is not None:
             import torch
@@ -907,6 +921,10 @@ def main():
     gamma_cells, eval_cells = lib.last_raytrace_counts()
     zero_cells = lib.last_raytrace_zero_rates()
     if slab:
+        # the counters of the sharded device loop run on from slab_begin, like the one-GPU loop's
+        n_done, _, _ = comm.slab_poll(lib, 0)
+        n_done = max(n_done, 1)
+        gamma_cells, eval_cells, zero_cells = gamma_cells // n_done, eval_cells // n_done, zero_cells // n_done
         comm.slab_gather(lib, plan, _capi.GRID_XH_INTERMED, N)
         comm.slab_gather(lib, plan, _capi.GRID_PHI_ION, N)
     if comm is None:
@@ -975,7 +993,8 @@ def main():
     ch_launch_s = (ch_ms / max(ch_n, 1)) * 1e-3
     chem_cells = N ** 3 if (comm is None or not slab) else (plan.own[0][1] - plan.own[0][0]) * N * N
     ch_achieved = CHEM_BYTES_PER_UPDATE * chem_cells / ch_launch_s / 1e9 if ch_n else None
-    ch_actual = (CHEM_FUSED_BYTES_PER_UPDATE if comm is None else CHEM_BYTES_PER_UPDATE) * chem_cells / ch_launch_s / 1e9 if ch_n else None
+    fused_pass = comm is None or slab           # (the sharded device loop runs the same fused pass on the own planes)
+    ch_actual = (CHEM_FUSED_BYTES_PER_UPDATE if fused_pass else CHEM_BYTES_PER_UPDATE) * chem_cells / ch_launch_s / 1e9 if ch_n else None
     comm_bytes = None
     if slab:
         comm_bytes = 2 * max(sum(plan.bytes_per_rank(r)) for r in range(world))     # two exchanges, sent + received
@@ -1033,8 +1052,10 @@ def main():
                                 "trace, next accumulators zeroed) + convergence test on the device; and, once per %d steps as in "
                                 "evolve3D's loop, asora_evolve_poll inside the timed region (status read-back + fold of the last "
                                 "iteration's rate accumulators into phi_ion)" % poll_every) if comm is None else
-                               "one outer iteration of evolve3D_MPI through the calls it makes (TorchComm.slab_iteration or "
-                               "raytrace_and_allreduce): see phases_ms",
+                               "one outer iteration of evolve3D_MPI through the calls it makes (TorchComm.slab_enqueue -- the sharded "
+                               "device loop: trace, rates to the owners, ONE fused pass on the own planes, xh_av back, convergence test "
+                               "on the device -- with one slab_poll per %d steps inside the timed region; or raytrace_and_allreduce): "
+                               "see phases_ms" % poll_every,
         },
         "roofline": {
             "bound": "hbm",
@@ -1089,7 +1110,7 @@ def main():
              "frac": (ch_achieved / HBM_PEAK_GBS) if ch_achieved else None, "bytes_per_unit": CHEM_BYTES_PER_UPDATE,
              "units_per_launch": chem_cells, "avg_launch_ms": ch_ms / max(ch_n, 1), "share_of_step": (ch_ms / n_timed) / (elapsed / K * 1e3),
              "counter_bytes": pmc_traffic_bytes("chemistry_tile_kernel", pmc_summary),
-             "bytes_moved_per_unit": CHEM_FUSED_BYTES_PER_UPDATE if comm is None else CHEM_BYTES_PER_UPDATE,
+             "bytes_moved_per_unit": CHEM_FUSED_BYTES_PER_UPDATE if fused_pass else CHEM_BYTES_PER_UPDATE,
              "moved_GBs": ch_actual,
              "note": "the fused pass also folds the two rate accumulators, writes nHI in both layouts for the next raytrace and "
                      "zeroes the accumulators: 88 B per cell move through HBM (uniform temperature: that grid is not read; the folded rates are not stored), of which 56 B are "
@@ -1111,7 +1132,7 @@ def main():
                                              "ranks waited at a barrier; speedup = that / ms_per_step" % (poll_every, one_gpu_how))
         out["phases_ms"] = phases_ms
         out["phases_note"] = ("mean per step over the timed regions, MAX over the ranks; slab exchange: spans between HIP events on the "
-                              "library's stream (wait_rates_add = what the rate exchange left un-hidden + the adds; xh_av_exchange is "
+                              "library's stream (wait_rates_add = what the rate exchange left un-hidden + the adds; xh_av_exchange_nhi is "
                               "serial by construction), all-reduce path: wall clock between the host synchronisations of its three calls")
         out["measured_link_GBs"] = links
     if world == 1 and (args.evolving_state == 1 or (args.evolving_state < 0 and default_job)):

@@ -230,6 +230,41 @@ int asora_evolve_begin(double dt, double bh00, double albpow, double colh0, doub
 int asora_evolve_enqueue(int iterations);
 int asora_evolve_poll(int *niter, int *converged, double *history, int history_rows, int *rows_written);
 
+/* The same device-resident loop with the sources sharded over several GPUs (pyc2ray/evolve.py:249-498 evolve3D_MPI: sources cut
+ * into contiguous blocks :360-371, rate grids summed over the ranks every iteration :433-437, results broadcast :480-497).
+ * Here a rank traces its block of sources, owns the chemistry of the planes [own_begin, own_begin + own_count), sends the
+ * rates it traced onto other ranks' planes to their owners and receives the new xh_av of the foreign planes its sources
+ * reach (pyc2ray_amd/dist.py: SlabPlan, TorchComm).  One iteration, all calls asynchronous on asora_stream():
+ *   asora_evolve_slab_trace       traces sources [src_begin, src_begin + src_count) of the step (one call, or one per chunk)
+ *   asora_evolve_slab_fold_out    planes owned by ANOTHER rank: the rates traced onto them are summed over the two accumulator
+ *                                 layouts into the out-box (asora_evolve_slab_outbox(): an N^3 grid, plane i at i*N*N), from
+ *                                 where the caller sends them; the accumulators of the NEXT iteration are zeroed there
+ *   asora_evolve_slab_add         rates received for OWN planes (a device buffer of i_count*N*N doubles; _add_host: a host
+ *                                 buffer), added in call order
+ *   asora_evolve_slab_pass        the fused pass of the one-GPU loop on the own planes (rates folded, chemistry, nHI of the new
+ *                                 xh_av in both layouts, next accumulators zeroed); leaves THIS RANK'S {sum x, sum 1-x, conv_flag}
+ *                                 at asora_reduction_ptr()
+ *   asora_evolve_slab_nhi         planes whose new xh_av has just arrived in ASORA_GRID_XH_AV: nHI for the next trace
+ *   asora_evolve_slab_close       host_sums = NULL: the caller has summed the three doubles at asora_reduction_ptr() over the
+ *                                 ranks IN PLACE (one all-reduce ordered on asora_stream()); else the three sums over all ranks,
+ *                                 from the host.  Evaluates the convergence test of evolve.py:216-236 on them on the device.
+ * Every launch is gated by the device's `done` flag, so -- as on one GPU -- several iterations can be enqueued per
+ * asora_evolve_poll, and every rank, working from identical sums, stops at the same iteration.  asora_evolve_poll folds the last
+ * iteration's rates into ASORA_GRID_PHI_ION (complete on the own planes).  ASORA_GRID_XH_INTERMED / _XH_AV: own planes. */
+int asora_evolve_begin_slab(double dt, double bh00, double albpow, double colh0, double temph0, double abu_c,
+                            double R, double sig, double dr, double minlogtau, double dlogtau, int NumTau,
+                            int src_begin, int src_count, double conv_criterion, double convergence_fraction,
+                            int own_begin, int own_count);
+int asora_evolve_slab_trace(int src_begin, int src_count);
+int asora_evolve_slab_fold_out(int i_begin, int i_count);
+void *asora_evolve_slab_outbox(void);
+int asora_evolve_slab_outbox_to_host(int i_begin, int i_count, double *host);
+int asora_evolve_slab_add(int i_begin, int i_count, const double *dev_planes);
+int asora_evolve_slab_add_host(int i_begin, int i_count, const double *host_planes);
+int asora_evolve_slab_pass(void);
+int asora_evolve_slab_nhi(int i_begin, int i_count);
+int asora_evolve_slab_close(const double *host_sums);
+
 /* Runs of i-planes [i_begin, i_begin + i_count) of a grid to / from a host buffer of i_count*N*N doubles (C order).
  * What multi-GPU ranks exchange are such runs: the planes a rank's sources reach, the planes whose chemistry it owns. */
 int asora_planes_to_host(int which, int i_begin, int i_count, double *host);

@@ -65,6 +65,16 @@ SIGNATURES = {
     "asora_evolve_begin": (C.c_int, [C.c_double] * 11 + [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]),
     "asora_evolve_enqueue": (C.c_int, [C.c_int]),
     "asora_evolve_poll": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_int, C.POINTER(C.c_int)]),
+    "asora_evolve_begin_slab": (C.c_int, [C.c_double] * 11 + [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]),
+    "asora_evolve_slab_trace": (C.c_int, [C.c_int, C.c_int]),
+    "asora_evolve_slab_fold_out": (C.c_int, [C.c_int, C.c_int]),
+    "asora_evolve_slab_outbox": (C.c_void_p, []),
+    "asora_evolve_slab_outbox_to_host": (C.c_int, [C.c_int, C.c_int, _dp]),
+    "asora_evolve_slab_add": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
+    "asora_evolve_slab_add_host": (C.c_int, [C.c_int, C.c_int, _dp]),
+    "asora_evolve_slab_pass": (C.c_int, []),
+    "asora_evolve_slab_nhi": (C.c_int, [C.c_int, C.c_int]),
+    "asora_evolve_slab_close": (C.c_int, [_dp]),
     "asora_planes_to_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp]),
     "asora_planes_to_device": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp]),
     "asora_set_option": (C.c_int, [C.c_int, C.c_int]),

@@ -1269,14 +1269,19 @@ int asora_subbox_raytrace_device(int max_subbox, int subboxsize, float loss_frac
 // The evolve loop on the device (pyc2ray/evolve.py:168-240): raytrace -> fused chemistry -> convergence test,
 // nothing in between and nothing on the host
 // ---------------------------------------------------------------------------------------------
-int asora_evolve_begin(double dt, double bh00, double albpow, double colh0, double temph0, double abu_c,
-                       double R, double sig, double dr, double minlogtau, double dlogtau, int NumTau,
-                       int src_begin, int src_count, double conv_criterion, double convergence_fraction)
+static int evolve_begin_impl(double dt, double bh00, double albpow, double colh0, double temph0, double abu_c,
+                             double R, double sig, double dr, double minlogtau, double dlogtau, int NumTau,
+                             int src_begin, int src_count, double conv_criterion, double convergence_fraction,
+                             bool slab, int own_begin, int own_count)
 {
     clear_error();
     if (int rc = require_init("evolve_begin")) return rc;
     State &st = g_state;
     st.ev_open = false;
+    if (slab) {
+        if (own_begin < 0 || own_count < 0 || own_begin + own_count > st.N) return fail(4, "evolve_begin_slab: bad range of own planes");
+        if (!st.opt[ASORA_OPT_Z_TRANSPOSED]) return fail(4, "evolve_begin_slab: needs the [k][j][i] twins (ASORA_OPT_Z_TRANSPOSED = 1)");
+    }
     static const int need[] = {ASORA_GRID_NDENS, ASORA_GRID_TEMP, ASORA_GRID_XH};
     for (int g : need)
         if (!st.grid_valid[g]) return fail(4, "evolve_begin: grid " + std::to_string(g) + " holds no data");
@@ -1305,7 +1310,16 @@ int asora_evolve_begin(double dt, double bh00, double albpow, double colh0, doub
     // BASELINE configurations gains, sparse runs (few sources, small radii) do.  Whenever the set of lines the
     // passes zero changes, BOTH pairs are zeroed once: the dirty pair of the previous step may hold rates where the new
     // sources do not reach.  Not for traces that cover (nearly) the whole box, nor with ASORA_REACH_MASK=0 (2: whenever built).
-    {
+    if (slab) {
+        // multi-GPU: the pass sweeps the own planes only and the out-box folds zero the foreign ones (asora_evolve_slab_fold_out);
+        // which planes those are changes with the plan, so a step simply starts from two zeroed pairs (256 MiB of stores at
+        // 256^3, once per time step), and no reach mask
+        if (!(st.ev_clean[0] && st.ev_clean[1])) {
+            ASORA_HIP_TRY(hipMemsetAsync(st.acc, 0, 4 * bytes, st.stream));
+            st.ev_clean[0] = st.ev_clean[1] = true;
+        }
+        st.reach_in_use = false;
+    } else {
         static const int mode = []() { const char *v = getenv("ASORA_REACH_MASK"); return v ? atoi(v) : 1; }();
         const bool possible = mode != 0 && std::isfinite(R) && 2.0 * R + 2.0 < (double)st.N && st.opt[ASORA_OPT_Z_TRANSPOSED] != 0;
         const bool same = st.reach_valid && st.reach_src_generation == st.src_generation && st.reach_src_begin == src_begin &&
@@ -1362,7 +1376,183 @@ int asora_evolve_begin(double dt, double bh00, double albpow, double colh0, doub
     st.ev_first = true;
     st.ev_reported = 0;
     st.ev_enqueued = 0;
+    st.ev_slab = slab; st.ev_own_begin = own_begin; st.ev_own_count = own_count; st.ev_slab_passed = false;
     st.ev_open = true;
+    return 0;
+}
+
+int asora_evolve_begin(double dt, double bh00, double albpow, double colh0, double temph0, double abu_c,
+                       double R, double sig, double dr, double minlogtau, double dlogtau, int NumTau,
+                       int src_begin, int src_count, double conv_criterion, double convergence_fraction)
+{
+    return evolve_begin_impl(dt, bh00, albpow, colh0, temph0, abu_c, R, sig, dr, minlogtau, dlogtau, NumTau, src_begin, src_count,
+                             conv_criterion, convergence_fraction, false, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same loop when the sources are sharded over several GPUs (pyc2ray/evolve.py:249-498; pyc2ray_amd/dist.py SlabPlan): a
+// rank traces ITS sources, owns the chemistry of ITS planes, and one iteration is the sequence
+//   asora_evolve_slab_trace      (once, or per chunk of sources)     -> rates into the iteration's accumulator pair
+//   asora_evolve_slab_fold_out   per run of foreign planes           -> out-box planes to send; the other pair zeroed there
+//   asora_evolve_slab_add        per run received from another rank  -> added to the own planes of the pair
+//   asora_evolve_slab_pass                                            -> the fused pass of the one-GPU loop on the own planes
+//   asora_evolve_slab_nhi        per run of xh_av received           -> nHI of the halo planes for the next trace
+//   asora_evolve_slab_close                                           -> convergence test on the sums over all ranks
+// all asynchronous on the library's stream and all gated by the status block's `done`, so that -- as on one GPU -- a caller
+// enqueues several iterations and reads the status back once (asora_evolve_poll; it folds the own rates into PHI_ION).
+// ---------------------------------------------------------------------------------------------
+int asora_evolve_begin_slab(double dt, double bh00, double albpow, double colh0, double temph0, double abu_c,
+                            double R, double sig, double dr, double minlogtau, double dlogtau, int NumTau,
+                            int src_begin, int src_count, double conv_criterion, double convergence_fraction,
+                            int own_begin, int own_count)
+{
+    return evolve_begin_impl(dt, bh00, albpow, colh0, temph0, abu_c, R, sig, dr, minlogtau, dlogtau, NumTau, src_begin, src_count,
+                             conv_criterion, convergence_fraction, true, own_begin, own_count);
+}
+
+static int require_slab(const char *who)
+{
+    if (int rc = require_init(who)) return rc;
+    if (!g_state.ev_open || !g_state.ev_slab)
+        return fail(4, std::string(who) + ": no multi-GPU evolve step in progress (call asora_evolve_begin_slab)");
+    if (g_state.ev_enqueued - g_state.ev_reported + 1 > EVOLVE_HIST)
+        return fail(4, std::string(who) + ": " + std::to_string(EVOLVE_HIST) + " iterations enqueued since the last asora_evolve_poll (poll first)");
+    return 0;
+}
+static double *slab_pair(int which)            // 0: the pair the current iteration traces into, 1: the other one
+{
+    State &st = g_state;
+    const int set = ((st.ev_base + st.ev_enqueued) & 1) ^ which;
+    return st.acc + (size_t)set * 2 * st.ncell;
+}
+
+int asora_evolve_slab_trace(int src_begin, int src_count)
+{
+    clear_error();
+    if (int rc = require_slab("evolve_slab_trace")) return rc;
+    State &st = g_state;
+    if (st.ev_slab_passed) return fail(4, "evolve_slab_trace: the iteration's pass has been enqueued already (close it first)");
+    if (src_begin < st.ev_src_begin || src_count < 0 || src_begin + src_count > st.ev_src_begin + st.ev_src_count)
+        return fail(4, "evolve_slab_trace: source range outside the step's sources");
+    if (src_count == 0) return 0;
+    st.ev_sets_known = false;
+    RtParams p = st.ev_rt;
+    p.phi = slab_pair(0);
+    p.src_begin = src_begin; p.src_count = src_count;          // (shape_src_count stays the rank's whole share: one launch shape)
+    if (!(src_begin == 0 && src_count == st.num_src)) { p.src_pos = st.src_pos; p.src_flux = st.src_flux; }
+    return launch_raytrace(st, p, false, false);
+}
+
+int asora_evolve_slab_fold_out(int i_begin, int i_count)
+{
+    clear_error();
+    if (int rc = require_slab("evolve_slab_fold_out")) return rc;
+    State &st = g_state;
+    if (i_begin < 0 || i_count < 0 || i_begin + i_count > st.N) return fail(4, "evolve_slab_fold_out: bad plane range");
+    st.ev_sets_known = false;
+    double *cur = slab_pair(0), *nxt = slab_pair(1);
+    return launch_fold_out(st, cur, cur + st.ncell, st.staging, nxt, nxt + st.ncell, i_begin, i_count, &st.ev_status->done);
+}
+
+void *asora_evolve_slab_outbox(void) { return g_state.init ? (void *)g_state.staging : nullptr; }
+
+int asora_evolve_slab_outbox_to_host(int i_begin, int i_count, double *host)
+{
+    clear_error();
+    if (int rc = require_init("evolve_slab_outbox_to_host")) return rc;
+    State &st = g_state;
+    if (i_begin < 0 || i_count < 0 || i_begin + i_count > st.N || (i_count > 0 && !host)) return fail(3, "evolve_slab_outbox_to_host: bad arguments");
+    if (i_count == 0) return 0;
+    const size_t plane = (size_t)st.N * st.N;
+    ASORA_HIP_TRY(hipMemcpyAsync(host, st.staging + (size_t)i_begin * plane, (size_t)i_count * plane * sizeof(double), hipMemcpyDeviceToHost, st.stream));
+    ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    return 0;
+}
+
+int asora_evolve_slab_add(int i_begin, int i_count, const double *dev_planes)
+{
+    clear_error();
+    if (int rc = require_slab("evolve_slab_add")) return rc;
+    State &st = g_state;
+    if (i_begin < 0 || i_count < 0 || i_begin + i_count > st.N || (i_count > 0 && !dev_planes)) return fail(4, "evolve_slab_add: bad arguments");
+    if (st.ev_slab_passed) return fail(4, "evolve_slab_add: the iteration's pass has been enqueued already");
+    st.ev_sets_known = false;
+    const size_t plane = (size_t)st.N * st.N;
+    return launch_add_planes(st, slab_pair(0) + (size_t)i_begin * plane, dev_planes, (size_t)i_count * plane, &st.ev_status->done);
+}
+
+int asora_evolve_slab_add_host(int i_begin, int i_count, const double *host_planes)
+{
+    clear_error();
+    if (int rc = require_slab("evolve_slab_add_host")) return rc;
+    State &st = g_state;
+    if (i_begin < 0 || i_count < 0 || i_begin + i_count > st.N || (i_count > 0 && !host_planes)) return fail(4, "evolve_slab_add_host: bad arguments");
+    if (i_count == 0) return 0;
+    // through the out-box: what is added belongs to planes this rank owns, what the out-box holds to planes it does not
+    const size_t plane = (size_t)st.N * st.N;
+    double *tmp = st.staging + (size_t)i_begin * plane;
+    ASORA_HIP_TRY(hipMemcpyAsync(tmp, host_planes, (size_t)i_count * plane * sizeof(double), hipMemcpyHostToDevice, st.stream));
+    ASORA_HIP_TRY(hipStreamSynchronize(st.stream));              // (the host buffer may be pageable)
+    return asora_evolve_slab_add(i_begin, i_count, tmp);
+}
+
+int asora_evolve_slab_pass(void)
+{
+    clear_error();
+    if (int rc = require_slab("evolve_slab_pass")) return rc;
+    State &st = g_state;
+    if (st.ev_slab_passed) return fail(4, "evolve_slab_pass: already enqueued for this iteration");
+    st.ev_sets_known = false;
+    st.ev_slab_passed = true;
+    st.grid_valid[ASORA_GRID_XH_AV] = st.grid_valid[ASORA_GRID_XH_INTERMED] = true;
+    st.grid_valid[ASORA_GRID_PHI_ION] = false;
+    if (st.ev_own_count == 0) {           // nothing to own (more ranks than planes): this rank's share of the sums is zero
+        ASORA_HIP_TRY(hipMemsetAsync(st.red_final, 0, sizeof(double) * 3, st.stream));
+        return 0;
+    }
+    double *cur = slab_pair(0), *nxt = slab_pair(1);
+    ChemTileParams c;
+    c.N = st.N; c.i_begin = st.ev_own_begin; c.i_end = st.ev_own_begin + st.ev_own_count;
+    c.dt = st.ev_chem[0]; c.bh00 = st.ev_chem[1]; c.albpow = st.ev_chem[2]; c.colh0 = st.ev_chem[3];
+    c.temph0 = st.ev_chem[4]; c.abu_c = st.ev_chem[5];
+    c.ndens = st.grid[ASORA_GRID_NDENS]; c.temp = st.grid[ASORA_GRID_TEMP]; c.xh = st.grid[ASORA_GRID_XH];
+    c.xh_av_in = st.ev_first ? st.grid[ASORA_GRID_XH] : st.grid[ASORA_GRID_XH_AV];
+    c.gamma = cur; c.gamma_t = cur + st.ncell; c.phi_out = nullptr;
+    c.zero_a = nxt; c.zero_t = nxt + st.ncell;
+    c.xh_av = st.grid[ASORA_GRID_XH_AV]; c.xh_intermed = st.grid[ASORA_GRID_XH_INTERMED];
+    c.nhi = st.nhi; c.nhi_t = st.nhi_t;
+    if (int rc = ensure_red_capacity(3 * chemistry_tile_blocks(st, st.N, st.ev_own_count))) return rc;    // (sized for every range at init)
+    c.red_partial = st.red_partial; c.red_final = st.red_final;
+    c.status = st.ev_status; c.local_sums = true;
+    c.fold = true; c.emit = true;
+    set_uniform_temperature(c);
+    return launch_chemistry_tiles(st, c, st.stream);
+}
+
+int asora_evolve_slab_nhi(int i_begin, int i_count)
+{
+    clear_error();
+    if (int rc = require_slab("evolve_slab_nhi")) return rc;
+    State &st = g_state;
+    if (i_begin < 0 || i_count < 0 || i_begin + i_count > st.N) return fail(4, "evolve_slab_nhi: bad plane range");
+    return launch_prepare_range(st, i_begin, i_count, false, nullptr, &st.ev_status->done);
+}
+
+int asora_evolve_slab_close(const double *host_sums)
+{
+    clear_error();
+    if (int rc = require_slab("evolve_slab_close")) return rc;
+    State &st = g_state;
+    if (!st.ev_slab_passed) return fail(4, "evolve_slab_close: the iteration's pass has not been enqueued");
+    if (host_sums) {          // summed over the ranks on the host (gloo rehearsals, mpi4py): {sum x, sum 1-x, conv_flag}
+        ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+        std::memcpy(st.red_host, host_sums, sizeof(double) * 3);
+        ASORA_HIP_TRY(hipMemcpyAsync(st.red_final, st.red_host, sizeof(double) * 3, hipMemcpyHostToDevice, st.stream));
+    }
+    if (int rc = launch_convergence_test(st, st.red_final, st.ev_status)) return rc;
+    st.ev_first = false;
+    st.ev_slab_passed = false;
+    st.ev_enqueued += 1;
     return 0;
 }
 
@@ -1372,6 +1562,7 @@ int asora_evolve_enqueue(int iterations)
     if (int rc = require_init("evolve_enqueue")) return rc;
     State &st = g_state;
     if (!st.ev_open) return fail(4, "evolve_enqueue: no evolve step in progress (call asora_evolve_begin)");
+    if (st.ev_slab) return fail(4, "evolve_enqueue: the step was begun with asora_evolve_begin_slab (use the asora_evolve_slab_* calls)");
     if (iterations < 1 || iterations > EVOLVE_HIST / 2) return fail(3, "evolve_enqueue: between 1 and 32 iterations per call");
     // the per-iteration history is a ring of EVOLVE_HIST rows on the device: rows not yet handed out by asora_evolve_poll
     // must not be overwritten

@@ -229,6 +229,10 @@ struct State {
     double ev_chem[6] = {0, 0, 0, 0, 0, 0}; // dt, bh00, albpow, colh0, temph0, abu_c
     int ev_src_begin = 0, ev_src_count = 0;
     RtParams ev_rt;
+    // multi-GPU form of the loop (asora_evolve_begin_slab): this rank runs the fused pass on the planes it owns only
+    bool ev_slab = false;
+    int ev_own_begin = 0, ev_own_count = 0;
+    bool ev_slab_passed = false;            // the current iteration's pass has been enqueued (close comes next)
     // Which 64-byte lines of the rate accumulators the sources of the current step can touch at all (round 4): one byte per
     // line of 8 cells, [i][j][k >> 3] for the plain layout and, behind it, [k][j][i >> 3] for the transposed one.  The fused
     // pass neither reads nor zeroes the lines no source reaches (they are zero and stay zero): 32 of its 88 bytes per cell.
@@ -370,6 +374,8 @@ struct ChemTileParams {
     int red_stride = 0;                              // number of workgroups of the launch (set by the launcher)
     int accumulate = 0;
     EvolveStatus *status = nullptr;
+    bool local_sums = false;                         // status only gates the launch: the reductions stop at red_final, the convergence
+                                                     // test follows later, on the sums over all ranks (launch_convergence_test)
     const unsigned char *reach_a = nullptr, *reach_t = nullptr;   // fold + emit: lines of the accumulators any source reaches (State::reach_mask), or nullptr
     bool fold = false, emit = false;
     // the grid has one temperature (launch_temp_probe): its factors, evaluated on the device, travel with the parameters
@@ -382,7 +388,13 @@ int launch_temp_probe(State &st, const double *temp, size_t n, double bh00, doub
 int launch_chemistry_tiles(State &st, ChemTileParams &p, hipStream_t stream);
 size_t chemistry_tile_blocks(const State &st, int N, int planes);
 int launch_prepare_nhi_from(State &st, const double *xh_av, bool need_transposed);
-int launch_prepare_range(State &st, int i_begin, int i_count, bool zero_acc, double *acc);
+int launch_prepare_range(State &st, int i_begin, int i_count, bool zero_acc, double *acc, const int *done = nullptr);
+// multi-GPU device loop: foreign planes folded into the out-box (+ the other accumulator pair zeroed there); received planes added
+int launch_fold_out(State &st, const double *a, const double *a_t, double *out, double *z_a, double *z_t, int i_begin, int i_count,
+                    const int *done);
+int launch_add_planes(State &st, double *dst, const double *src, size_t n, const int *done);
+// the convergence test of evolve.py:216-236 on sums[3] = {sum x, sum 1-x, conv_flag} (summed over the ranks beforehand)
+int launch_convergence_test(State &st, const double *sums, EvolveStatus *status);
 // mask[0 .. N*N*NL) for [i][j][k >> 3], mask[N*N*NL .. ) for [k][j][i >> 3], NL = (N + 7) / 8: 1 where a source of the range reaches
 int launch_reach_mask(State &st, const int32_t *src_pos, int src_begin, int src_count, double R, unsigned char *mask, size_t bytes_one_layout);
 int launch_reach_count(State &st, const unsigned char *mask, size_t bytes_both_layouts, unsigned long long *out_dev);

@@ -140,9 +140,11 @@ __global__ void __launch_bounds__(CH_THREADS) chemistry_kernel(const ChemParams 
 // below convergence_fraction`; the iteration is booked in the status block's history ring.
 constexpr int RED_THREADS = 1024;
 __global__ void __launch_bounds__(RED_THREADS) chemistry_reduce_kernel(const double *partial, int nblocks, double *out,
-                                                                       int accumulate, EvolveStatus *status)
+                                                                       int accumulate, EvolveStatus *status,
+                                                                       const EvolveStatus *gate = nullptr)
 {
     if (status && status->done) return;
+    if (gate && gate->done) return;
     // fixed order: thread t sums partials t, t + 1024, ...; lanes of a wave are combined by a butterfly of DPP-free
     // shuffles in a fixed pattern, the 16 waves through LDS -- the same bits on every launch and on every rank
     double v[3];
@@ -409,7 +411,8 @@ int launch_chemistry(State &st, ChemParams &p, hipStream_t stream)
         ASORA_HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(chemistry_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, stream,
-                       (const double *)p.red_partial, blocks, p.red_final, p.accumulate, (EvolveStatus *)nullptr);
+                       (const double *)p.red_partial, blocks, p.red_final, p.accumulate, (EvolveStatus *)nullptr,
+                       (const EvolveStatus *)nullptr);
     ASORA_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -452,7 +455,33 @@ int launch_chemistry_tiles(State &st, ChemTileParams &p, hipStream_t stream)
         ASORA_HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(chemistry_reduce_kernel, dim3(1), dim3(RED_THREADS), 0, stream,
-                       (const double *)p.red_partial, (int)blocks, p.red_final, p.accumulate, p.status);
+                       (const double *)p.red_partial, (int)blocks, p.red_final, p.accumulate,
+                       p.local_sums ? (EvolveStatus *)nullptr : p.status, (const EvolveStatus *)(p.local_sums ? p.status : nullptr));
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// The convergence test of the evolve loop on its own (pyc2ray/evolve.py:216-236): multi-GPU, where the three sums of a rank's
+// slab pass are first summed over the ranks (in place, RCCL) -- every rank then evaluates this on identical bits and takes
+// the same decision.  Same arithmetic and bookkeeping as the tail of chemistry_reduce_kernel.
+__global__ void convergence_test_kernel(const double *sums, EvolveStatus *status)
+{
+    if (status->done) return;
+    const double sum1 = sums[0], sum0 = sums[1], nconv = sums[2];
+    const double rel1 = sum1 > 0.0 ? fabs((sum1 - status->prev1) / sum1) : 1.0;      // evolve.py:219-227
+    const double rel0 = sum0 > 0.0 ? fabs((sum0 - status->prev0) / sum0) : 1.0;
+    const bool converged = (nconv < status->conv_criterion) ||
+                           (rel1 < status->conv_fraction && rel0 < status->conv_fraction);   // evolve.py:232
+    double *h = status->hist[status->niter % EVOLVE_HIST];
+    h[0] = nconv; h[1] = sum1; h[2] = sum0; h[3] = rel1; h[4] = rel0;
+    status->prev1 = sum1; status->prev0 = sum0;                                       // evolve.py:234-235
+    status->niter += 1;
+    if (converged) status->done = 1;
+}
+
+int launch_convergence_test(State &st, const double *sums, EvolveStatus *status)
+{
+    hipLaunchKernelGGL(convergence_test_kernel, dim3(1), dim3(1), 0, st.stream, sums, status);
     ASORA_HIP_TRY(hipGetLastError());
     return 0;
 }

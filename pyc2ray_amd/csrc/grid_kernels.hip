@@ -17,8 +17,10 @@ namespace asora {
 template <bool WITH_T, bool ZERO>
 __global__ void __launch_bounds__(256) prepare_nhi_kernel(const double *__restrict__ nd, const double *__restrict__ xh,
                                                           double *__restrict__ nhi, double *__restrict__ nhi_t, int N,
-                                                          int i_begin, int i_end, double *__restrict__ acc, size_t ncell)
+                                                          int i_begin, int i_end, double *__restrict__ acc, size_t ncell,
+                                                          const int *__restrict__ done = nullptr)
 {
+    if (done && *done) return;                                  // device loop: the time step has converged
     __shared__ double tile[32][33];
     const int j = blockIdx.y;
     const int ib = i_begin + blockIdx.z * 32, kb = blockIdx.x * 32;
@@ -74,10 +76,10 @@ int launch_prepare_nhi_from(State &st, const double *xh_av, bool need_transposed
     const int N = st.N;
     if (need_transposed)
         hipLaunchKernelGGL((prepare_nhi_kernel<true, false>), tile_grid(N), dim3(32, 8), 0, st.stream,
-                           st.grid[ASORA_GRID_NDENS], xh_av, st.nhi, st.nhi_t, N, 0, N, (double *)nullptr, st.ncell);
+                           st.grid[ASORA_GRID_NDENS], xh_av, st.nhi, st.nhi_t, N, 0, N, (double *)nullptr, st.ncell, (const int *)nullptr);
     else
         hipLaunchKernelGGL((prepare_nhi_kernel<false, false>), tile_grid(N), dim3(32, 8), 0, st.stream,
-                           st.grid[ASORA_GRID_NDENS], xh_av, st.nhi, st.nhi_t, N, 0, N, (double *)nullptr, st.ncell);
+                           st.grid[ASORA_GRID_NDENS], xh_av, st.nhi, st.nhi_t, N, 0, N, (double *)nullptr, st.ncell, (const int *)nullptr);
     ASORA_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -88,7 +90,7 @@ int launch_prepare_nhi(State &st, bool need_transposed)
 }
 
 // nHI in both layouts on the planes [i_begin, i_begin + i_count) only; zero_acc: also zero both layouts of `acc` there
-int launch_prepare_range(State &st, int i_begin, int i_count, bool zero_acc, double *acc)
+int launch_prepare_range(State &st, int i_begin, int i_count, bool zero_acc, double *acc, const int *done)
 {
     if (i_count <= 0) return 0;
     KernelTimer kt(ASORA_KERNEL_PREP);
@@ -97,10 +99,10 @@ int launch_prepare_range(State &st, int i_begin, int i_count, bool zero_acc, dou
     const dim3 grid(t, N, (i_count + 31) / 32);
     if (zero_acc)
         hipLaunchKernelGGL((prepare_nhi_kernel<true, true>), grid, dim3(32, 8), 0, st.stream, st.grid[ASORA_GRID_NDENS],
-                           st.grid[ASORA_GRID_XH_AV], st.nhi, st.nhi_t, N, i_begin, i_begin + i_count, acc, st.ncell);
+                           st.grid[ASORA_GRID_XH_AV], st.nhi, st.nhi_t, N, i_begin, i_begin + i_count, acc, st.ncell, done);
     else
         hipLaunchKernelGGL((prepare_nhi_kernel<true, false>), grid, dim3(32, 8), 0, st.stream, st.grid[ASORA_GRID_NDENS],
-                           st.grid[ASORA_GRID_XH_AV], st.nhi, st.nhi_t, N, i_begin, i_begin + i_count, acc, st.ncell);
+                           st.grid[ASORA_GRID_XH_AV], st.nhi, st.nhi_t, N, i_begin, i_begin + i_count, acc, st.ncell, done);
     ASORA_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -148,6 +150,60 @@ int launch_fold_range(State &st, const double *src_t, double *dst, int i_begin, 
     const unsigned tk = (st.N + 31) / 32, ti = (i_count + 31) / 32;
     hipLaunchKernelGGL(fold_range_kernel, dim3(ti, st.N, tk), dim3(32, 8), 0, st.stream, src_t, dst, st.N, i_begin,
                        i_begin + i_count);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Multi-GPU device loop (asora_evolve_slab_*): the rates this rank traced onto planes [i_begin, i_end) that ANOTHER rank owns,
+// out[i][j][k] = a[i][j][k] + a_t[k][j][i] -- the message to the owner, a[] and a_t[] left intact -- and, in the same sweep, the
+// OTHER accumulator pair zeroed on those planes for the next iteration's trace (what the fused pass does on the own planes).
+__global__ void __launch_bounds__(256) fold_out_kernel(const double *__restrict__ a, const double *__restrict__ a_t, double *__restrict__ out,
+                                                       double *__restrict__ z_a, double *__restrict__ z_t, int N, int i_begin, int i_end,
+                                                       const int *__restrict__ done)
+{
+    if (done && *done) return;
+    __shared__ double tile[32][33];
+    const int j = blockIdx.y;
+    const int kb = blockIdx.z * 32, ib = i_begin + blockIdx.x * 32;       // a_t tile: rows k, columns i
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int k = kb + r, i = ib + threadIdx.x;
+        if (k < N && i < i_end) { const size_t o = ((size_t)k * N + j) * N + i; tile[r][threadIdx.x] = a_t[o]; z_t[o] = 0.0; }
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int i = ib + r, k = kb + threadIdx.x;
+        if (i < i_end && k < N) { const size_t o = ((size_t)i * N + j) * N + k; out[o] = a[o] + tile[threadIdx.x][r]; z_a[o] = 0.0; }
+    }
+}
+
+int launch_fold_out(State &st, const double *a, const double *a_t, double *out, double *z_a, double *z_t, int i_begin, int i_count,
+                    const int *done)
+{
+    if (i_count <= 0) return 0;
+    KernelTimer kt(ASORA_KERNEL_FINISH);
+    const unsigned tk = (st.N + 31) / 32, ti = (i_count + 31) / 32;
+    hipLaunchKernelGGL(fold_out_kernel, dim3(ti, st.N, tk), dim3(32, 8), 0, st.stream, a, a_t, out, z_a, z_t, st.N, i_begin,
+                       i_begin + i_count, done);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// dst[q] += src[q], q < n (n even: whole planes of an even N^2, or handled by the tail): the rates another rank sent for planes
+// this rank owns, added to its own accumulator in the order the host issues the calls
+__global__ void __launch_bounds__(256) add_planes_kernel(double *__restrict__ dst, const double *__restrict__ src, size_t n,
+                                                         const int *__restrict__ done)
+{
+    if (done && *done) return;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) dst[q] += src[q];
+}
+
+int launch_add_planes(State &st, double *dst, const double *src, size_t n, const int *done)
+{
+    if (n == 0) return 0;
+    KernelTimer kt(ASORA_KERNEL_FINISH);
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, (size_t)st.cu_count * 32);
+    hipLaunchKernelGGL(add_planes_kernel, dim3(blocks), dim3(256), 0, st.stream, dst, src, n, done);
     ASORA_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -414,8 +414,8 @@ class TorchComm:
 
     def phase_report(self, reduce_max=True):
         """Mean milliseconds per iteration of every phase booked since ``phase_reset`` -- the MAXIMUM over the ranks when
-        `reduce_max` (a collective: every rank must call it), plus "iterations".  Phase names: slab exchange -- prepare,
-        trace_fold_post, wait_rates_add, slab_chemistry, xh_av_exchange, scalar_allreduce; all-reduce path -- trace,
+        `reduce_max` (a collective: every rank must call it), plus "iterations".  Phase names: slab exchange --
+        trace_fold_post, wait_rates_add, slab_pass, xh_av_exchange_nhi, scalar_allreduce_test; all-reduce path -- trace,
         rate_allreduce, chemistry."""
         import torch
         self._phase_resolve()
@@ -600,81 +600,153 @@ class TorchComm:
             else:
                 libasora.planes_to_device(which, a, t.numpy())
 
-    def _sum_scalars(self, libasora):
-        """Sum of (conv_flag, sum x, sum 1-x) of the slab chemistry over the ranks: ONE all-reduce of three doubles and ONE
-        read-back per iteration (the result of an all-reduce is the same on every rank, so every rank takes the same
-        convergence decision).  With RCCL the all-reduce runs in place on the library's reduction buffer, ordered on its
-        stream behind the chemistry -- the host does not wait for the chemistry first."""
+    # -- the device-resident loop over several ranks (asora_evolve_slab_*, include/asora_hip.h) ------------------------
+    def slab_begin(self, libasora, plan, N, R, sig, dr, num_src_local, minlogtau, dlogtau, NumTau, chemistry,
+                   conv_criterion, convergence_fraction):
+        """Start a time step of the sharded loop: NDENS, TEMP, XH and this rank's sources are on the device.  `chemistry` =
+        (dt, bh00, albpow, colh0, temph0, abu_c); conv_criterion from the TOTAL source count (pyc2ray/evolve.py:127,346)."""
+        a, b = plan.own[self.Get_rank()]
+        libasora.evolve_begin_slab(*chemistry, R, sig, dr, minlogtau, dlogtau, NumTau, 0, num_src_local, conv_criterion,
+                                   convergence_fraction, a, b - a)
+        self._slab = (plan, int(N), int(num_src_local))
+
+    def slab_enqueue(self, libasora, iterations=1):
+        """Enqueue outer iterations of the step begun with ``slab_begin``.  One iteration = what the one-GPU loop does -- the
+        trace and ONE fused pass -- with two plane exchanges in between:
+
+          trace (in K chunks; after each, the foreign planes no later chunk reaches are folded into the out-box and sent to
+          their owners) -> received rates added on the own planes -> fused pass on the own planes (rates folded, chemistry,
+          nHI in both layouts, next accumulators zeroed) -> new xh_av of the planes other ranks trace through sent back, nHI
+          formed on the halo planes as they arrive -> the three convergence sums all-reduced IN PLACE on the device and the
+          test of evolve.py:216-236 evaluated there.
+
+        With RCCL nothing here waits on the host: transfers, kernels and the test are ordered on the library's stream, every
+        launch is gated by the device's `done` flag, and every rank evaluates the test on identical bits, so all ranks stop
+        at the same iteration; ``slab_poll`` reads the status back once per batch.  With gloo (CPU rehearsals) the planes
+        and the sums are staged through the host, one synchronisation per exchange."""
+        for _ in range(int(iterations)):
+            self._slab_one(libasora)
+
+    def slab_poll(self, libasora, max_rows=32):
+        """(iterations carried out, converged, rows) -- asora_evolve_poll; folds the last iteration's rates into PHI_ION
+        (complete on the own planes; ``slab_gather`` collects the owners' slabs at the end of the step)."""
+        return libasora.evolve_poll(max_rows)
+
+    def _outbox_view(self, libasora, N):
+        import torch
+        ptr = libasora.evolve_slab_outbox_ptr()
+        cache = self.__dict__.setdefault("_views", {})
+        if (ptr, N) not in cache:
+            cache[(ptr, N)] = torch.as_tensor(_DevicePointer(ptr, N ** 3), device="cuda").view(N, N * N)
+        return cache[(ptr, N)]
+
+    def _post_rates(self, libasora, N, sends, recvs, tag):
+        """The first exchange: out-box planes to their owners, foreign contributions to the own planes into receive buffers."""
+        import torch
+        dist = self._dist
+        if not sends and not recvs:
+            return None
+        if self._backend() == "nccl":
+            with torch.cuda.stream(self._library_stream(libasora)):
+                box = self._outbox_view(libasora, N)
+                key = ("rates", tag, N, tuple(sends), tuple(recvs), box.data_ptr())
+                cache = self.__dict__.setdefault("_rounds", {})
+                if key not in cache:
+                    targets = [torch.empty((b - a, N * N), dtype=torch.float64, device="cuda") for _, a, b in recvs]
+                    ops = [dist.P2POp(dist.isend, box[a:b], q, group=self._group) for q, a, b in sends]
+                    ops += [dist.P2POp(dist.irecv, t, q, group=self._group) for (q, _, _), t in zip(recvs, targets)]
+                    cache[key] = (targets, ops)
+                targets, ops = cache[key]
+                works = dist.batch_isend_irecv(ops)
+            return ("nccl", works, recvs, targets)
+        out = [torch.from_numpy(libasora.evolve_slab_outbox_to_host(a, b - a, N)) for _, a, b in sends]
+        inc = [torch.empty((b - a, N, N), dtype=torch.float64) for _, a, b in recvs]
+        ops = [dist.P2POp(dist.isend, t, q, group=self._group) for (q, _, _), t in zip(sends, out)]
+        ops += [dist.P2POp(dist.irecv, t, q, group=self._group) for (q, _, _), t in zip(recvs, inc)]
+        return ("gloo", dist.batch_isend_irecv(ops), recvs, inc, out)
+
+    def _complete_rates(self, libasora, handle):
+        """Wait for a round of ``_post_rates`` and add what arrived, in the order of `recvs` (rank order)."""
+        import torch
+        if handle is None:
+            return
+        kind, works, recvs, targets = handle[:4]
+        if kind == "nccl":
+            with torch.cuda.stream(self._library_stream(libasora)):
+                for w in works:
+                    w.wait()                                   # the library's stream waits, not the host
+            for (_, a, b), t in zip(recvs, targets):
+                libasora.evolve_slab_add(a, b - a, t.data_ptr())
+            return
+        for w in works:
+            w.wait()
+        for (_, a, b), t in zip(recvs, targets):
+            libasora.evolve_slab_add_host(a, t.numpy())
+
+    def _close_iteration(self, libasora):
+        """The three sums of this rank's pass summed over the ranks, then the convergence test on the device."""
         import torch
         if self._backend() == "nccl" and hasattr(libasora, "reduction_ptr"):
             ptr = libasora.reduction_ptr()
             cache = self.__dict__.setdefault("_views", {})
             if (ptr, 3) not in cache:
                 cache[(ptr, 3)] = torch.as_tensor(_DevicePointer(ptr, 3), device="cuda")
-            red = cache[(ptr, 3)]                               # {sum x, sum 1-x, conv_flag}
             with torch.cuda.stream(self._library_stream(libasora)):
-                self._dist.all_reduce(red, op=self._dist.ReduceOp.SUM, group=self._group)
-                v = red.cpu().tolist()
-            return int(round(v[2])), v[0], v[1]
+                self._dist.all_reduce(cache[(ptr, 3)], op=self._dist.ReduceOp.SUM, group=self._group)
+            libasora.evolve_slab_close(None)
+            return
         part = libasora.chemistry_finish()                      # (conv_flag, sum x, sum 1-x) of this rank
         t = torch.tensor([float(part[0]), float(part[1]), float(part[2])], dtype=torch.float64)
-        if self._backend() == "nccl":
-            t = t.cuda()
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
-        v = t.cpu().tolist()
-        return int(round(v[0])), v[1], v[2]
+        v = t.tolist()
+        libasora.evolve_slab_close((v[0], v[1], v[2]))
 
-    def slab_iteration(self, libasora, plan, N, R, sig, dr, num_src_local, minlogtau, dlogtau, NumTau, chemistry, first):
-        """One outer iteration with the rates summed slab-wise: raytrace this rank's sources, send the rates to the
-        owners of the planes, chemistry on the own slab, send the new xh_av back to the ranks that trace through it.
-        Returns (conv_flag, sum x, sum 1-x) over the WHOLE grid, identical on every rank.  `first`: the first
-        iteration of a time step (accumulators and nHI are set up on the whole grid).
-
-        With self.slab_chunks = K > 1 (and the rank's sources uploaded in ascending order of their first coordinate, which
-        ``shard_sources_by_slab`` gives) the trace runs in K chunks and every foreign plane is sent as soon as no later
-        chunk can reach it (SlabPlan.send_schedule): the first exchange runs beside the trace."""
+    def _slab_one(self, libasora):
         from . import _capi
+        plan, N, num_src_local = self._slab
         me = self.Get_rank()
         # every rank walks through the same number of rounds and derives every other rank's schedule: the chunk count is a
         # function of the plan, never of this rank alone
         K = plan.common_chunks(getattr(self, "slab_chunks", 1))
         ph = _Phases(self, libasora) if self.phase_timing else None
-        if first:
-            libasora.raytrace_begin_planes(R, sig, dr, minlogtau, dlogtau, NumTau, [(0, N)])
-        else:
-            libasora.raytrace_begin_planes(R, sig, dr, minlogtau, dlogtau, NumTau,
-                                           [(a, b - a) for a, b in plan.work_runs(me)])
-        if ph: ph.mark("prepare")
         sched, rsched = plan.send_schedule(me, K), plan.recv_schedule(me, K)
         bounds = plan.chunk_bounds(num_src_local, K)
         handles = []
         for c in range(K):
-            libasora.raytrace_range(bounds[c], bounds[c + 1] - bounds[c])
+            libasora.evolve_slab_trace(bounds[c], bounds[c + 1] - bounds[c])
             for _, a, b in sched[c]:
-                libasora.raytrace_fold(a, b - a)                        # the z-face accumulator of the planes that leave now
-            handles.append(self._post(libasora, _capi.GRID_PHI_ION, N, sched[c], rsched[c], True, ("rates", c)))
-        a, b = plan.own[me]
-        if b > a:
-            libasora.raytrace_fold(a, b - a)
+                libasora.evolve_slab_fold_out(a, b - a)                 # the planes that leave now
+            handles.append(self._post_rates(libasora, N, sched[c], rsched[c], c))
         if ph: ph.mark("trace_fold_post")
         for h in handles:                                               # chunk order, then rank order: a fixed order of additions
-            self._complete(libasora, _capi.GRID_PHI_ION, N, h)
+            self._complete_rates(libasora, h)
         if ph: ph.mark("wait_rates_add")
-        libasora.chemistry_range(*chemistry, a, b - a, True)
-        if ph: ph.mark("slab_chemistry")
-        # xh_av back: the owner q of a run sends it to the rank r that traces through it
+        libasora.evolve_slab_pass()
+        if ph: ph.mark("slab_pass")
+        # xh_av back: the owner q of a run sends it to the rank r that traces through it; nHI there once it has arrived
         back = plan.__dict__.setdefault("_back_cache", {})
         if me not in back:
             back[me] = ([(r, s0, s1) for r in range(plan.P) if r != me for s0, s1 in plan.runs[r][me]],
                         [(q, s0, s1) for q in range(plan.P) if q != me for s0, s1 in plan.runs[me][q]])
         sends, recvs = back[me]
         self._complete(libasora, _capi.GRID_XH_AV, N, self._post(libasora, _capi.GRID_XH_AV, N, sends, recvs, False, "xh_av"))
-        if ph: ph.mark("xh_av_exchange")
-        res = self._sum_scalars(libasora)
+        for _, a, b in recvs:
+            libasora.evolve_slab_nhi(a, b - a)
+        if ph: ph.mark("xh_av_exchange_nhi")
+        self._close_iteration(libasora)
         if ph:
-            ph.mark("scalar_allreduce")
+            ph.mark("scalar_allreduce_test")
             ph.close()
-        return res
+
+    def slab_iteration(self, libasora, plan, N, R, sig, dr, num_src_local, minlogtau, dlogtau, NumTau, chemistry, first):
+        """ONE outer iteration and its three sums (conv_flag, sum x, sum 1-x) over the WHOLE grid, identical on every rank:
+        ``slab_begin`` (when `first`; with a convergence test that never passes) + ``slab_enqueue(1)`` + ``slab_poll``.  For
+        callers that drive the loop themselves; evolve3D_MPI and bench.py enqueue batches instead."""
+        if first:
+            self.slab_begin(libasora, plan, N, R, sig, dr, num_src_local, minlogtau, dlogtau, NumTau, chemistry, -1.0, 0.0)
+        self.slab_enqueue(libasora, 1)
+        _, _, rows = self.slab_poll(libasora, 1)
+        return int(rows[-1][0]), float(rows[-1][1]), float(rows[-1][2])
 
     def slab_gather(self, libasora, plan, which, N):
         """Every rank gets every owner's slab of grid `which` (end of a time step: xh_intermed, phi_ion)."""

@@ -225,7 +225,7 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
     niter = 0
 
     # source shard of this rank, evolve.py:360-371
-    slab = (distributed and hasattr(comm, "slab_iteration") and getattr(comm, "exchange", "") == "slab"
+    slab = (distributed and hasattr(comm, "slab_enqueue") and getattr(comm, "exchange", "") == "slab"
             and not getattr(comm, "overlap", False))
     plan = None
     all_pos, all_flux = np.asarray(src_pos), src_flux
@@ -285,18 +285,37 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
                                 convergence_fraction, NumCells, logfile, quiet)
         converged = True
 
-    while distributed and not converged:
+    if slab:
+        # the device-resident loop, sharded (pyc2ray_amd.dist.TorchComm.slab_*): per iteration the trace, the rates to the
+        # owners of the planes, ONE fused pass on the own slab, xh_av back, and the convergence test on the device behind the
+        # in-place all-reduce of its three sums -- identical bits, hence the same decision, on every rank.  With RCCL a batch of
+        # iterations is enqueued per host round trip (launches beyond convergence do nothing); with gloo every exchange
+        # goes through the host anyway and the batch is one.
+        comm.slab_begin(libasora, plan, N, R_max_LLS, sig, dr, NumSrc_local, minlogtau, dlogtau, NumTau, chem,
+                        conv_criterion, convergence_fraction)
+        batch = max(1, min(EVOLVE_BATCH, 32)) if comm._backend() == "nccl" else 1
+        while not converged:
+            trt0 = time.time()
+            comm.slab_enqueue(libasora, batch)
+            _, converged, rows = comm.slab_poll(libasora, batch)
+            per_iteration = (time.time() - trt0) / max(len(rows), 1)
+            lines = []
+            for conv_flag, _s1, _s0, rel_change_xh1, _rel0 in rows:
+                niter += 1
+                conv_flag = int(conv_flag)
+                lines += [(f"Doing Raytracing and Chemistry, slab-wise (rank={rank:n})...", ' '),
+                          (f"rank={rank:n} took {per_iteration : .1e} s.", '\n')]
+                if rank == 0:
+                    lines += [(f"Number of non-converged points: {conv_flag} of {NumCells} ({conv_flag / NumCells * 100 : .3f} % ), "
+                               f"Relative change in ionfrac: {rel_change_xh1 : .2e}", '\n')]
+            printlog_lines(lines, logfile, quiet)
+
+    while distributed and not slab and not converged:
         niter += 1
 
         # (1) raytracing, evolve.py:174-196
         trt0 = time.time()
-        if slab:
-            # raytrace; rates to the owners of the planes; chemistry of the own slab; xh_av back (steps (1) and (2))
-            printlog(f"Doing Raytracing and Chemistry, slab-wise (rank={rank:n})...", logfile, quiet, ' ')
-            conv_flag, sum_xh1_int, sum_xh0_int = comm.slab_iteration(
-                libasora, plan, N, R_max_LLS, sig, dr, NumSrc_local, minlogtau, dlogtau, NumTau, chem, niter == 1)
-            printlog(f"rank={rank:n} took {(time.time()-trt0) : .1e} s.", logfile, quiet)
-        elif pipelined:
+        if pipelined:
             # raytrace, sum over ranks and chemistry slab by slab (pyc2ray_amd.dist): steps (1) and (2) in one
             printlog(f"Doing Raytracing and Chemistry, pipelined (rank={rank:n})...", logfile, quiet, ' ')
             conv_flag, sum_xh1_int, sum_xh0_int = comm.raytrace_and_allreduce(
@@ -334,9 +353,7 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
 
         converged = (conv_flag < conv_criterion) or ((rel_change_xh1 < convergence_fraction) and
                                                      (rel_change_xh0 < convergence_fraction))
-        if not (slab and getattr(comm, "identical_scalars", False)):
-            # (the slab path's three scalars come out of ONE all-reduce: the same bits, hence the same decision, on every rank)
-            converged = _agree_on_convergence(comm, converged)        # evolve.py:484-489
+        converged = _agree_on_convergence(comm, converged)            # evolve.py:484-489
         prev_sum_xh1_int = sum_xh1_int
         prev_sum_xh0_int = sum_xh0_int
 

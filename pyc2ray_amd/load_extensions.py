@@ -231,6 +231,52 @@ class _LibAsora:
                                                 int(max_rows), C.byref(got)), "evolve_poll")
         return niter.value, bool(done.value), hist[:got.value]
 
+    # ---- the device-resident loop with the sources sharded over several GPUs (asora_evolve_slab_*) ----
+    def evolve_begin_slab(self, dt, bh00, albpow, colh0, temph0, abu_c, R, sig, dr, minlogtau, dlogtau, NumTau,
+                          src_begin, src_count, conv_criterion, convergence_fraction, own_begin, own_count):
+        _capi.check(self._lib.asora_evolve_begin_slab(float(dt), float(bh00), float(albpow), float(colh0), float(temph0),
+                                                      float(abu_c), float(R), float(sig), float(dr), float(minlogtau),
+                                                      float(dlogtau), int(NumTau), int(src_begin), int(src_count),
+                                                      float(conv_criterion), float(convergence_fraction), int(own_begin),
+                                                      int(own_count)), "evolve_begin_slab")
+
+    def evolve_slab_trace(self, src_begin, src_count):
+        _capi.check(self._lib.asora_evolve_slab_trace(int(src_begin), int(src_count)), "evolve_slab_trace")
+
+    def evolve_slab_fold_out(self, i_begin, i_count):
+        _capi.check(self._lib.asora_evolve_slab_fold_out(int(i_begin), int(i_count)), "evolve_slab_fold_out")
+
+    def evolve_slab_outbox_ptr(self):
+        return self._lib.asora_evolve_slab_outbox()
+
+    def evolve_slab_outbox_to_host(self, i_begin, i_count, N):
+        out = np.empty((int(i_count), N, N))
+        _capi.check(self._lib.asora_evolve_slab_outbox_to_host(int(i_begin), int(i_count), _capi.dptr(out)), "evolve_slab_outbox_to_host")
+        return out
+
+    def evolve_slab_add(self, i_begin, i_count, dev_ptr):
+        """dev_ptr: device address of i_count*N*N doubles (e.g. torch tensor .data_ptr())."""
+        _capi.check(self._lib.asora_evolve_slab_add(int(i_begin), int(i_count), C.c_void_p(int(dev_ptr))), "evolve_slab_add")
+
+    def evolve_slab_add_host(self, i_begin, planes):
+        a = np.ascontiguousarray(planes, dtype=np.float64)
+        _capi.check(self._lib.asora_evolve_slab_add_host(int(i_begin), int(a.shape[0]), _capi.dptr(a)), "evolve_slab_add_host")
+
+    def evolve_slab_pass(self):
+        _capi.check(self._lib.asora_evolve_slab_pass(), "evolve_slab_pass")
+
+    def evolve_slab_nhi(self, i_begin, i_count):
+        _capi.check(self._lib.asora_evolve_slab_nhi(int(i_begin), int(i_count)), "evolve_slab_nhi")
+
+    def evolve_slab_close(self, sums=None):
+        """sums = None: {sum x, sum 1-x, conv_flag} at reduction_ptr() have been summed over the ranks in place; else the
+        three sums over all ranks as (conv_flag, sum x, sum 1-x), the order chemistry_finish() returns them in."""
+        if sums is None:
+            _capi.check(self._lib.asora_evolve_slab_close(None), "evolve_slab_close")
+        else:
+            a = np.array([float(sums[1]), float(sums[2]), float(sums[0])])
+            _capi.check(self._lib.asora_evolve_slab_close(_capi.dptr(a)), "evolve_slab_close")
+
     def planes_to_host(self, which, i_begin, i_count, N):
         out = np.empty((int(i_count), N, N))
         _capi.check(self._lib.asora_planes_to_host(int(which), int(i_begin), int(i_count), _capi.dptr(out)),

@@ -139,6 +139,115 @@ class OracleAsora:
     def chemistry_finish(self):
         return tuple(self._red)
 
+    # ---- the device-resident loop, sharded (asora_evolve_slab_*): same call sequence, numpy underneath.  Wherever the library
+    # would hold stale data, the stand-in holds NaN, so a plan that forgets a plane poisons the result instead of passing by
+    # accident: after every iteration nHI and xh_av of every plane this rank does not own are NaN until the exchange has
+    # delivered xh_av there and evolve_slab_nhi has formed nHI from it.
+    def evolve_begin_slab(self, dt, bh00, albpow, colh0, temph0, abu_c, R, sig, dr, minlogtau, dlogtau, NumTau,
+                          src_begin, src_count, conv_criterion, convergence_fraction, own_begin, own_count):
+        N = self.g[0].shape[0]
+        self._ev = dict(chem=(dt, bh00, albpow, colh0, temph0, abu_c), rt=(R, sig, dr, minlogtau, dlogtau, NumTau),
+                        src=(src_begin, src_count), crit=conv_criterion, frac=convergence_fraction,
+                        own=slice(own_begin, own_begin + own_count), niter=0, done=False, reported=0, rows=[],
+                        prev1=2.0 * N ** 3, prev0=2.0 * N ** 3, passed=False)
+        self._nhi = self.g[0] * (1.0 - self.g[4])            # from xh: xh_av = copy(xh), evolve.py:136
+        self.g[1] = np.full((N, N, N), np.nan)               # XH_AV: nothing valid yet
+        self.g[5] = self.g[4].copy()
+        self._acc = np.zeros((N, N, N))
+        self._outbox = np.full((N, N, N), np.nan)
+        self._phi_own = np.zeros((N, N, N))
+        self._folded = np.zeros(N, dtype=bool)
+        self._first = True
+
+    def evolve_slab_trace(self, src_begin, src_count):
+        e = self._ev
+        if e["done"] or src_count == 0:
+            return
+        assert not e["passed"]
+        R, sig, dr, minlogtau, dlogtau, NumTau = e["rt"]
+        sl = slice(3 * src_begin, 3 * (src_begin + src_count))
+        add = O.asora_do_all_sources(R, sig, dr, self._nhi, np.zeros_like(self._nhi), self.pos[sl],
+                                     self.flux[src_begin:src_begin + src_count], self.thin, self.thick,
+                                     minlogtau, dlogtau, NumTau=NumTau, flags=O.ASORA_MODE)["phi_ion"]
+        w = add != 0
+        self._acc[w] += add[w]
+
+    def evolve_slab_fold_out(self, i_begin, i_count):
+        if self._ev["done"]:
+            return
+        sl = slice(i_begin, i_begin + i_count)
+        assert not self._folded[sl].any(), "a plane was folded twice"
+        own = self._ev["own"]
+        assert i_begin + i_count <= own.start or i_begin >= own.stop or i_count == 0, "an own plane was sent away"
+        self._folded[sl] = True
+        self._outbox[sl] = self._acc[sl]
+        self._acc[sl] = 0.0
+
+    def evolve_slab_outbox_to_host(self, i_begin, i_count, N):
+        return self._outbox[i_begin:i_begin + i_count].copy()
+
+    def evolve_slab_add_host(self, i_begin, planes):
+        if self._ev["done"]:
+            return
+        planes = np.asarray(planes)
+        own = self._ev["own"]
+        assert own.start <= i_begin and i_begin + planes.shape[0] <= own.stop, "rates received for a plane this rank does not own"
+        self._acc[i_begin:i_begin + planes.shape[0]] += planes.reshape(planes.shape[0], *self._acc.shape[1:])
+
+    def evolve_slab_pass(self):
+        e = self._ev
+        e["passed"] = True
+        self._red = [0, 0.0, 0.0]
+        if e["done"]:
+            return
+        sl = e["own"]
+        if sl.stop > sl.start:
+            xav_in = self.g[4][sl] if self._first else self.g[1][sl]
+            xa, xi, conv, _ = O.global_pass(e["chem"][0], self.g[0][sl], self.g[3][sl], self.g[4][sl], xav_in, self.g[5][sl],
+                                            self._acc[sl], *e["chem"][1:])
+            self.g[1][sl], self.g[5][sl] = xa, xi
+            self._phi_own[sl] = self._acc[sl]
+            self._acc[sl] = 0.0
+            self._nhi[sl] = self.g[0][sl] * (1.0 - xa)
+            self._red = [conv, float(np.sum(xi)), float(np.sum(1.0 - xi))]
+        # what the next trace may read must be formed from data that ARRIVES after this pass: poison everything not owned
+        keep = np.zeros(self._nhi.shape[0], dtype=bool)
+        keep[sl] = True
+        self._nhi[~keep] = np.nan
+        self.g[1][~keep] = np.nan
+
+    def evolve_slab_nhi(self, i_begin, i_count):
+        if self._ev["done"]:
+            return
+        sl = slice(i_begin, i_begin + i_count)
+        self._nhi[sl] = self.g[0][sl] * (1.0 - self.g[1][sl])
+
+    def evolve_slab_close(self, sums=None):
+        e = self._ev
+        assert e["passed"] and sums is not None
+        e["passed"] = False
+        self._folded[:] = False
+        if e["done"]:
+            return
+        nconv, s1, s0 = float(sums[0]), float(sums[1]), float(sums[2])
+        rel1 = abs((s1 - e["prev1"]) / s1) if s1 > 0.0 else 1.0
+        rel0 = abs((s0 - e["prev0"]) / s0) if s0 > 0.0 else 1.0
+        e["rows"].append((nconv, s1, s0, rel1, rel0))
+        e["prev1"], e["prev0"] = s1, s0
+        e["niter"] += 1
+        e["done"] = (nconv < e["crit"]) or (rel1 < e["frac"] and rel0 < e["frac"])
+        self._first = False
+
+    def evolve_poll(self, max_rows=32):
+        e = self._ev
+        rows = e["rows"][e["reported"]:e["reported"] + max_rows] if max_rows > 0 else []
+        e["reported"] = e["reported"] + len(rows) if max_rows > 0 else e["niter"]
+        N = self.g[0].shape[0]
+        phi = np.full((N, N, N), np.nan)
+        phi[e["own"]] = self._phi_own[e["own"]]
+        self.g[2] = phi
+        return e["niter"], e["done"], np.array(rows).reshape(-1, 5)
+
     def chemistry_device(self, dt, bh00, albpow, colh0, temph0, abu_c):
         xa, xi, conv, _ = O.global_pass(dt, self.g[0], self.g[3], self.g[4], self.g[1], self.g[5], self.g[2],
                                         bh00, albpow, colh0, temph0, abu_c)

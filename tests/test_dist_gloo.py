@@ -301,7 +301,7 @@ def test_slab_exchange_matches_single_process(tmp_path, world, N, ns, R):
 @pytest.mark.parametrize("world,exchange", [(2, "slab"), (3, "slab"), (2, "allreduce")])
 def test_phase_times_and_link_rates_of_a_multi_rank_run(tmp_path, world, exchange):
     """What bench.py --gpus N prints beside its value: per-phase milliseconds of an iteration -- booked by
-    TorchComm.slab_iteration / raytrace_and_allreduce when `phase_timing` is set, maximum over the ranks -- and the rates a
+    TorchComm.slab_enqueue / raytrace_and_allreduce when `phase_timing` is set, maximum over the ranks -- and the rates a
     point-to-point ring and an all-reduce reach in this job (TorchComm.measure_links).  Every rank reports the same numbers
     (they drive `--exchange auto`, which all ranks must decide alike); switching the timers on changes no result."""
     import json
@@ -313,7 +313,7 @@ def test_phase_times_and_link_rates_of_a_multi_rank_run(tmp_path, world, exchang
     ph = [json.loads(str(r["phases"])) for r in res]
     ln = [json.loads(str(r["links"])) for r in res]
     assert all(q == ph[0] for q in ph[1:]) and all(q == ln[0] for q in ln[1:])
-    want = ({"prepare", "trace_fold_post", "wait_rates_add", "slab_chemistry", "xh_av_exchange", "scalar_allreduce"}
+    want = ({"trace_fold_post", "wait_rates_add", "slab_pass", "xh_av_exchange_nhi", "scalar_allreduce_test"}
             if exchange == "slab" else {"trace", "rate_allreduce", "chemistry"})
     assert set(ph[0]) == want | {"iterations"}
     assert ph[0]["iterations"] == (niter_ref if exchange == "slab" else 2)

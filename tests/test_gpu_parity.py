@@ -534,6 +534,25 @@ def test_slab_iteration_over_rccl_world1_equals_the_single_gpu_loop(asora, tmp_p
         assert niter == n1, (chunks, niter, n1)
         np.testing.assert_allclose(x2, x1, rtol=1e-10, atol=0)
         np.testing.assert_allclose(phi2, phi1, rtol=1e-10, atol=0)
+        # the way evolve3D_MPI drives it: the convergence test on the device behind the in-place all-reduce, batches of 8
+        # iterations per poll -- the launches enqueued beyond convergence must do nothing (same count, same fields)
+        lib.grid_to_device(capi.GRID_XH, xh)
+        comm.slab_begin(lib, plan, N, 7.0, cases.SIG, dr, 11, cases.MINLOGTAU, dlog, thin.shape[0], chem, crit, 1e-4)
+        done, rows_all = False, []
+        while not done:
+            comm.slab_enqueue(lib, 8)
+            n3, done, rows = comm.slab_poll(lib, 8)
+            rows_all += list(rows)
+            assert n3 < 100
+        assert n3 == n1 == len(rows_all), (chunks, n3, n1, len(rows_all))
+        comm.slab_enqueue(lib, 3)                                   # beyond convergence: nothing may change
+        n4, done4, rows4 = comm.slab_poll(lib, 8)
+        assert (n4, done4, len(rows4)) == (n1, True, 0)
+        x3 = lib.grid_to_host(capi.GRID_XH_INTERMED, np.empty((N, N, N)))
+        phi3 = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+        assert np.array_equal(x3, x2)                               # the same kernels on the same inputs in the same order
+        np.testing.assert_allclose(phi3, phi1, rtol=1e-10, atol=0)
+        assert rows_all[-1][0] == conv and rows_all[-1][1] == s1
     p.device_close()
 
 
