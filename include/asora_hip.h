@@ -351,7 +351,11 @@ enum {
      * request rate is what bounds the trace).  Two sources share a workgroup only when they agree modulo 8.  Results are
      * the same sums in a different order. */
     ASORA_OPT_ALIGNED_ROWS = 15,
-    ASORA_OPT_COUNT = 16
+    /* 1: the geometry tables of the raytrace are built by the host-side builder (geometry.hip: the statement of what a table
+     * holds, and the checker of the device-side builder, geometry_device.hip, which is what runs by default and produces the
+     * same tables bit for bit -- tests/test_gpu_geometry.py) */
+    ASORA_OPT_GEOMETRY_ON_HOST = 16,
+    ASORA_OPT_COUNT = 17
 };
 int asora_set_option(int option, int value);
 int asora_get_option(int option);
@@ -378,6 +382,25 @@ int asora_last_raytrace_counts_ex(long long *gamma_cells, long long *evaluated_c
  * N^3 grid (zero elsewhere), C-order.  For parity tests of the column density
  * (the reference keeps it in cdh_dev, src/asora/memory.cu:20, and never downloads it). */
 int asora_debug_coldens(double R, double sig, double dr, int source_index, double *coldens_out, int N);
+
+/* Which form of the raytrace kernel the last launch took (measurement and tests; no reference counterpart): a bit set of
+ * ASORA_VARIANT_* | workgroups per source << 8 | threads per workgroup << 16.  0 before the first launch. */
+enum {
+    ASORA_VARIANT_PAIRED = 1,             /* two sources per workgroup */
+    ASORA_VARIANT_ALIGNED = 2,            /* line-aligned geometry tables (eight forms by source position) */
+    ASORA_VARIANT_BUFFER_ATOMICS = 4,     /* rate atomics through buffer descriptors (else global_atomic_add_f64 under a branch) */
+    ASORA_VARIANT_SPLIT_DESCRIPTORS = 8,  /* N > 512: one descriptor per layout of the rate grid */
+    ASORA_VARIANT_SKIP_ZERO = 16,         /* the form that leaves exact-zero rates out */
+    ASORA_VARIANT_GLOBAL_SHELLS = 32      /* shell buffers in global memory (they exceed LDS) */
+};
+int asora_last_raytrace_variant(void);
+
+/* The geometry tables the last raytrace launch used (tests: device-built against host-built tables).  *ntables = tables of the
+ * launch shape (units x 8 when line-aligned); for 0 <= table < *ntables: `words` receives 8 uint32 per entry (the 16-byte
+ * cell-A and cell-B records, raytrace.hip) for up to capacity_entries entries, *entries the table's entry count, *nsteps its
+ * steps, *shells / *max_cells the launch's shell count and zero slot.  table = -1 only reports the counts. */
+int asora_debug_geometry_table(int table, uint32_t *words, size_t capacity_entries, size_t *entries, int *nsteps, int *ntables,
+                               int *shells, int *max_cells, int *threads);
 
 /* Which build this is: a hash over every source and header of the library and the compiler flags (pyc2ray_amd/csrc/Makefile),
  * and those flags.  Measurement hygiene, no reference counterpart: the committed counter summaries under profiles/ name the

@@ -15,8 +15,9 @@ LIB_PATH = os.environ.get("PYC2RAY_AMD_LIBASORA") or os.path.join(_HERE, "lib", 
 GRID_NDENS, GRID_XH_AV, GRID_PHI_ION, GRID_TEMP, GRID_XH, GRID_XH_INTERMED, GRID_PHI_HEAT = range(7)
 (OPT_FORTRAN_CONSTANTS, OPT_GREY_NOTABLES, OPT_TIMING, OPT_Z_TRANSPOSED, OPT_BLOCK_THREADS, OPT_SECTORS,
  OPT_HEATING, OPT_C2RAY_OWN_FLUX, OPT_NO_UNIFORM_T, OPT_SUBBOX_GLOBAL_SHELLS, OPT_PIPELINED_COPIES,
- OPT_SKIP_ZERO_RATES, OPT_GLOBAL_ATOMICS, OPT_PAIR_SOURCES, OPT_SUBBOX_TABLES, OPT_ALIGNED_ROWS) = range(16)
+ OPT_SKIP_ZERO_RATES, OPT_GLOBAL_ATOMICS, OPT_PAIR_SOURCES, OPT_SUBBOX_TABLES, OPT_ALIGNED_ROWS, OPT_GEOMETRY_ON_HOST) = range(17)
 KERNEL_RAYTRACE, KERNEL_CHEMISTRY, KERNEL_PREP, KERNEL_FINISH = range(4)
+VARIANT_PAIRED, VARIANT_ALIGNED, VARIANT_BUFFER_ATOMICS, VARIANT_SPLIT_DESCRIPTORS, VARIANT_SKIP_ZERO, VARIANT_GLOBAL_SHELLS = 1, 2, 4, 8, 16, 32
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -85,6 +86,9 @@ SIGNATURES = {
     "asora_last_raytrace_counts": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "asora_last_raytrace_counts_ex": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "asora_debug_coldens": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int, _dp, C.c_int]),
+    "asora_last_raytrace_variant": (C.c_int, []),
+    "asora_debug_geometry_table": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int),
+                                             C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "asora_build_id": (C.c_char_p, []),
     "asora_build_flags": (C.c_char_p, []),
 }

@@ -159,7 +159,7 @@ static int release_all()
     drop(st.sb_active); drop(st.sb_nbox); drop(st.sb_loss); drop(st.sb_loss_final); st.subbox_cap = 0;
     release_geometry(st);
     st.init = false; st.N = 0; st.ncell = 0;
-    st.rt_last_R = -1.0; st.rt_same_R_calls = 0; st.rt_R_has_changed = false;
+    st.rt_radius[0] = State::RadiusHistory(); st.rt_radius[1] = State::RadiusHistory();
     if (st.zero_probe_dev) { (void)hipFree(st.zero_probe_dev); st.zero_probe_dev = nullptr; }
     if (st.zero_probe_host) { (void)hipHostFree(st.zero_probe_host); st.zero_probe_host = nullptr; }
     if (st.zero_probe_done) { (void)hipEventDestroy(st.zero_probe_done); st.zero_probe_done = nullptr; }
@@ -182,8 +182,10 @@ static int check_N(const char *who, int N)
     return 0;
 }
 
-// The parameter block of a raytrace of the uploaded sources into PHI_ION (+ its [k][j][i] twin)
-static void fill_rt_params(RtParams &p, double R, double sig, double dr, double minlogtau, double dlogtau, int NumTau)
+// The parameter block of a raytrace of the uploaded sources into PHI_ION (+ its [k][j][i] twin).  radius_path: which radius
+// history the call belongs to (note_call_radius; exactly one call of it per API call: here) -- 0 the whole-box entry points,
+// 1 the sub-box sweep
+static void fill_rt_params(RtParams &p, double R, double sig, double dr, double minlogtau, double dlogtau, int NumTau, int radius_path = 0)
 {
     State &st = g_state;
     std::memset(&p, 0, sizeof p);
@@ -202,7 +204,7 @@ static void fill_rt_params(RtParams &p, double R, double sig, double dr, double 
     p.heat = st.grid[ASORA_GRID_PHI_HEAT];
     p.src_pos = st.src_pos; p.src_flux = st.src_flux;
     p.counters = st.counters;
-    p.radius_stays = note_call_radius(st, R) ? 1 : 0;
+    p.radius_stays = note_call_radius(st, R, radius_path) ? 1 : 0;
 #ifdef ASORA_ENABLE_ABLATION
     { const char *ab = getenv("ASORA_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
 #endif
@@ -382,7 +384,7 @@ static int subbox_core(const SubboxCall &c, long long &total_nbox, double &total
     // geometry (cells within R_max_LLS only; raytrace.hip, SUBBOX) when that applies; the dumped source -- it needs the
     // whole cube -- and everything else stay with the on-the-fly kernel of subbox.hip
     RtParams tp;
-    fill_rt_params(tp, c.R, c.sig, c.dr, c.minlogtau, c.dlogtau, c.NumTau);
+    fill_rt_params(tp, c.R, c.sig, c.dr, c.minlogtau, c.dlogtau, c.NumTau, 1);
     tp.numtau_f = p.numtau_f; tp.lut_k1 = p.lut_k1; tp.lut_k0 = p.lut_k0; tp.tau_zero = INFINITY;
     tp.table_len = c.table_len; tp.tables = c.tables;
     tp.fortran_consts = 1; tp.grey = grey ? 1 : 0; tp.z_transposed = 1;
@@ -1324,7 +1326,15 @@ static int evolve_begin_impl(double dt, double bh00, double albpow, double colh0
         const bool possible = mode != 0 && std::isfinite(R) && 2.0 * R + 2.0 < (double)st.N && st.opt[ASORA_OPT_Z_TRANSPOSED] != 0;
         const bool same = st.reach_valid && st.reach_src_generation == st.src_generation && st.reach_src_begin == src_begin &&
                           st.reach_src_count == src_count && st.reach_R == R;
-        if (possible && !same) {
+        // where the spheres together hold more cells than the box, (nearly) every line is reached: the mask can not pay and is
+        // not built (in a cosmological run R changes every step, and every build ends with a blocking read-back)
+        const bool covers = possible && (double)src_count * (4.0 / 3.0) * 3.14159265358979 * R * R * R >= (double)st.ncell;
+        if (possible && !same && covers) {
+            st.reach_pays = false;
+            st.reach_valid = true; st.reach_src_generation = st.src_generation; st.reach_src_begin = src_begin;
+            st.reach_src_count = src_count; st.reach_R = R;
+        }
+        if (possible && !same && !covers) {
             const size_t one = (size_t)st.N * st.N * ((st.N + 7) / 8);
             if (!st.reach_mask) { ASORA_HIP_TRY(hipMalloc(&st.reach_mask, 2 * one)); st.reach_bytes = one; }
             if (!st.reach_count_dev) ASORA_HIP_TRY(hipMalloc(&st.reach_count_dev, sizeof(unsigned long long)));
@@ -1742,6 +1752,8 @@ int asora_last_raytrace_counts_ex(long long *gamma_cells, long long *evaluated_c
     if (zero_rates_left_out) *zero_rates_left_out = (long long)tot[2];
     return 0;
 }
+
+int asora_last_raytrace_variant(void) { return g_state.last_variant; }
 
 int asora_debug_coldens(double R, double sig, double dr, int source_index, double *coldens_out, int N)
 {

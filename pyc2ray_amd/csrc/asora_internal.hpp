@@ -53,6 +53,7 @@ struct RtParams {
     int fortran_consts, grey, z_transposed;
     int src_begin, src_count;
     int shape_src_count;   // source count the launch shape is chosen for (the whole call's, not a pipelined range's)
+    int split_desc;        // 1: N > 512 -- the buffer descriptors of the rate atomics span ONE layout of the grid each (raytrace.hip)
     int radius_stays;      // decided once per call (note_call_radius): the line-aligned tables may be built for this radius
     int ablate;            // diagnostics only (env ASORA_ABLATE): 1 = no rate atomics, 2 = no rates
     OctGeomDev geom[MAX_UNITS]; // by value: pointers read from the kernarg segment are known-global to the compiler
@@ -146,9 +147,9 @@ struct State {
     hipEvent_t zero_probe_done = nullptr;
     bool zero_probe_pending = false, zero_known = false, zero_dark = false;
     int zero_since_probe = 0;
-    double rt_last_R = -1.0;
-    long rt_same_R_calls = 0;
-    bool rt_R_has_changed = false;
+    int last_variant = 0;                   // ASORA_VARIANT_* bits | units << 8 | threads << 16 of the last raytrace launch
+    struct RadiusHistory { double last_R = -1.0; long same_R_calls = 0; bool has_changed = false; };
+    RadiusHistory rt_radius[2];             // [0]: whole-box traces and the evolve loop, [1]: the sub-box sweep (note_call_radius)
     // host copies of the two source lists (as uploaded, and in lexicographic order of the position) and, for the paired-sources
     // variant on aligned tables, who shares a workgroup with whom: built once per (list, range), see source_pairs_by_class
     std::vector<int32_t> src_pos_host, src_pos_sorted_host;
@@ -157,6 +158,7 @@ struct State {
     int geom_units = 0;
     double2 *logtab_dev = nullptr;          // log2 table (ensure_logtab), lives until the runtime is torn down
     bool geom_valid = false;
+    bool geom_on_host = false;              // the cached tables were built by the host builder (ASORA_OPT_GEOMETRY_ON_HOST)
     // table entries of cells that sit (to rounding) exactly ON the sphere: whether such a cell gets a rate is decided by
     // the reference's floating-point distance test, whose outcome depends on dr.  They are always tabulated (evaluated);
     // their RATE bit is re-decided in place when dr changes (a cosmological run: every time step) -- no rebuild.
@@ -251,7 +253,7 @@ struct State {
     struct PendingTimer { int which; hipEvent_t e0, e1; };
     std::vector<PendingTimer> pending_timers;     // recorded, not yet resolved
     std::vector<hipEvent_t> free_events;
-    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0};
+    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
     double k_ms[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
     long k_n[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
 };
@@ -289,11 +291,24 @@ constexpr unsigned CELL_VALID = 1u << 30, CELL_LAST = 1u << 31, CELL_RATE = 1u <
                    CELL_NEG_SHIFT = 22,               // bits 22..24: the cell lies on the mirrored side of axis 0 / 1 / 2 (axes the unit merges)
                    CELL_SLOT_MASK = (1u << 22) - 1;
 
+// What one geometry table holds (geometry.hip: UnitSpec + the alignment class): a dependency-closed part of the sphere
+struct GeomTableSpec {
+    int face = -1;            // -1: whole octant(s); 0 / 1 / 2: the x- / y- / z-sector
+    int merge_mask = 0;       // bit ax: the unit covers BOTH signs of axis ax
+    int ext[3] = {0, 0, 0};   // periodic-window extent of each axis on the side the unit looks at
+    int ext_neg = 0;          // extent on the mirrored side of a merged axis
+    int wedge = -1;           // 0..3: a quarter of the sector, -1: the whole unit
+    int align_class = -1;     // 0..7: line-aligned form for sources at this position modulo 8; -1: densely packed
+};
+// geometry_device.hip: the DISTINCT tables of a launch shape built on the GPU (bit-identical to geometry.hip's host builder)
+int build_geometry_on_device(State &st, const std::vector<GeomTableSpec> &specs, double R, double dr, int q_max, int threads,
+                             int boxsize, std::vector<OctGeomDev> &out, std::vector<std::vector<int>> &step_after, int &S_all,
+                             uint32_t &max_cells_all);
 struct SubboxGeometry { int ext_r, ext_l, boxsize; };     // sub-box tables: the traversal range of raytracing.f90:174-175, the box size
 // Build (or reuse) the geometry tables for (N, R, dr, threads, units): geometry.hip
 int ensure_geometry(State &st, RtParams &p, int threads, int units, const SubboxGeometry *sbg = nullptr, bool aligned = false);
 void release_geometry(State &st);
-bool note_call_radius(State &st, double R);   // once per call: may the eight-fold aligned tables be built for this radius?
+bool note_call_radius(State &st, double R, int path);   // once per API call: may the eight-fold aligned tables be built for this radius?
 void release_pair_lists(State &st);     // with every change of the source lists
 int launch_fold_range(State &st, const double *src_t, double *dst, int i_begin, int i_count);   // dst[i][j][k] += src_t[k][j][i], i in the range
 int ensure_logtab(State &st);

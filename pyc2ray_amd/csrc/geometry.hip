@@ -429,7 +429,8 @@ int ensure_geometry(State &st, RtParams &p, int threads, int units, const Subbox
     const int boxsize = sbg ? sbg->boxsize : 0;
     // dr only matters for the cells that sit exactly on the sphere (a cosmological run changes dr every step): their RATE
     // bits are re-decided in place
-    if (st.geom_valid && st.geom_N == N && st.geom_R == p.R && st.geom_threads == threads && st.geom_units == units &&
+    const bool on_host = st.opt[ASORA_OPT_GEOMETRY_ON_HOST] != 0;
+    if (st.geom_valid && st.geom_on_host == on_host && st.geom_N == N && st.geom_R == p.R && st.geom_threads == threads && st.geom_units == units &&
         st.geom_aligned == aligned && st.geom_subbox == (sbg ? 1 : 0) && (!sbg || (st.geom_ext_r == ext_pos && st.geom_ext_l == ext_neg && st.geom_boxsize == boxsize))) {
         if (st.geom_dr != p.dr && !st.geom_sphere.empty()) {
             if (int rc = patch_sphere_cells(st, p.R, p.dr)) return rc;
@@ -515,14 +516,42 @@ int ensure_geometry(State &st, RtParams &p, int threads, int units, const Subbox
             }
         }
     }
-    std::vector<HostGeom> hg(tables);       // [class * units + unit]; the distinct ones are at [class * units + owner[unit]]
     OctGeomDev od[MAX_UNITS];
+    int Smax = 0;
+    uint32_t max_cells = 1;
+    std::vector<int> steps_after[12];
+    if (!on_host) {
+        // ---- the default: the distinct tables are built on the device (geometry_device.hip) ----
+        std::vector<GeomTableSpec> specs;
+        std::vector<int> where((size_t)tables, -1);
+        for (int cls = 0; cls < classes; ++cls)
+            for (int u = 0; u < units; ++u) {
+                if (owner[u] != u) continue;
+                GeomTableSpec g;
+                g.face = spec[u].face; g.merge_mask = spec[u].merge_mask; g.ext_neg = spec[u].ext_neg; g.wedge = spec[u].wedge;
+                for (int ax = 0; ax < 3; ++ax) g.ext[ax] = spec[u].ext[ax];
+                g.align_class = aligned ? cls : -1;
+                where[(size_t)(cls * units + u)] = (int)specs.size();
+                specs.push_back(g);
+            }
+        std::vector<OctGeomDev> built;
+        std::vector<std::vector<int>> after;
+        if (int rc = build_geometry_on_device(st, specs, p.R, p.dr, q_max, threads, boxsize, built, after, Smax, max_cells)) {
+            release_geometry(st);
+            return rc;
+        }
+        for (int v = 0; v < tables; ++v) {
+            const int src = where[(size_t)((v / units) * units + owner[v % units])];
+            od[v] = built[(size_t)src];
+            od[v].info = info[v % units];
+        }
+        for (int u = 0; u < units && u < 12; ++u) steps_after[u] = after[(size_t)where[(size_t)owner[u]]];
+    } else {
+    std::vector<HostGeom> hg(tables);       // [class * units + unit]; the distinct ones are at [class * units + owner[unit]]
     const bool geom_timing = getenv("ASORA_GEOM_TIMING") != nullptr;
     auto now_s = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now_s();
     double t_sectors = t_begin;
-    int Smax = 0;
-    uint32_t max_cells = 1;
     const uint32_t MARK = 0xffffffffu;
     {   // the tables of the distinct units are independent: one host thread each (a whole-box trace tabulates N^3
         // cells per unit set -- ~1 s on one core at 320^3)
@@ -609,6 +638,9 @@ int ensure_geometry(State &st, RtParams &p, int threads, int units, const Subbox
                 units, entries * 1e-6, entries * 32e-6, t_sectors - t_begin, t_built - t_sectors, now_s() - t_built);
     }
 
+    for (int u = 0; u < units && u < 12; ++u) steps_after[u] = hg[owner[u]].step_after_shell;
+    }   // host builder
+
     if (int rc = ensure_logtab(st)) return rc;
     const double2 *ltd = st.logtab_dev;
 
@@ -618,7 +650,8 @@ int ensure_geometry(State &st, RtParams &p, int threads, int units, const Subbox
     st.geom_N = N; st.geom_R = p.R; st.geom_dr = p.dr; st.geom_S = Smax; st.geom_max_cells = (int)max_cells;
     st.geom_threads = threads;
     st.geom_subbox = sbg ? 1 : 0; st.geom_ext_r = ext_pos; st.geom_ext_l = ext_neg; st.geom_boxsize = boxsize;
-    for (int u = 0; u < units && u < 12; ++u) st.geom_step_after_shell[u] = hg[owner[u]].step_after_shell;
+    for (int u = 0; u < units && u < 12; ++u) st.geom_step_after_shell[u] = steps_after[u];
+    st.geom_on_host = on_host;
     st.geom_valid = true;
     for (int o = 0; o < tables; ++o) p.geom[o] = od[o];
     p.units = units;
@@ -627,5 +660,35 @@ int ensure_geometry(State &st, RtParams &p, int threads, int units, const Subbox
     return 0;
 }
 
-
 } // namespace asora
+
+extern "C" int asora_debug_geometry_table(int table, uint32_t *words, size_t capacity_entries, size_t *entries, int *nsteps, int *ntables,
+                                          int *shells, int *max_cells, int *threads)
+{
+    using namespace asora;
+    clear_error();
+    State &st = state();
+    if (!st.geom_valid) return fail(4, "debug_geometry_table: no geometry tables (no raytrace yet)");
+    const int nt = st.geom_units * (st.geom_aligned ? 8 : 1);
+    if (ntables) *ntables = nt;
+    if (shells) *shells = st.geom_S;
+    if (max_cells) *max_cells = st.geom_max_cells;
+    if (threads) *threads = st.geom_threads;
+    if (table < 0) return 0;
+    if (table >= nt) return fail(3, "debug_geometry_table: no such table");
+    const OctGeomDev &g = st.geom_host[table];
+    const size_t n = ((size_t)g.nsteps + 4) * (size_t)st.geom_threads;
+    if (entries) *entries = n;
+    if (nsteps) *nsteps = g.nsteps;
+    if (!words) return 0;
+    if (capacity_entries < n) return fail(3, "debug_geometry_table: buffer too small");
+    ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
+    std::vector<uint4> a(n), b(n);
+    ASORA_HIP_TRY(hipMemcpy(a.data(), g.cellA, n * sizeof(uint4), hipMemcpyDeviceToHost));
+    ASORA_HIP_TRY(hipMemcpy(b.data(), g.cellB, n * sizeof(uint4), hipMemcpyDeviceToHost));
+    for (size_t q = 0; q < n; ++q) {
+        std::memcpy(words + 8 * q, &a[q], 16);
+        std::memcpy(words + 8 * q + 4, &b[q], 16);
+    }
+    return 0;
+}

@@ -252,26 +252,27 @@ __global__ void __launch_bounds__(256) reach_mask_kernel(const int32_t *__restri
                                                          int S, double R2hi, unsigned char *__restrict__ mask, size_t bytes_one_layout)
 {
     const int side = 2 * S + 1;
-    const long per_src = 2L * side * side;
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= per_src * src_count) return;
-    const int s = src_begin + (int)(t / per_src);
-    const int r = (int)(t % per_src);
+    const int per_src = 2 * side * side;                                          // (S <= N/2 <= 640: < 2^22)
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= per_src) return;
     const int layout = r / (side * side);
     const int u = (r % (side * side)) / side - S, v = (r % side) - S;         // u: offset along the slowest axis of the layout, v: along j
     const double rest = R2hi - (double)u * u - (double)v * v;
     if (rest < 0.0) return;
     int half = (int)floor(sqrt(rest));
     if (half > N / 2) half = N / 2;                                           // (the whole axis)
-    const int i0 = src_pos[3 * s], j0 = src_pos[3 * s + 1], k0 = src_pos[3 * s + 2];
-    // layout 0: line (i, j, k >> 3), chord along k;  layout 1: line (k, j, i >> 3), chord along i
-    const int outer0 = layout == 0 ? i0 : k0, fast0 = layout == 0 ? k0 : i0;
-    int outer = (outer0 + u) % N; if (outer < 0) outer += N;
-    int j = (j0 + v) % N; if (j < 0) j += N;
-    unsigned char *row = mask + (size_t)layout * bytes_one_layout + ((size_t)outer * N + j) * NL;
-    for (int c = -half; c <= half; ++c) {
-        int f = (fast0 + c) % N; if (f < 0) f += N;
-        row[f >> 3] = 1;                                                       // (every writer writes 1)
+    for (int sl = blockIdx.y; sl < src_count; sl += gridDim.y) {              // sources on the grid's second dimension (any count)
+        const int s = src_begin + sl;
+        const int i0 = src_pos[3 * s], j0 = src_pos[3 * s + 1], k0 = src_pos[3 * s + 2];
+        // layout 0: line (i, j, k >> 3), chord along k;  layout 1: line (k, j, i >> 3), chord along i
+        const int outer0 = layout == 0 ? i0 : k0, fast0 = layout == 0 ? k0 : i0;
+        int outer = (outer0 + u) % N; if (outer < 0) outer += N;
+        int j = (j0 + v) % N; if (j < 0) j += N;
+        unsigned char *row = mask + (size_t)layout * bytes_one_layout + ((size_t)outer * N + j) * NL;
+        for (int c = -half; c <= half; ++c) {
+            int f = (fast0 + c) % N; if (f < 0) f += N;
+            row[f >> 3] = 1;                                                   // (every writer writes 1)
+        }
     }
 }
 
@@ -299,9 +300,9 @@ int launch_reach_mask(State &st, const int32_t *src_pos, int src_begin, int src_
     const int N = st.N, NL = (N + 7) / 8;
     const double R2hi = R * R * (1.0 + 1e-9) + 1e-9;                          // as the geometry tables' outer bound (geometry.hip)
     const int S = (int)std::min((double)(N / 2), std::floor(std::sqrt(R2hi)));
-    const long threads = 2L * (2 * S + 1) * (2 * S + 1) * src_count;
-    hipLaunchKernelGGL(reach_mask_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st.stream, src_pos, src_begin, src_count, N, NL,
-                       S, R2hi, mask, bytes_one_layout);
+    const int per_src = 2 * (2 * S + 1) * (2 * S + 1);
+    hipLaunchKernelGGL(reach_mask_kernel, dim3((unsigned)((per_src + 255) / 256), (unsigned)std::min(src_count, 65535)), dim3(256), 0, st.stream,
+                       src_pos, src_begin, src_count, N, NL, S, R2hi, mask, bytes_one_layout);
     ASORA_HIP_TRY(hipGetLastError());
     return 0;
 }

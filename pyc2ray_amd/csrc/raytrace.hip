@@ -251,6 +251,9 @@ extern "C" __device__ double asora_buffer_atomic_fadd_f64(double, __amdgpu_buffe
 //   column-density dump            256 x {256,1024}                                f/t  t    f    f         f/t  f       1    f        launch_variant
 //   sub-box sweep                  {256,512} x 256                                 f    f    f/t  f         f    t       1|2  t        launch_subbox_tables_variant
 //   (SKIP_ZERO with HEAT or GREY, NSRC = 2 with HEAT, DUMP, GREY or global atomics, SUBBOX with NSRC = 2 and HEAT: not built)
+// split descriptors: does this unit's face write the [k][j][i] twin?  (the z-sector with the twins in use)
+__device__ __forceinline__ bool ztr_desc(const RtParams &p, int uinfo) { return p.z_transposed != 0 && ((uinfo >> 8) & 3) == 3; }
+
 template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP, bool HEAT, int TABCAP, bool SKIP_ZERO = false, bool GREY = false,
           bool BUFATOM = false, int NSRC = 1, bool SUBBOX = false>
 __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? ASORA_PAIR_MIN_WAVES : ASORA_MIN_WAVES) : 1)) raytrace_octant_kernel(const RtParams p)
@@ -367,16 +370,23 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     unsigned int src_cell_gamma = 0, src_cell_eval = 0;      // the source cell (thread 0 only)
 
     // rate accumulation: `idx` indexes [phi | phi_t] (and [heat | heat_t])
-    __amdgpu_buffer_rsrc_t rs_phi = __builtin_amdgcn_make_buffer_rsrc(p.phi, 0, BUFATOM ? (int)(16u * p.ncell) : 0, 0x00020000);
-    __amdgpu_buffer_rsrc_t rs_heat = __builtin_amdgcn_make_buffer_rsrc(HEAT ? p.heat : p.phi, 0, (BUFATOM && HEAT) ? (int)(16u * p.ncell) : 0, 0x00020000);
+    // One descriptor over [phi | phi_t] while the pair fits 2 GiB (N <= 512).  Beyond (p.split_desc, N <= 645 -- the reference's
+    // own limit, raytracing.cu:95): a descriptor over ONE layout, N^3 doubles -- possible for units whose rated cells all lie on
+    // one face (the sectors), where the layout is the same for the whole workgroup: the descriptor starts at the layout the
+    // unit's face writes and `desc_off8` (a scalar, 0 when not split) takes that layout's offset out of the byte offsets.
+    const bool unit_in_twin = p.split_desc && ztr_desc(p, uinfo);
+    const unsigned desc_cells = (BUFATOM && p.split_desc) ? p.ncell : 2u * p.ncell;
+    const int desc_off8 = unit_in_twin ? -(int)(8u * p.ncell) : 0;
+    __amdgpu_buffer_rsrc_t rs_phi = __builtin_amdgcn_make_buffer_rsrc(p.phi + (unit_in_twin ? p.ncell : 0u), 0, BUFATOM ? (int)(8u * desc_cells) : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_heat = __builtin_amdgcn_make_buffer_rsrc((HEAT ? p.heat : p.phi) + (unit_in_twin ? p.ncell : 0u), 0, (BUFATOM && HEAT) ? (int)(8u * desc_cells) : 0, 0x00020000);
     auto add_phi = [&](bool ok, unsigned idx, double v) {
         if (ASORA_ABLATED(1)) ok = ok && v == 1.2345e-300;
         if (ASORA_ABLATED(64)) idx &= 0xFFFFu;            // diagnostic: all rates into a 512 KiB window (wrong results)
-        if (BUFATOM) (void)asora_buffer_atomic_fadd_f64(v, rs_phi, ok ? (int)(idx * 8u) : ASORA_OOB_OFFSET, 0, 0);
+        if (BUFATOM) (void)asora_buffer_atomic_fadd_f64(v, rs_phi, ok ? (int)(idx * 8u) + desc_off8 : ASORA_OOB_OFFSET, 0, 0);
         else if (ok) unsafeAtomicAdd(p.phi + idx, v);
     };
     auto add_heat = [&](bool ok, unsigned idx, double v) {
-        if (BUFATOM) (void)asora_buffer_atomic_fadd_f64(v, rs_heat, ok ? (int)(idx * 8u) : ASORA_OOB_OFFSET, 0, 0);
+        if (BUFATOM) (void)asora_buffer_atomic_fadd_f64(v, rs_heat, ok ? (int)(idx * 8u) + desc_off8 : ASORA_OOB_OFFSET, 0, 0);
         else if (ok) unsafeAtomicAdd(p.heat + idx, v);
     };
     // BUFATOM: a pending rate is carried as the byte offset its atomic will use -- ASORA_OOB_OFFSET when the lane has nothing
@@ -751,7 +761,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
 #pragma unroll
                 for (int q = 0; q < NSRC; ++q) {
                     pend_A[q] = A2[q]; pend_B[q] = B2[q]; pend_thick[q] = thick[q]; pend_pref[q] = pref[q]; pend_dtau[q] = dtau[q];
-                    if (BUFATOM) late_off[q] = add[q] ? (int)(dst_idx[q] * 8u) : ASORA_OOB_OFFSET;
+                    if (BUFATOM) late_off[q] = add[q] ? (int)(dst_idx[q] * 8u) + desc_off8 : ASORA_OOB_OFFSET;
                     else { late_idx[q] = dst_idx[q]; late_ok[q] = add[q]; }
                 }
             }
@@ -984,6 +994,19 @@ static bool pair_sources_pays(const State &st, double R, int N, int src_count, i
     return (long)(src_count / 2) * units * (threads / 64) >= 8L * st.cu_count;
 }
 
+// Can the rate atomics go through buffer descriptors (the kernel's BUFATOM)?  One descriptor over both layouts of the rate
+// grid while the pair fits 2 GiB (N <= 512); one per layout (split) up to 2 GiB per layout (N <= 645) for units whose rated
+// cells all lie on one face -- the sector kinds.
+static bool buffer_atomics_fit(const State &st, const RtParams &p, int units, bool &split)
+{
+    split = false;
+    if (st.opt[ASORA_OPT_GLOBAL_ATOMICS]) return false;
+    if (16ull * p.ncell <= 0x80000000ull) return true;
+    const bool one_face = units == 3 || units == 6 || units == 12 || units == 24 || units == 96;
+    if (8ull * p.ncell <= 0x80000000ull && one_face && p.z_transposed) { split = true; return true; }
+    return false;
+}
+
 constexpr size_t lds_table_bytes(int tabcap, int nsrc = 1) { return LOG_TABLE_SIZE * sizeof(double2) + (size_t)tabcap * (sizeof(double) + (size_t)nsrc * 6 * sizeof(int)); }
 
 // the paired-sources variant (NSRC = 2) exists for the production path only: table rates, no heating, no dump, shell
@@ -1019,7 +1042,8 @@ static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t ld
     } while (0)
     const bool grey = q.grey != 0;
     // rate atomics through buffer descriptors (see the kernel's BUFATOM): [phi | phi_t] must not exceed 2 GiB
-    const bool ba = use_lds && 16ull * q.ncell <= 0x80000000ull && !st.opt[ASORA_OPT_GLOBAL_ATOMICS];
+    bool split_ = false;
+    const bool ba = use_lds && buffer_atomics_fit(st, q, q.units, split_);      // (q.split_desc was set from the same test)
     if (T == 256 && dump) {
         if (grey)         { if (use_lds) ASORA_LAUNCH(false, true, false, false, true, false); else ASORA_LAUNCH(true, true, false, false, true, false); }
         else              { if (use_lds) ASORA_LAUNCH(false, true, false, false, false, false); else ASORA_LAUNCH(true, true, false, false, false, false); }
@@ -1086,15 +1110,19 @@ __global__ void __launch_bounds__(ZERO_PROBE_SLOTS) zero_probe_sum_kernel(const 
 
 // How the radius behaves from call to call (a call = one raytrace of the library's API, one time step of the evolve loop):
 // the eight-fold line-aligned tables only pay when they are reused (see launch_raytrace)
-bool note_call_radius(State &st, double R)
+bool note_call_radius(State &st, double R, int path)
 {
-    if (R != st.rt_last_R) {
-        if (st.rt_last_R >= 0.0) st.rt_R_has_changed = true;
-        st.rt_last_R = R;
-        st.rt_same_R_calls = 0;
+    // (one history per path -- 0: the whole-box ASORA trace and the evolve loop, 1: the sub-box sweep, whose R is R_max_LLS and
+    //  whose calls alternate with the other's in a process that uses both: a shared history would see the radius "change" on
+    //  every alternation and never let the aligned tables back in)
+    State::RadiusHistory &h = st.rt_radius[path ? 1 : 0];
+    if (R != h.last_R) {
+        if (h.last_R >= 0.0) h.has_changed = true;
+        h.last_R = R;
+        h.same_R_calls = 0;
     }
-    st.rt_same_R_calls += 1;
-    return !st.rt_R_has_changed || st.rt_same_R_calls > 32;
+    h.same_R_calls += 1;
+    return !h.has_changed || h.same_R_calls > 32;
 }
 
 int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t side)
@@ -1127,6 +1155,10 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
         aligned = possible && (want == 2 || (want == 0 && r < 52.5 && p.radius_stays));
     }
     if (int rc = ensure_geometry(st, p, threads, units, nullptr, aligned)) return rc;
+    bool split = false;
+    const bool bufatom_fits = buffer_atomics_fit(st, p, units, split);
+    p.split_desc = split ? 1 : 0;
+    st.last_variant = 0;
     p.lut_k1 = 0.30102999566398119521 / p.dlogtau;      // log10(2)/dlogtau
     p.lut_k0 = 1.0 - p.minlogtau / p.dlogtau;
     // optical depth from which BOTH lookups of a thick cell return the same table value (index clamped to NumTau, or on
@@ -1156,7 +1188,7 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
     {
         const int want = st.opt[ASORA_OPT_PAIR_SOURCES];
         const bool possible = use_lds && !dump && !heat && !p.grey && !big_tables && threads <= 512 &&
-                              16ull * p.ncell <= 0x80000000ull && !st.opt[ASORA_OPT_GLOBAL_ATOMICS] && p.src_count >= 2 &&
+                              bufatom_fits && p.src_count >= 2 &&
                               2 * shell_bytes + lds_table_bytes((p.S + 1 <= 32 && threads == 256) ? 32 : (p.S + 1 <= 64 && threads <= 256) ? 64 : 256, 2) <= LDS_LIMIT_BYTES;
         pairs = possible && (want == 2 || (want == 0 && pair_sources_pays(st, p.R, p.N, p.shape_src_count > 0 ? p.shape_src_count : p.src_count, units, threads)));
     }
@@ -1186,8 +1218,7 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
     // waiting, by a later call: the first launch, every 64th after it, every launch while the dark variant runs anyway.
     bool skip_zero = false, probe = false;
     {
-        const bool exists = use_lds && !dump && !heat && !p.grey && std::isfinite(p.tau_zero) && 16ull * p.ncell <= 0x80000000ull &&
-                            !st.opt[ASORA_OPT_GLOBAL_ATOMICS];
+        const bool exists = use_lds && !dump && !heat && !p.grey && std::isfinite(p.tau_zero) && bufatom_fits;
         if (exists && skip_zero_opt == 1) skip_zero = true;
         else if (exists && skip_zero_opt == 0) {
             if (!st.zero_probe_dev) {
@@ -1245,6 +1276,9 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
         }
         q.spread = (long)groups * units <= 2L * st.cu_count ? 1 : 0;     // few workgroups: spread a source's units over the XCDs
         const unsigned grid = q.spread ? (unsigned)units * (unsigned)groups : 8u * (unsigned)units * (unsigned)((groups + 7) / 8);
+        st.last_variant = (pairs ? ASORA_VARIANT_PAIRED : 0) | (aligned ? ASORA_VARIANT_ALIGNED : 0) |
+                          ((bufatom_fits && use_lds && !dump) ? ASORA_VARIANT_BUFFER_ATOMICS : 0) | (split ? ASORA_VARIANT_SPLIT_DESCRIPTORS : 0) |
+                          (skip_zero ? ASORA_VARIANT_SKIP_ZERO : 0) | (use_lds ? 0 : ASORA_VARIANT_GLOBAL_SHELLS) | (units << 8) | (threads << 16);
         {
             KernelTimer kt(ASORA_KERNEL_RAYTRACE, stream);
             int rc = 0;
@@ -1312,7 +1346,7 @@ int subbox_tables_prepare(State &st, RtParams &p, int ext_r, int ext_l, int subb
     out = SubboxTables();
     const int want = st.opt[ASORA_OPT_SUBBOX_TABLES];
     if (want == 1 || p.grey || ext_r <= 0 || ext_l <= 0 || src_count < 1) return 0;
-    if (16ull * p.ncell > 0x80000000ull || st.opt[ASORA_OPT_GLOBAL_ATOMICS] || !p.z_transposed) return 0;   // the rates go through buffer atomics
+    if (!p.z_transposed || st.opt[ASORA_OPT_GLOBAL_ATOMICS] || 8ull * p.ncell > 0x80000000ull) return 0;   // the rates go through buffer atomics
     const double R2hi = p.R * p.R * (1.0 + 1e-9) + 1e-9;
     const int range = std::max(ext_r, ext_l);
     const int S_tab = std::isfinite(R2hi) ? (int)std::min((double)range, std::floor(std::sqrt(R2hi))) : range;
@@ -1330,6 +1364,11 @@ int subbox_tables_prepare(State &st, RtParams &p, int ext_r, int ext_l, int subb
     else if (r < 52.5) { units = 12; threads = 256; }
     else { units = 12; threads = 512; }
     if (want == 0 && (long)src_count * units < 2L * st.cu_count) return 0;     // a handful of sources: subbox.hip's wide workgroups
+    {
+        bool split = false;
+        if (!buffer_atomics_fit(st, p, units, split)) return 0;               // (N > 512: the sector kinds only)
+        p.split_desc = split ? 1 : 0;
+    }
     const SubboxGeometry sbg{ext_r, ext_l, subboxsize};
     if (int rc = ensure_geometry(st, p, threads, units, &sbg)) return rc;
     const size_t slots = ((size_t)p.max_cells + 2) & ~(size_t)1;

@@ -318,6 +318,29 @@ class _LibAsora:
         _capi.check(self._lib.asora_last_raytrace_counts_ex(C.byref(g), C.byref(e), C.byref(z)), "last_raytrace_counts_ex")
         return z.value
 
+    def last_raytrace_variant(self):
+        """{"paired", "aligned", "buffer_atomics", "split_descriptors", "skip_zero", "global_shells": bool, "units", "threads"} of the
+        last raytrace launch (asora_last_raytrace_variant)."""
+        v = self._lib.asora_last_raytrace_variant()
+        return {"paired": bool(v & 1), "aligned": bool(v & 2), "buffer_atomics": bool(v & 4), "split_descriptors": bool(v & 8),
+                "skip_zero": bool(v & 16), "global_shells": bool(v & 32), "units": (v >> 8) & 255, "threads": v >> 16}
+
+    def debug_geometry_tables(self):
+        """The geometry tables of the last raytrace launch: (list of (entries x 8) uint32 arrays, dict(nsteps, shells, max_cells, threads))."""
+        n, ns, nt, sh, mc, th = C.c_size_t(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        _capi.check(self._lib.asora_debug_geometry_table(-1, None, 0, C.byref(n), C.byref(ns), C.byref(nt), C.byref(sh), C.byref(mc),
+                                                         C.byref(th)), "debug_geometry_table")
+        tables, steps = [], []
+        for t in range(nt.value):
+            _capi.check(self._lib.asora_debug_geometry_table(t, None, 0, C.byref(n), C.byref(ns), C.byref(nt), C.byref(sh), C.byref(mc),
+                                                             C.byref(th)), "debug_geometry_table")
+            a = np.zeros((n.value, 8), dtype=np.uint32)
+            _capi.check(self._lib.asora_debug_geometry_table(t, a.ctypes.data_as(C.POINTER(C.c_uint32)), n.value, C.byref(n), C.byref(ns),
+                                                             C.byref(nt), C.byref(sh), C.byref(mc), C.byref(th)), "debug_geometry_table")
+            tables.append(a)
+            steps.append(ns.value)
+        return tables, {"nsteps": steps, "shells": sh.value, "max_cells": mc.value, "threads": th.value}
+
     def build_id(self):
         """Hash over the library's sources, headers and compiler flags (asora_build_id)."""
         return self._lib.asora_build_id().decode()

@@ -384,7 +384,7 @@ def test_config4_512_all_1e5_sources_evolve_loop_and_reference_subset(asora, ben
 
 
 # ---- meshes beyond the buffer descriptors' range -----------------------------------------------------------------------
-def test_mesh_576_global_atomic_family_at_real_size(asora):
+def test_mesh_576_both_atomic_families_at_real_size(asora):
     """N > 512: [phi | phi_t] no longer fits the 2 GiB a raw buffer descriptor spans, so the rates go through
     global_atomic_add_f64 with one 32-bit cell index over both layouts (2 x 576^3 = 3.8e8 < 2^32) formed by two 24-bit
     multiply-adds (raytrace.hip, nhi_address), and neither the paired-sources variant nor the line-aligned tables exist.
@@ -454,6 +454,36 @@ def test_mesh_576_global_atomic_family_at_real_size(asora):
     assert np.array_equal(many != 0, w)
     np.testing.assert_allclose(many[w], ref[w], rtol=1e-8, atol=0)
     del many, ref, w
+
+    # the production forms beyond N = 512 (round 5).  At r_RT = 30 a source is cut into six sectors, whose rated cells lie on one
+    # face each, so the rate atomics of a workgroup go through a buffer descriptor over ONE layout of the grid (8 N^3 bytes
+    # <= 2 GiB up to N = 645, the reference's own limit, raytracing.cu:95) -- and with buffer atomics come two sources per
+    # workgroup and the line-aligned tables.  Against the oracle, and against the global-atomic family forced onto the same launch.
+    R2, NM2 = 30.0, 320
+    lib.source_data_to_device(m0[:3 * NM2], mf0[:NM2], NM2)
+    lib.set_option(capi.OPT_ALIGNED_ROWS, 2)      # (left to itself the library waits for a radius to settle: it has just changed)
+    lib.raytrace_device(R2, cases.SIG, dr, 0, NM2, cases.MINLOGTAU, dlog, numtau)
+    lib.set_option(capi.OPT_ALIGNED_ROWS, 0)
+    v = lib.last_raytrace_variant()
+    assert v["paired"] and v["aligned"] and v["buffer_atomics"] and v["split_descriptors"] and v["units"] == 6, v
+    prod = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+    gam, ev = lib.last_raytrace_counts()
+    assert gam == NM2 * _lattice_points_within(R2)
+    ref = O.asora_do_all_sources(R2, cases.SIG, dr, nd, xh, m0[:3 * NM2], mf0[:NM2], thin, thick, cases.MINLOGTAU, dlog,
+                                 NumTau=numtau, flags=O.ASORA_MODE)["phi_ion"]
+    w = ref != 0
+    assert np.array_equal(prod != 0, w)
+    np.testing.assert_allclose(prod[w], ref[w], rtol=1e-8, atol=0)
+    del ref
+    lib.set_option(capi.OPT_GLOBAL_ATOMICS, 1)
+    lib.raytrace_device(R2, cases.SIG, dr, 0, NM2, cases.MINLOGTAU, dlog, numtau)
+    v = lib.last_raytrace_variant()
+    assert not v["buffer_atomics"] and not v["paired"] and not v["split_descriptors"], v
+    lib.set_option(capi.OPT_GLOBAL_ATOMICS, 0)
+    glob = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+    assert np.array_equal(glob != 0, w)
+    np.testing.assert_allclose(glob[w], prod[w], rtol=1e-11, atol=0)
+    del glob, prod, w
 
     # one iteration of the device-resident loop against the separate calls
     lib.source_data_to_device(p0, f0, NS)
