@@ -269,6 +269,7 @@ __global__ void __launch_bounds__(GB_THREADS) geometry_write_kernel(const TableJ
     const size_t e0 = shell_entry[J.meta_base + s];
     const bool aligned = us.align_class >= 0 && us.face >= 0;
     const double sd = (double)s;
+    const int len = shell_len[J.meta_base + s];         // entries of the shell's steps proper (before any sub-box padding)
     for (int cand = threadIdx.x; cand < ncand; cand += GB_THREADS) {
         const uint32_t slot = rank[base + cand];
         if (slot == MARK) continue;
@@ -317,18 +318,20 @@ __global__ void __launch_bounds__(GB_THREADS) geometry_write_kernel(const TableJ
         if (nb.y == MARK) nb.y = max_cells;
         if (nb.z == MARK) nb.z = max_cells;
         if (nb.w == MARK) nb.w = max_cells;
-        const size_t at = e0 + (aligned ? pos[base + cand] : slot);
+        const uint32_t in_shell = aligned ? pos[base + cand] : slot;
+        const size_t at = e0 + in_shell;
         J.cellA[at] = ca;
         J.cellB[at] = nb;
-        if (s == 1 && (aligned ? pos[base + cand] : slot) >= (uint32_t)(3 * P.threads)) atomicOr(flags, 2);   // shell 1 within the first three steps
+        if (s == 1 && in_shell >= (uint32_t)(3 * P.threads)) atomicOr(flags, 2);   // shell 1 within the first three steps
         if (sph) {
+            // (the word the patch writes: as the entry will stand once the shell's last step has been flagged, below)
+            const uint32_t last = (int)in_shell >= len - P.threads ? CELL_LAST : 0u;
             const unsigned q = atomicAdd(n_sphere, 1u);
-            if (q < sphere_cap) sphere[q] = SphereRecord{(unsigned long long)at, ca.y & ~CELL_RATE, a, b, c, blockIdx.y};
+            if (q < sphere_cap) sphere[q] = SphereRecord{(unsigned long long)at, (ca.y & ~CELL_RATE) | last, a, b, c, blockIdx.y};
         }
     }
     // every entry of the shell's last step carries CELL_LAST (padding included)
     __syncthreads();
-    const int len = shell_len[J.meta_base + s];         // entries of the shell's steps proper (before any sub-box padding)
     for (int q = threadIdx.x; q < P.threads; q += GB_THREADS) J.cellA[e0 + (size_t)(len - P.threads + q)].y |= CELL_LAST;
 }
 
@@ -419,6 +422,7 @@ __global__ void __launch_bounds__(GB_THREADS) wedge_write_kernel(const WedgeJob 
     const size_t e0 = shell_entry[J.meta_base + s], ep = shell_entry[J.meta_base + s - 1];
     const size_t w0 = wshell_entry[J.wmeta_base + s];
     const int n = count[J.meta_base + s];
+    const int len = wshell_len[J.wmeta_base + s];
     for (int q = threadIdx.x; q < n; q += GB_THREADS) {
         const uint32_t ns = newslot[J.keep_base + e0 + q];
         if (ns == MARK) continue;
@@ -438,13 +442,13 @@ __global__ void __launch_bounds__(GB_THREADS) wedge_write_kernel(const WedgeJob 
         J.cellB[w0 + ns] = b;
         if (s == 1 && ns >= (uint32_t)(3 * threads)) atomicOr(flags, 2);
         if (a.y & CELL_SPHERE) {
+            const uint32_t last = (int)ns >= len - threads ? CELL_LAST : 0u;
             const unsigned k = atomicAdd(n_sphere, 1u);
-            if (k < sphere_cap) sphere[k] = SphereRecord{(unsigned long long)(w0 + ns), a.y & ~CELL_RATE, (int)(a.x & 1023), (int)((a.x >> 10) & 1023),
+            if (k < sphere_cap) sphere[k] = SphereRecord{(unsigned long long)(w0 + ns), (a.y & ~CELL_RATE) | last, (int)(a.x & 1023), (int)((a.x >> 10) & 1023),
                                                          (int)((a.x >> 20) & 1023), table0 + blockIdx.y};
         }
     }
     __syncthreads();
-    const int len = wshell_len[J.wmeta_base + s];
     for (int q = threadIdx.x; q < threads; q += GB_THREADS) J.cellA[w0 + (size_t)(len - threads + q)].y |= CELL_LAST;
 }
 

@@ -45,7 +45,7 @@ def _tables(lib, capi, on_host, call):
     lib.set_option(capi.OPT_GEOMETRY_ON_HOST, 1 if on_host else 0)
     call()
     t, meta = lib.debug_geometry_tables()
-    meta["variant"] = lib.last_raytrace_variant()
+    meta["variant"] = {k: v for k, v in lib.last_raytrace_variant().items() if k != "skip_zero"}     # (that one follows the probes of the medium)
     return t, meta
 
 
