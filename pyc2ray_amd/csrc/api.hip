@@ -331,6 +331,7 @@ struct SubboxCall {
     int NumTau, table_len;
     const double2 *tables;          // [thick | thin | heat thick | heat thin] pairs, table_len each
     const int32_t *src_pos;         // 0-based, xyz-interleaved
+    const int32_t *host_pos;        // the same list on the host (pairing of sources for the line-aligned tables), or nullptr
     const double *src_flux;
     int src_begin, src_count;
     bool heat, keep_heat;           // keep_heat: add onto PHI_HEAT as it stands (f2py intent(inout)) instead of zeroing it
@@ -380,6 +381,9 @@ static int subbox_core(const SubboxCall &c, long long &total_nbox, double &total
 
     total_nbox = 0;
     total_loss = 0.0;
+    // (pair lists are cached by the address of the source list: a caller's temporary list must not meet an older one's entries)
+    struct DropPairs { State &s; bool on; ~DropPairs() { if (on) release_pair_lists(s); } } drop_pairs{st, c.src_pos != st.src_pos};
+    if (drop_pairs.on) release_pair_lists(st);
     // Round 3: the sources whose column densities do not go back to the caller are swept on the ASORA kernel's tabulated
     // geometry (cells within R_max_LLS only; raytrace.hip, SUBBOX) when that applies; the dumped source -- it needs the
     // whole cube -- and everything else stay with the on-the-fly kernel of subbox.hip
@@ -396,7 +400,7 @@ static int subbox_core(const SubboxCall &c, long long &total_nbox, double &total
     const int table_sources = c.src_count - (has_dump ? 1 : 0);
     {
         if (range_open && table_sources > 0)
-            if (int rc = subbox_tables_prepare(st, tp, ext_r, ext_l, c.subboxsize, table_sources, c.heat, tab)) return rc;
+            if (int rc = subbox_tables_prepare(st, tp, ext_r, ext_l, c.subboxsize, table_sources, c.heat, tab, c.host_pos)) return rc;
     }
 
     // sources in batches bounded by the scratch: the on-the-fly kernel keeps 8 octants x 2 buffers x 3 W^2 doubles per source
@@ -1181,8 +1185,10 @@ int c2ray_do_all_sources(const double *normflux, const int32_t *srcpos, int max_
     if (heat) { if (int rc = asora_grid_to_device(ASORA_GRID_PHI_HEAT, phi_heat, N, 'F')) return rc; }
 
     int32_t *d_pos = nullptr; double *d_flux = nullptr; double2 *d_tables = nullptr;
+    std::vector<int32_t> host_pos0;
     if (NumSrc > 0) {
-        std::vector<int32_t> pos0(3 * (size_t)NumSrc);
+        host_pos0.resize(3 * (size_t)NumSrc);
+        std::vector<int32_t> &pos0 = host_pos0;
         for (size_t q = 0; q < pos0.size(); ++q) pos0[q] = srcpos[q] - 1;
         if (int rc = tmp.alloc(d_pos, pos0.size())) return rc;
         if (int rc = tmp.alloc(d_flux, (size_t)NumSrc)) return rc;
@@ -1204,6 +1210,7 @@ int c2ray_do_all_sources(const double *normflux, const int32_t *srcpos, int max_
     c.max_subbox = max_subbox; c.subboxsize = subboxsize; c.loss_fraction = loss_fraction;
     c.sig = sig; c.dr = dr; c.R = R_max_LLS; c.minlogtau = minlogtau; c.dlogtau = dlogtau; c.NumTau = NumTau;
     c.table_len = len; c.tables = d_tables; c.src_pos = d_pos; c.src_flux = d_flux;
+    c.host_pos = host_pos0.empty() ? nullptr : host_pos0.data();
     c.src_begin = 0; c.src_count = NumSrc;
     c.heat = heat; c.keep_heat = true;                  // phi_heat is intent(inout): added onto what was uploaded
     c.dump = st.staging;                                // column densities of the last source
@@ -1258,6 +1265,7 @@ int asora_subbox_raytrace_device(int max_subbox, int subboxsize, float loss_frac
     c.sig = sig; c.dr = dr; c.R = R_max_LLS; c.minlogtau = minlogtau; c.dlogtau = dlogtau; c.NumTau = NumTau;
     c.table_len = st.table_len > 0 ? st.table_len : 1; c.tables = st.tables;
     c.src_pos = st.src_pos; c.src_flux = st.src_flux; c.src_begin = src_begin; c.src_count = src_count;
+    c.host_pos = st.src_pos_host.empty() ? nullptr : st.src_pos_host.data();
     c.heat = heat; c.keep_heat = false; c.dump = nullptr;
     long long total_nbox = 0;
     double total_loss = 0.0;

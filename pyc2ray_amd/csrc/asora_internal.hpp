@@ -317,8 +317,9 @@ int launch_finish_phi(State &st);
 int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t side = nullptr);   // side: stream to launch on when no shared scratch is needed
 // The sub-box sweep on tabulated geometry (raytrace.hip): prepare -> tables for (N, R, range, box size), then one launch per
 // sub-box.  `shells` = (s_begin, s_end] of the box; returns without launching when the tables hold nothing there.
-struct SubboxTables { int units = 0, threads = 0, S = 0, max_batch = 0, nsrc = 1; bool ok = false; };   // max_batch: sources per launch the trailing-shell scratch holds; nsrc: sources per workgroup (2: paired sweep)
-int subbox_tables_prepare(State &st, RtParams &p, int ext_r, int ext_l, int subboxsize, int src_count, bool heat, SubboxTables &out);
+struct SubboxTables { int units = 0, threads = 0, S = 0, max_batch = 0, nsrc = 1; bool ok = false, aligned = false; const int32_t *host_pos = nullptr; };   // max_batch: sources per launch the trailing-shell scratch holds; nsrc: sources per workgroup (2: paired sweep); host_pos: the source positions on the host (0-based, xyz-interleaved; pairing for the aligned tables) or nullptr
+int subbox_tables_prepare(State &st, RtParams &p, int ext_r, int ext_l, int subboxsize, int src_count, bool heat, SubboxTables &out,
+                          const int32_t *host_pos);
 int subbox_tables_sweep(State &st, const RtParams &p, const SubboxTables &tab, int s_begin, int s_end, bool heat);
 int launch_fold_transposed(State &st, const double *src_t, double *dst);   // dst[i][j][k] += src_t[k][j][i]
 int launch_fold_sum(State &st, const double *a, const double *b_t, double *dst);   // dst[i][j][k] = a[i][j][k] + b_t[k][j][i]

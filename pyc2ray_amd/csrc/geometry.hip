@@ -419,7 +419,7 @@ static int patch_sphere_cells(State &st, double R, double dr)
 int ensure_geometry(State &st, RtParams &p, int threads, int units, const SubboxGeometry *sbg, bool aligned)
 {
     // aligned (units of one face: 6 or 12 per source): eight tables per unit, [class * units + unit], see build_unit_geometry
-    if (aligned && (sbg || !(units == 6 || units == 12))) return fail(11, "raytrace geometry: aligned tables for this kind of unit (internal error)");
+    if (aligned && !(units == 6 || units == 12)) return fail(11, "raytrace geometry: aligned tables for this kind of unit (internal error)");
     const int classes = aligned ? 8 : 1, tables = units * classes;
     const int N = p.N;
     // (the Fortran path has no octahedron bound and its own range instead of the ASORA window)

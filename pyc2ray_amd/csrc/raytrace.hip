@@ -283,13 +283,14 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     const int uinfo = p.geom[unit].info;           // sign bits of the unit | merged axes << 3 | rates-source << 6 | (face + 1) << 8
     // p.aligned: the unit's tables come in eight forms, by the source's position modulo 8 along the memory-contiguous axis of
     // the unit's face; the two sources of a workgroup agree in it (the host paired them so: p.pairs)
-    const bool by_class = !SUBBOX && p.aligned != 0;
+    const bool by_class = p.aligned != 0;
     const int face_type = ((uinfo >> 8) & 3) == 3 ? 1 : 0;          // 1: z-sector (rows along i), 0: x- / y-sector (rows along k)
     const bool listed = by_class && NSRC == 2;
     if (listed ? src_local >= p.npairs[face_type] : src_local * NSRC >= p.src_count) return;
 
     const int N = p.N;
     int i0[NSRC], j0[NSRC], k0[NSRC];
+    int loc[NSRC];            // SUBBOX: the source's index within the batch (activity, photon loss, trailing shell)
     double flux[NSRC];
     bool have[NSRC];
     unsigned nreal = 0;
@@ -304,10 +305,11 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
         } else {
             have[q] = src_local * NSRC + q < p.src_count;
             ns = p.src_begin + (have[q] ? src_local * NSRC + q : src_local * NSRC);
-            // SUBBOX: a source that stopped growing after an earlier box is swept along with its partner, its rates and its
-            // photon loss dropped like those of the copy that fills an odd count; a workgroup without a live source ends here
-            if (SUBBOX) have[q] = have[q] && p.sb_active[src_local * NSRC + q] != 0;
         }
+        loc[q] = ns - p.src_begin;
+        // SUBBOX: a source that stopped growing after an earlier box is swept along with its partner, its rates and its
+        // photon loss dropped like those of the copy that fills an odd count; a workgroup without a live source ends here
+        if (SUBBOX) have[q] = have[q] && p.sb_active[loc[q]] != 0;
         i0[q] = p.src_pos[3 * ns + 0];
         j0[q] = p.src_pos[3 * ns + 1];
         k0[q] = p.src_pos[3 * ns + 2];
@@ -401,12 +403,13 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     // ---- SUBBOX, a later box of the source: continue from the trailing shell of the box before ------------
     const bool continues = SUBBOX && !p.sb_first;
     // (one trailing shell per source of the batch and unit)
-    double *trail = SUBBOX ? p.sb_trail + ((size_t)src_local * NSRC * p.units + unit) * (size_t)slots : nullptr;
-    const size_t trail_stride = (size_t)p.units * (size_t)slots;          // from a source's shell to its partner's
+    double *trail[NSRC];
+#pragma unroll
+    for (int q = 0; q < NSRC; ++q) trail[q] = SUBBOX ? p.sb_trail + ((size_t)loc[q] * p.units + unit) * (size_t)slots : nullptr;
     if (continues) {
 #pragma unroll
         for (int q = 0; q < NSRC; ++q)
-            if (have[q]) for (int t = threadIdx.x; t < p.max_cells; t += RT_THREADS) prev[q * src_stride + t] = trail[q * trail_stride + t];
+            if (have[q]) for (int t = threadIdx.x; t < p.max_cells; t += RT_THREADS) prev[q * src_stride + t] = trail[q][t];
     }
     // ---- shell 0: the source cell (raytracing.cu:285-294) -----------------------------------
     if (threadIdx.x == 0 && !continues) {
@@ -882,10 +885,10 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
             if (!have[q]) continue;
             // hand the last shell swept to the next sub-box's launch (the step that closed it ended with the barrier and the
             // swap: it is `prev`, complete)
-            for (int t = threadIdx.x; t < p.max_cells; t += RT_THREADS) trail[q * trail_stride + t] = prev[q * src_stride + t];
+            for (int t = threadIdx.x; t < p.max_cells; t += RT_THREADS) trail[q][t] = prev[q * src_stride + t];
             double l = loss[q];
             for (int o = 32; o > 0; o >>= 1) l += __shfl_down(l, o);
-            if ((threadIdx.x & 63) == 0 && l != 0.0) unsafeAtomicAdd(p.sb_loss + src_local * NSRC + q, l * (dr * dr * dr));
+            if ((threadIdx.x & 63) == 0 && l != 0.0) unsafeAtomicAdd(p.sb_loss + loc[q], l * (dr * dr * dr));
         }
     }
 
@@ -1340,10 +1343,12 @@ static int launch_subbox_tables_variant(const RtParams &q, unsigned grid, size_t
     return 0;
 }
 
-int subbox_tables_prepare(State &st, RtParams &p, int ext_r, int ext_l, int subboxsize, int src_count, bool heat, SubboxTables &out)
+int subbox_tables_prepare(State &st, RtParams &p, int ext_r, int ext_l, int subboxsize, int src_count, bool heat, SubboxTables &out,
+                          const int32_t *host_pos)
 {
     (void)heat;
     out = SubboxTables();
+    out.host_pos = host_pos;
     const int want = st.opt[ASORA_OPT_SUBBOX_TABLES];
     if (want == 1 || p.grey || ext_r <= 0 || ext_l <= 0 || src_count < 1) return 0;
     if (!p.z_transposed || st.opt[ASORA_OPT_GLOBAL_ATOMICS] || 8ull * p.ncell > 0x80000000ull) return 0;   // the rates go through buffer atomics
@@ -1370,7 +1375,16 @@ int subbox_tables_prepare(State &st, RtParams &p, int ext_r, int ext_l, int subb
         p.split_desc = split ? 1 : 0;
     }
     const SubboxGeometry sbg{ext_r, ext_l, subboxsize};
-    if (int rc = ensure_geometry(st, p, threads, units, &sbg)) return rc;
+    // rows cut at 64-byte lines, as for the ASORA sweep (launch_raytrace): sectors of one face, a mesh whose rows start on lines,
+    // positions the host knows, and a radius that stays (one history for this path: note_call_radius)
+    bool aligned = false;
+    {
+        const int want_a = st.opt[ASORA_OPT_ALIGNED_ROWS];
+        const bool possible = (units == 6 || units == 12) && p.N % 8 == 0 && host_pos != nullptr && r <= 110.0;
+        aligned = possible && (want_a == 2 || (want_a == 0 && r < 52.5 && p.radius_stays));
+    }
+    if (int rc = ensure_geometry(st, p, threads, units, &sbg, aligned)) return rc;
+    out.aligned = aligned;
     const size_t slots = ((size_t)p.max_cells + 2) & ~(size_t)1;
     if (2 * slots * sizeof(double) + lds_table_bytes(256) > LDS_LIMIT_BYTES) return 0;
     // one trailing shell per source and unit, within 2 GiB (82 KB per source at r_RT = 32: 26 000 sources per launch)
@@ -1416,9 +1430,17 @@ int subbox_tables_sweep(State &st, const RtParams &p, const SubboxTables &tab, i
     const size_t slots = ((size_t)p.max_cells + 2) & ~(size_t)1;
     const bool pairs = tab.nsrc == 2 && !heat;
     const size_t lds_bytes = (pairs ? 4 : 2) * slots * sizeof(double) + lds_table_bytes(256, pairs ? 2 : 1);
-    const int groups = pairs ? (q.src_count + 1) / 2 : q.src_count;
+    int groups = pairs ? (q.src_count + 1) / 2 : q.src_count;
+    if (pairs && tab.aligned) {        // partners agree modulo 8 along the memory-contiguous axis of the unit's face
+        const State::PairList *pl = nullptr;
+        if (int rc = source_pairs_by_class(st, tab.host_pos, p.src_pos, q.src_begin, q.src_count, pl)) return rc;
+        for (int ft = 0; ft < 2; ++ft) { q.pairs[ft] = pl->dev[ft]; q.npairs[ft] = pl->n[ft]; }
+        groups = std::max(pl->n[0], pl->n[1]);
+    }
     q.spread = (long)groups * tab.units <= 2L * st.cu_count ? 1 : 0;
     const unsigned grid = q.spread ? (unsigned)tab.units * (unsigned)groups : 8u * (unsigned)tab.units * (unsigned)((groups + 7) / 8);
+    st.last_variant = (pairs ? ASORA_VARIANT_PAIRED : 0) | (tab.aligned ? ASORA_VARIANT_ALIGNED : 0) | ASORA_VARIANT_BUFFER_ATOMICS |
+                      (p.split_desc ? ASORA_VARIANT_SPLIT_DESCRIPTORS : 0) | (tab.units << 8) | (tab.threads << 16);
     KernelTimer kt(ASORA_KERNEL_RAYTRACE);
     if (pairs) return tab.threads == 512 ? launch_subbox_tables_variant<512, false, 2>(q, grid, lds_bytes, st.stream)
                                          : launch_subbox_tables_variant<256, false, 2>(q, grid, lds_bytes, st.stream);

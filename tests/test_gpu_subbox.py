@@ -435,6 +435,56 @@ def test_tabulated_sweep_randomised_against_oracle_and_on_the_fly_kernel(libs):
     assert seen_multi_box >= 8
 
 
+@pytest.mark.parametrize("heat", [False, True])
+def test_tabulated_sweep_on_line_aligned_tables(libs, heat):
+    """Round 5: the sub-box sweep on the line-aligned form of its tables (eight forms of every sector table, by the source's
+    position modulo 8 along the memory-contiguous axis of the sector's face; two sources share a workgroup only when they agree
+    in it: pair lists) -- sectors of one face, i.e. radii from 25.5 cells.  N = 64, 41 sources (an odd count; corners of the box
+    included), sub-boxes of 7 cells grown until the loss is small: aligned paired / aligned single / packed tables against each
+    other (same arithmetic per cell) and against the oracle."""
+    p, c2ray, asora, capi = libs
+    N, ns, R = 64, 41, 28.0
+    rng = np.random.default_rng(77)
+    thin, thick, dlog = cases.soft_tables(400)
+    ht, hk = 1e-11 * thin[::-1].copy(), 3e-12 * thick
+    zeros = np.zeros(thin.shape[0])
+    nd, xh, dr = cases.grid(N, "lognormal", 78, 0.08)
+    pos = 1 + rng.integers(0, N, size=(3, ns))
+    pos[:, 0], pos[:, 1] = [1, N, 1], [N, N, N]
+    flux = rng.uniform(0.5, 4.0, size=ns)
+    _fresh(p, N)
+    out = {}
+    for name, aligned, pairs in (("aligned_pairs", 2, 2), ("aligned_single", 2, 1), ("packed_pairs", 1, 2)):
+        phi = np.zeros((N, N, N), order="F"); hgrid = np.zeros((N, N, N), order="F"); cd = np.zeros((N, N, N), order="F")
+        asora.set_option(capi.OPT_SUBBOX_TABLES, 2)
+        asora.set_option(capi.OPT_ALIGNED_ROWS, aligned)
+        asora.set_option(capi.OPT_PAIR_SOURCES, pairs)
+        try:
+            nbox, loss = c2ray.raytracing.do_all_sources(flux, pos, 1000, 7, cd, cases.SIG, dr, nd, xh, phi, hgrid, 1e-3, thin, thick,
+                                                         ht if heat else zeros, hk if heat else zeros, cases.MINLOGTAU, dlog, R)
+            v = asora.last_raytrace_variant()
+        finally:
+            asora.set_option(capi.OPT_SUBBOX_TABLES, 0)
+            asora.set_option(capi.OPT_ALIGNED_ROWS, 0)
+            asora.set_option(capi.OPT_PAIR_SOURCES, 0)
+        assert v["aligned"] == (aligned == 2) and v["units"] == 6 and v["paired"] == (pairs == 2 and not heat), (name, v)
+        out[name] = (phi, hgrid, cd, nbox, loss)
+    a, b, c = out["aligned_pairs"], out["aligned_single"], out["packed_pairs"]
+    for other in (b, c):
+        assert a[3] == other[3]
+        np.testing.assert_allclose(a[4], other[4], rtol=1e-12)
+        assert np.array_equal(a[2], other[2])
+        _close(a[0], other[0], 1e-12)
+        _close(a[1], other[1], 1e-12)
+    ref = O.do_all_sources(flux, pos, 1000, 7, cases.SIG, dr, nd, xh, 1e-3, thin, thick, cases.MINLOGTAU, dlog, R,
+                           heat_thin=ht if heat else None, heat_thick=hk if heat else None)
+    if a[3] == ref["nsubbox"]:
+        _close(a[0], ref["phi_ion"], RATE_RTOL)
+        if heat:
+            _close(a[1], ref["phi_heat"], RATE_RTOL)
+    assert a[3] >= ns and np.isfinite(a[0]).all() and a[0].max() > 0
+
+
 def test_tabulated_sweep_in_several_batches(libs, monkeypatch):
     """The trailing shells of the tabulated sweep live in a scratch of bounded size; more sources than it holds are swept
     in batches (the dumped source in the last one).  Forced here with a scratch of a few sources: same results."""
