@@ -255,12 +255,13 @@ extern "C" __device__ double asora_buffer_atomic_fadd_f64(double, __amdgpu_buffe
 __device__ __forceinline__ bool ztr_desc(const RtParams &p, int uinfo) { return p.z_transposed != 0 && ((uinfo >> 8) & 3) == 3; }
 
 template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP, bool HEAT, int TABCAP, bool SKIP_ZERO = false, bool GREY = false,
-          bool BUFATOM = false, int NSRC = 1, bool SUBBOX = false>
+          bool BUFATOM = false, int NSRC = 1, bool SUBBOX = false, bool SPLIT = false>
 __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? ASORA_PAIR_MIN_WAVES : ASORA_MIN_WAVES) : 1)) raytrace_octant_kernel(const RtParams p)
 {
     extern __shared__ double lds_raw[];
     static_assert(NSRC == 1 || (ASORA_LATE_LOOKUP && !GLOBAL_SCRATCH && !DUMP && BUFATOM), "paired sources: production variant only");
     static_assert(!SUBBOX || (ASORA_LATE_LOOKUP && !GLOBAL_SCRATCH && !DUMP && !SKIP_ZERO && !GREY), "sub-box sweep: table rates, shells in LDS");
+    static_assert(!SPLIT || (BUFATOM && !SUBBOX && !HEAT && !GREY && !DUMP), "descriptors per layout: the production forms for 512 < N <= 645");
 
     if (p.done_flag && *p.done_flag) return;   // evolve loop: an iteration enqueued beyond convergence does nothing
     const int blk = blockIdx.x;
@@ -372,13 +373,15 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     unsigned int src_cell_gamma = 0, src_cell_eval = 0;      // the source cell (thread 0 only)
 
     // rate accumulation: `idx` indexes [phi | phi_t] (and [heat | heat_t])
-    // One descriptor over [phi | phi_t] while the pair fits 2 GiB (N <= 512).  Beyond (p.split_desc, N <= 645 -- the reference's
-    // own limit, raytracing.cu:95): a descriptor over ONE layout, N^3 doubles -- possible for units whose rated cells all lie on
+    // One descriptor over [phi | phi_t] while the pair fits 2 GiB (N <= 512).  Beyond (SPLIT, N <= 645 -- the reference's own
+    // limit, raytracing.cu:95): a descriptor over ONE layout, N^3 doubles -- possible for units whose rated cells all lie on
     // one face (the sectors), where the layout is the same for the whole workgroup: the descriptor starts at the layout the
-    // unit's face writes and `desc_off8` (a scalar, 0 when not split) takes that layout's offset out of the byte offsets.
-    const bool unit_in_twin = p.split_desc && ztr_desc(p, uinfo);
-    const unsigned desc_cells = (BUFATOM && p.split_desc) ? p.ncell : 2u * p.ncell;
-    const int desc_off8 = unit_in_twin ? -(int)(8u * p.ncell) : 0;
+    // unit's face writes and `desc_off8` takes that layout's offset out of the byte offsets.  A compile-time variant: without
+    // it the kernels of N <= 512 are instruction for instruction what they were (the scalar alone cost two VGPRs, i.e. the
+    // fourth wave per SIMD of the paired kernels).
+    const bool unit_in_twin = SPLIT && ztr_desc(p, uinfo);
+    const unsigned desc_cells = SPLIT ? p.ncell : 2u * p.ncell;
+    const int desc_off8 = (SPLIT && unit_in_twin) ? -(int)(8u * p.ncell) : 0;
     __amdgpu_buffer_rsrc_t rs_phi = __builtin_amdgcn_make_buffer_rsrc(p.phi + (unit_in_twin ? p.ncell : 0u), 0, BUFATOM ? (int)(8u * desc_cells) : 0, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_heat = __builtin_amdgcn_make_buffer_rsrc((HEAT ? p.heat : p.phi) + (unit_in_twin ? p.ncell : 0u), 0, (BUFATOM && HEAT) ? (int)(8u * desc_cells) : 0, 0x00020000);
     auto add_phi = [&](bool ok, unsigned idx, double v) {
@@ -1000,13 +1003,15 @@ static bool pair_sources_pays(const State &st, double R, int N, int src_count, i
 // Can the rate atomics go through buffer descriptors (the kernel's BUFATOM)?  One descriptor over both layouts of the rate
 // grid while the pair fits 2 GiB (N <= 512); one per layout (split) up to 2 GiB per layout (N <= 645) for units whose rated
 // cells all lie on one face -- the sector kinds.
-static bool buffer_atomics_fit(const State &st, const RtParams &p, int units, bool &split)
+// The split form is built for the shapes such meshes take at ordinary radii: 256 or 512 threads, up to 256 shells, table rates
+// without heating (everything else beyond N = 512 keeps the global-atomic family).
+static bool buffer_atomics_fit(const State &st, const RtParams &p, int units, int threads, bool plain_tables, bool &split)
 {
     split = false;
     if (st.opt[ASORA_OPT_GLOBAL_ATOMICS]) return false;
     if (16ull * p.ncell <= 0x80000000ull) return true;
     const bool one_face = units == 3 || units == 6 || units == 12 || units == 24 || units == 96;
-    if (8ull * p.ncell <= 0x80000000ull && one_face && p.z_transposed) { split = true; return true; }
+    if (8ull * p.ncell <= 0x80000000ull && one_face && p.z_transposed && (threads == 256 || threads == 512) && plain_tables) { split = true; return true; }
     return false;
 }
 
@@ -1014,19 +1019,36 @@ constexpr size_t lds_table_bytes(int tabcap, int nsrc = 1) { return LOG_TABLE_SI
 
 // the paired-sources variant (NSRC = 2) exists for the production path only: table rates, no heating, no dump, shell
 // buffers in LDS, buffer atomics
-template <int T, int TABCAP>
+template <int T, int TABCAP, bool SPLIT = false>
 static int launch_variant_pairs(State &st, const RtParams &q, unsigned grid, size_t lds_bytes, hipStream_t stream, bool skip_zero)
 {
     if (skip_zero) {
-        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, false, TABCAP, true, false, true, 2>,
+        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, false, TABCAP, true, false, true, 2, false, SPLIT>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, false, TABCAP, true, false, true, 2>), dim3(grid), dim3(T),
+        hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, false, TABCAP, true, false, true, 2, false, SPLIT>), dim3(grid), dim3(T),
                            lds_bytes, stream, q);
     } else {
-        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, false, TABCAP, false, false, true, 2>,
+        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, false, TABCAP, false, false, true, 2, false, SPLIT>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, false, TABCAP, false, false, true, 2>), dim3(grid), dim3(T),
+        hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, false, TABCAP, false, false, true, 2, false, SPLIT>), dim3(grid), dim3(T),
                            lds_bytes, stream, q);
+    }
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// single source, table rates, buffer descriptors per layout (512 < N <= 645): the plain and the zero-skipping form
+template <int T>
+static int launch_variant_split(State &st, const RtParams &q, unsigned grid, size_t lds_bytes, hipStream_t stream, bool skip_zero)
+{
+    if (skip_zero) {
+        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, false, 256, true, false, true, 1, false, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, false, 256, true, false, true, 1, false, true>), dim3(grid), dim3(T), lds_bytes, stream, q);
+    } else {
+        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, false, 256, false, false, true, 1, false, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, false, 256, false, false, true, 1, false, true>), dim3(grid), dim3(T), lds_bytes, stream, q);
     }
     ASORA_HIP_TRY(hipGetLastError());
     return 0;
@@ -1045,8 +1067,8 @@ static int launch_variant(State &st, const RtParams &q, unsigned grid, size_t ld
     } while (0)
     const bool grey = q.grey != 0;
     // rate atomics through buffer descriptors (see the kernel's BUFATOM): [phi | phi_t] must not exceed 2 GiB
-    bool split_ = false;
-    const bool ba = use_lds && buffer_atomics_fit(st, q, q.units, split_);      // (q.split_desc was set from the same test)
+    // (q.split_desc: launch_raytrace has decided that the descriptors go per layout; those forms are launched from there)
+    const bool ba = use_lds && !q.split_desc && 16ull * q.ncell <= 0x80000000ull && !st.opt[ASORA_OPT_GLOBAL_ATOMICS];
     if (T == 256 && dump) {
         if (grey)         { if (use_lds) ASORA_LAUNCH(false, true, false, false, true, false); else ASORA_LAUNCH(true, true, false, false, true, false); }
         else              { if (use_lds) ASORA_LAUNCH(false, true, false, false, false, false); else ASORA_LAUNCH(true, true, false, false, false, false); }
@@ -1158,9 +1180,6 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
         aligned = possible && (want == 2 || (want == 0 && r < 52.5 && p.radius_stays));
     }
     if (int rc = ensure_geometry(st, p, threads, units, nullptr, aligned)) return rc;
-    bool split = false;
-    const bool bufatom_fits = buffer_atomics_fit(st, p, units, split);
-    p.split_desc = split ? 1 : 0;
     st.last_variant = 0;
     p.lut_k1 = 0.30102999566398119521 / p.dlogtau;      // log10(2)/dlogtau
     p.lut_k0 = 1.0 - p.minlogtau / p.dlogtau;
@@ -1184,6 +1203,9 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
     size_t fixed_bytes = lds_table_bytes(big_tables ? 1024 : small_tables ? 64 : 256);
     size_t shell_bytes = 2 * slots * sizeof(double);
     const bool use_lds = shell_bytes + fixed_bytes <= LDS_LIMIT_BYTES;
+    bool split = false;
+    const bool bufatom_fits = buffer_atomics_fit(st, p, units, threads, use_lds && !dump && !heat && !p.grey && !big_tables, split);
+    p.split_desc = split ? 1 : 0;
     // Two sources per workgroup (see the kernel's NSRC): the variant exists for table rates without heating, column-density
     // dump or exact-zero skipping, with the shell buffers in LDS and the rates through buffer atomics, for 64..512 threads
     // and the two smaller LDS table capacities
@@ -1285,7 +1307,15 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
         {
             KernelTimer kt(ASORA_KERNEL_RAYTRACE, stream);
             int rc = 0;
-            if (pairs) {
+            if (pairs && split) {         // 512 < N <= 645: sectors x 256 / 512 threads
+                if (pairs_tiny)          rc = launch_variant_pairs<256, 32, true>(st, q, grid, lds_bytes, stream, skip_zero);
+                else if (pairs_small)    rc = launch_variant_pairs<256, 64, true>(st, q, grid, lds_bytes, stream, skip_zero);
+                else if (threads == 512) rc = launch_variant_pairs<512, 256, true>(st, q, grid, lds_bytes, stream, skip_zero);
+                else                     rc = launch_variant_pairs<256, 256, true>(st, q, grid, lds_bytes, stream, skip_zero);
+            } else if (split) {
+                rc = threads == 512 ? launch_variant_split<512>(st, q, grid, lds_bytes, stream, skip_zero)
+                                    : launch_variant_split<256>(st, q, grid, lds_bytes, stream, skip_zero);
+            } else if (pairs) {
                 if (pairs_tiny) rc = launch_variant_pairs<256, 32>(st, q, grid, lds_bytes, stream, skip_zero);
                 else if (pairs_small) {
                     if (threads == 64)       rc = launch_variant_pairs<64, 64>(st, q, grid, lds_bytes, stream, skip_zero);
@@ -1351,7 +1381,7 @@ int subbox_tables_prepare(State &st, RtParams &p, int ext_r, int ext_l, int subb
     out.host_pos = host_pos;
     const int want = st.opt[ASORA_OPT_SUBBOX_TABLES];
     if (want == 1 || p.grey || ext_r <= 0 || ext_l <= 0 || src_count < 1) return 0;
-    if (!p.z_transposed || st.opt[ASORA_OPT_GLOBAL_ATOMICS] || 8ull * p.ncell > 0x80000000ull) return 0;   // the rates go through buffer atomics
+    if (!p.z_transposed || st.opt[ASORA_OPT_GLOBAL_ATOMICS] || 16ull * p.ncell > 0x80000000ull) return 0;   // the rates go through buffer atomics (one descriptor: N <= 512)
     const double R2hi = p.R * p.R * (1.0 + 1e-9) + 1e-9;
     const int range = std::max(ext_r, ext_l);
     const int S_tab = std::isfinite(R2hi) ? (int)std::min((double)range, std::floor(std::sqrt(R2hi))) : range;
@@ -1369,19 +1399,18 @@ int subbox_tables_prepare(State &st, RtParams &p, int ext_r, int ext_l, int subb
     else if (r < 52.5) { units = 12; threads = 256; }
     else { units = 12; threads = 512; }
     if (want == 0 && (long)src_count * units < 2L * st.cu_count) return 0;     // a handful of sources: subbox.hip's wide workgroups
-    {
-        bool split = false;
-        if (!buffer_atomics_fit(st, p, units, split)) return 0;               // (N > 512: the sector kinds only)
-        p.split_desc = split ? 1 : 0;
-    }
     const SubboxGeometry sbg{ext_r, ext_l, subboxsize};
-    // rows cut at 64-byte lines, as for the ASORA sweep (launch_raytrace): sectors of one face, a mesh whose rows start on lines,
-    // positions the host knows, and a radius that stays (one history for this path: note_call_radius)
+    // Rows cut at 64-byte lines, as for the ASORA sweep (launch_raytrace): sectors of one face, a mesh whose rows start on
+    // lines, positions the host knows.  ON REQUEST ONLY (ASORA_OPT_ALIGNED_ROWS = 2): measured on MI355X, 1000 sources, 256^3,
+    // r_RT = 32 (profiles/r05_ab_subbox_aligned.jsonl), the aligned tables give this sweep nothing -- 1.136 / 1.151 ms aligned
+    // against 1.139 / 1.143 ms packed with two sources per workgroup, 1.235 against 1.18 ms with one -- where they gave the
+    // ASORA sweep -1.5 ... -4.7 %: here the photon-loss arithmetic and 141 VGPRs (three waves per SIMD), not the atomic
+    // requests, set the pace.
     bool aligned = false;
     {
         const int want_a = st.opt[ASORA_OPT_ALIGNED_ROWS];
         const bool possible = (units == 6 || units == 12) && p.N % 8 == 0 && host_pos != nullptr && r <= 110.0;
-        aligned = possible && (want_a == 2 || (want_a == 0 && r < 52.5 && p.radius_stays));
+        aligned = possible && want_a == 2;
     }
     if (int rc = ensure_geometry(st, p, threads, units, &sbg, aligned)) return rc;
     out.aligned = aligned;
@@ -1440,7 +1469,7 @@ int subbox_tables_sweep(State &st, const RtParams &p, const SubboxTables &tab, i
     q.spread = (long)groups * tab.units <= 2L * st.cu_count ? 1 : 0;
     const unsigned grid = q.spread ? (unsigned)tab.units * (unsigned)groups : 8u * (unsigned)tab.units * (unsigned)((groups + 7) / 8);
     st.last_variant = (pairs ? ASORA_VARIANT_PAIRED : 0) | (tab.aligned ? ASORA_VARIANT_ALIGNED : 0) | ASORA_VARIANT_BUFFER_ATOMICS |
-                      (p.split_desc ? ASORA_VARIANT_SPLIT_DESCRIPTORS : 0) | (tab.units << 8) | (tab.threads << 16);
+                      (tab.units << 8) | (tab.threads << 16);
     KernelTimer kt(ASORA_KERNEL_RAYTRACE);
     if (pairs) return tab.threads == 512 ? launch_subbox_tables_variant<512, false, 2>(q, grid, lds_bytes, st.stream)
                                          : launch_subbox_tables_variant<256, false, 2>(q, grid, lds_bytes, st.stream);

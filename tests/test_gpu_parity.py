@@ -550,9 +550,9 @@ def test_slab_iteration_over_rccl_world1_equals_the_single_gpu_loop(asora, tmp_p
         assert (n4, done4, len(rows4)) == (n1, True, 0)
         x3 = lib.grid_to_host(capi.GRID_XH_INTERMED, np.empty((N, N, N)))
         phi3 = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
-        assert np.array_equal(x3, x2)                               # the same kernels on the same inputs in the same order
+        np.testing.assert_allclose(x3, x2, rtol=1e-10, atol=0)      # (the same kernels on the same inputs; the atomics' order is free)
         np.testing.assert_allclose(phi3, phi1, rtol=1e-10, atol=0)
-        assert rows_all[-1][0] == conv and rows_all[-1][1] == s1
+        assert rows_all[-1][0] == conv and abs(rows_all[-1][1] - s1) <= 1e-10 * abs(s1)
     p.device_close()
 
 

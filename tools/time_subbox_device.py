@@ -1,6 +1,6 @@
 """The sub-box sweep (libc2ray.raytracing.do_all_sources semantics) on DEVICE-RESIDENT inputs, no column-density dump: every
 source goes through the tabulated kernel (raytrace.hip SUBBOX), so the event timer is that kernel alone.  One JSON line per
-(radius, pair option).  usage (GPU box): python tools/time_subbox_device.py [--R 16 32] [--pairs 1 2] [--reps 10]"""
+(radius, pair option, table form).  usage (GPU box): python tools/time_subbox_device.py [--R 16 32] [--pairs 1 2] [--aligned 1 2] [--reps 10]"""
 import argparse
 import json
 import os
@@ -20,6 +20,7 @@ ap.add_argument("--N", type=int, default=256)
 ap.add_argument("--nsrc", type=int, default=1000)
 ap.add_argument("--R", type=float, nargs="+", default=[16.0, 32.0])
 ap.add_argument("--pairs", type=int, nargs="+", default=[1, 2])
+ap.add_argument("--aligned", type=int, nargs="+", default=[1, 2], help="ASORA_OPT_ALIGNED_ROWS: 1 = packed tables, 2 = line-aligned (sectors only: r >= 25.5), 0 = the library's choice")
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--loss-fraction", type=float, default=1e-2)
 a = ap.parse_args()
@@ -35,8 +36,10 @@ lib.grid_to_device(_capi.GRID_NDENS, ndens)
 lib.grid_to_device(_capi.GRID_XH_AV, xh)
 for R in a.R:
     for rnd in (1, 2):
+      for aligned in a.aligned:
         for pairs in a.pairs:
             lib.set_option(_capi.OPT_PAIR_SOURCES, pairs)
+            lib.set_option(_capi.OPT_ALIGNED_ROWS, aligned)
             call = lambda: lib.subbox_raytrace_device(1000, int(R), a.loss_fraction, R, bench.SIG, dr, bench.MINLOGTAU, dlog, thin.shape[0] - 1, 0, ns)
             call()
             lib.set_option(_capi.OPT_TIMING, 1)
@@ -48,7 +51,8 @@ for R in a.R:
             m = int(R)
             rr = np.arange(-m, m + 1)
             rated = int(((rr[:, None, None] ** 2 + rr[None, :, None] ** 2 + rr[None, None, :] ** 2) <= R * R).sum()) * ns
-            print(json.dumps({"R": R, "pair_sources_option": pairs, "round": rnd, "sweep_kernel_ms_per_call": ms / a.reps, "launches_per_call": n / a.reps,
+            print(json.dumps({"R": R, "pair_sources_option": pairs, "aligned_rows_option": aligned, "variant": lib.last_raytrace_variant(), "round": rnd, "sweep_kernel_ms_per_call": ms / a.reps, "launches_per_call": n / a.reps,
                               "nsubbox": nbox, "photon_loss": loss, "roofline_frac_hbm": 32.0 * rated / (ms / a.reps * 1e-3) / 8e12}), flush=True)
 lib.set_option(_capi.OPT_PAIR_SOURCES, 0)
+lib.set_option(_capi.OPT_ALIGNED_ROWS, 0)
 p.device_close()
