@@ -814,7 +814,7 @@ def main():
                 print(f"bench: one-GPU reference run failed: {type(e).__name__}: {e}", file=sys.stderr)
         comm.Barrier()
     lib.source_data_to_device(p0, f0, n_local)
-    state = {"slab": slab, "unpolled": 0, "rows": []}
+    state = {"slab": slab, "unpolled": 0, "rows": [], "host_enqueue_s": 0.0, "host_enqueued": 0}
 
     def begin_time_step():
         # conv_criterion = -1 and convergence_fraction = 0 can never be met: every enqueued iteration does its work
@@ -837,7 +837,10 @@ def main():
 
     def step():
         if state["slab"]:              # what evolve3D_MPI does per outer iteration with a TorchComm: the sharded device loop
+            t_ = time.perf_counter()
             comm.slab_enqueue(lib, 1)
+            state["host_enqueue_s"] += time.perf_counter() - t_       # host time to ISSUE an iteration (nothing in it waits for the GPU)
+            state["host_enqueued"] += 1
             state["unpolled"] += 1
             if state["unpolled"] >= poll_every:
                 poll_slab()
@@ -897,6 +900,7 @@ def main():
     conv = None
     last_rows = []
     n_timed = 0
+    state["host_enqueue_s"], state["host_enqueued"] = 0.0, 0
     for _ in range(max(1, args.repeats)):
         fence()
         t0 = time.perf_counter()
@@ -1131,6 +1135,9 @@ def main():
                                              "(asora_evolve_enqueue + one poll per %d steps): %s, while the other "
                                              "ranks waited at a barrier; speedup = that / ms_per_step" % (poll_every, one_gpu_how))
         out["phases_ms"] = phases_ms
+        # the host's share: what it takes to ISSUE one iteration of the sharded loop (library calls + torch.distributed calls; the
+        # device runs behind, a batch of iterations per poll) -- must stay below the iteration's GPU time or the GPU starves
+        out["host_issue_ms_per_step"] = (state["host_enqueue_s"] / state["host_enqueued"] * 1e3) if state["host_enqueued"] else None
         out["phases_note"] = ("mean per step over the timed regions, MAX over the ranks; slab exchange: spans between HIP events on the "
                               "library's stream (wait_rates_add = what the rate exchange left un-hidden + the adds; xh_av_exchange_nhi is "
                               "serial by construction), all-reduce path: wall clock between the host synchronisations of its three calls")

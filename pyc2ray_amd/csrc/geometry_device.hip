@@ -547,6 +547,7 @@ int build_geometry_on_device(State &st, const std::vector<GeomTableSpec> &specs,
             out[(size_t)t] = OctGeomDev{a, b, 0, 0};
             step_after[(size_t)t] = std::vector<int>(1, 0);
         }
+        ASORA_HIP_TRY(hipStreamSynchronize(st.stream));      // (a pipelined call launches on side streams: the tables must be complete)
         return 0;
     }
 

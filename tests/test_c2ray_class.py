@@ -179,6 +179,26 @@ def test_single_black_body_regression_thresholds(tmp_path):
 
 
 @pytest.mark.gpu
+def test_single_black_body_regression_at_the_reference_size():
+    """The same regression at the reference's own size -- 128^3, ten steps of 1 Myr (run_test.py:30-88) -- through
+    tools/hackathon_test1.py: this build's ASORA path and its sub-box-semantics path on the GPU against the reference's own
+    Fortran driven by the same loop on one host core (~20 s), under the script's eight thresholds (run_test.py:91-115)."""
+    import json
+    import subprocess
+    import sys
+    from oracle import ref_fortran as F
+    if not F.available():
+        pytest.skip("oracle/_ref/libc2ray_ref.so not built")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "hackathon_test1.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["asora_path_vs_reference"]["failed_thresholds"] == [] and d["subbox_semantics_path_vs_reference"]["failed_thresholds"] == []
+    assert abs(d["mean_x_asora_path"] - d["mean_x_reference_fortran"]) < 1e-9 * d["mean_x_reference_fortran"]
+    assert d["outer_iterations_reference"] >= 10 and 0.01 < d["mean_x_reference_fortran"] < 0.2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,grey,teff,c2ray_mean", [("grey", 1, "5e4", 0.09488065), ("Teff=5e3", 0, "5e3", 0.09503048),
                                                         ("Teff=5e4", 0, "5e4", 0.09583101), ("Teff=1e5", 0, "1e5", 0.09492813)])
 def test_paper_test3_mean_ionised_fractions(tmp_path, name, grey, teff, c2ray_mean):
