@@ -1467,6 +1467,8 @@ int asora_evolve_slab_fold_out(int i_begin, int i_count)
     if (int rc = require_slab("evolve_slab_fold_out")) return rc;
     State &st = g_state;
     if (i_begin < 0 || i_count < 0 || i_begin + i_count > st.N) return fail(4, "evolve_slab_fold_out: bad plane range");
+    if (i_count > 0 && i_begin < st.ev_own_begin + st.ev_own_count && st.ev_own_begin < i_begin + i_count)
+        return fail(4, "evolve_slab_fold_out: the range holds planes this rank owns (their rates stay: the pass folds them)");
     st.ev_sets_known = false;
     double *cur = slab_pair(0), *nxt = slab_pair(1);
     return launch_fold_out(st, cur, cur + st.ncell, st.staging, nxt, nxt + st.ncell, i_begin, i_count, &st.ev_status->done);
@@ -1494,6 +1496,8 @@ int asora_evolve_slab_add(int i_begin, int i_count, const double *dev_planes)
     State &st = g_state;
     if (i_begin < 0 || i_count < 0 || i_begin + i_count > st.N || (i_count > 0 && !dev_planes)) return fail(4, "evolve_slab_add: bad arguments");
     if (st.ev_slab_passed) return fail(4, "evolve_slab_add: the iteration's pass has been enqueued already");
+    if (i_count > 0 && (i_begin < st.ev_own_begin || i_begin + i_count > st.ev_own_begin + st.ev_own_count))
+        return fail(4, "evolve_slab_add: rates received for planes this rank does not own");
     st.ev_sets_known = false;
     const size_t plane = (size_t)st.N * st.N;
     return launch_add_planes(st, slab_pair(0) + (size_t)i_begin * plane, dev_planes, (size_t)i_count * plane, &st.ev_status->done);

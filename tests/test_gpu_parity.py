@@ -811,6 +811,55 @@ def test_pipelined_raytrace_allreduce_world1(asora, monkeypatch):
     p.device_close()
 
 
+def test_sharded_device_loop_refuses_calls_out_of_order_or_out_of_range(asora):
+    """The asora_evolve_slab_* calls (include/asora_hip.h): no step begun, planes that are not the caller's to send or to receive,
+    a close without a pass, the one-GPU enqueue on a sharded step -- error codes with messages, nothing launched."""
+    p, lib, capi = asora
+    N = 16
+    nd, xh, dr = cases.grid(N, "lognormal", 5, 0.1)
+    thin, thick, dlog = cases.soft_tables()
+    pos, flux = cases.sources(N, 3, 6, flux=1.0)
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 8)
+    p.photo_table_to_device(thin, thick)
+    p0, f0 = cases.flat_sources(pos, flux)
+    lib.source_data_to_device(p0, f0, 3)
+    for which, a in ((capi.GRID_NDENS, nd), (capi.GRID_TEMP, np.full((N, N, N), 1e4)), (capi.GRID_XH, xh)):
+        lib.grid_to_device(which, a)
+    with pytest.raises(RuntimeError, match="no multi-GPU evolve step in progress"):
+        lib.evolve_slab_trace(0, 3)
+    chem = (3.15576e13, cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C)
+    with pytest.raises(RuntimeError, match="bad range of own planes"):
+        lib.evolve_begin_slab(*chem, 4.0, cases.SIG, dr, cases.MINLOGTAU, dlog, thin.shape[0], 0, 3, -1.0, 0.0, 12, 8)
+    lib.evolve_begin_slab(*chem, 4.0, cases.SIG, dr, cases.MINLOGTAU, dlog, thin.shape[0], 0, 3, -1.0, 0.0, 8, 4)     # owns planes 8..11
+    with pytest.raises(RuntimeError, match="begun with asora_evolve_begin_slab"):
+        lib.evolve_enqueue(1)
+    with pytest.raises(RuntimeError, match="outside the step's sources"):
+        lib.evolve_slab_trace(2, 5)
+    lib.evolve_slab_trace(0, 3)
+    with pytest.raises(RuntimeError, match="planes this rank owns"):
+        lib.evolve_slab_fold_out(10, 3)
+    lib.evolve_slab_fold_out(12, 4)
+    lib.evolve_slab_fold_out(0, 8)
+    with pytest.raises(RuntimeError, match="does not own"):
+        lib.evolve_slab_add_host(6, np.zeros((4, N, N)))
+    lib.evolve_slab_add_host(8, np.zeros((2, N, N)))
+    with pytest.raises(RuntimeError, match="pass has not been enqueued"):
+        lib.evolve_slab_close((0, 1.0, 1.0))
+    lib.evolve_slab_pass()
+    with pytest.raises(RuntimeError, match="already enqueued"):
+        lib.evolve_slab_pass()
+    with pytest.raises(RuntimeError, match="pass has been enqueued already"):
+        lib.evolve_slab_trace(0, 3)
+    conv, s1, s0 = lib.chemistry_finish()                     # this rank's share of the three sums: its four planes
+    assert 0 <= conv <= 4 * N * N and abs(s1 + s0 - 4 * N * N) < 1e-9 * 4 * N * N
+    lib.evolve_slab_close((conv, s1, s0))
+    n, done, rows = lib.evolve_poll(4)
+    assert (n, done, len(rows)) == (1, False, 1) and rows[0][0] == conv
+    p.device_close()
+
+
 def test_beyond_the_last_table_entry_rates_are_exactly_zero(asora):
     """A medium so thick that the optical depth passes the last table entry (10^maxlogtau) a dozen cells from the
     source -- the reference benchmark's own medium does (tau = 228 per cell at 256^3).  Both table lookups then

@@ -36,6 +36,7 @@ timeout -k 10 300 python tools/test2_cosmo_ifront.py > $O/test2.json 2> $O/test2
 timeout -k 10 300 python tools/hackathon_test1.py > $O/hackathon_test1_128.json 2> $O/hackathon.err; echo "hackathon exit $?"
 timeout -k 10 300 python tools/time_steps_resident.py > $O/time_steps_resident.json 2> $O/tsr.err
 timeout -k 10 300 python tools/dephase_small_R.py > $O/dephase_R16.json 2> $O/dephase.err
+timeout -k 10 300 python tools/slab_compute_model.py --chunks 1 > $O/slab_compute_model_cosmo.json 2> $O/slab_model.err; echo "slab model exit $?"
 fi
 if [[ $PART == *4* ]]; then
 PYC2RAY_AMD_FORCE_COLLECTIVE=1 timeout -k 10 300 python bench.py --gpus 1 --workload cosmo --steps 20 --warmup 5 --cpu-sources 0 > $O/world1_rccl_slab_path.json 2> $O/world1_slab.err; echo "world-1 slab exit $?"

@@ -2,9 +2,10 @@
 
 There is one GPU on the build box, so the multi-GPU step cannot be measured; its compute half can.  For P = 1, 2, 4, 8
 ranks and BASELINE configs[3] (256^3 log-normal density, 1000 sources IN TOTAL on the densest cells, r_RT = 32) this runs,
-for every rank r of the plan in turn, exactly the library calls TorchComm.slab_iteration makes between the exchanges --
-asora_raytrace_begin_planes on reach[r] | own[r], the trace of r's sources, the folds, asora_chemistry_range on own[r] --
-and reports the slowest rank's time next to the plan's bytes per rank.  The exchange time is then MODELLED from the
+for every rank r of the plan in turn, exactly the library calls one iteration of TorchComm.slab_enqueue makes around the exchanges
+(the sharded device loop, round 5) -- the trace of r's sources (in chunks), the out-box folds of the planes that leave, the adds of
+what would arrive (same bytes, from a grid of the device), the fused pass on own[r], nHI on the halo planes, the convergence
+test -- and reports the slowest rank's time next to the plan's bytes per rank.  The exchange time is then MODELLED from the
 bytes at an assumed point-to-point xGMI rate (printed), not measured.
 Prints one JSON line.  usage: python tools/slab_compute_model.py [--workload cosmo] [--link-GBs 50]
 """
@@ -56,41 +57,51 @@ for P in (1, 2, 4, 8):
         p0, f0 = format_sources(spos[:, lo:hi], sflux[lo:hi])
         lib.source_data_to_device(p0, f0, hi - lo)
         work = [(x, y - x) for x, y in plan.work_runs(r)]
-        lib.raytrace_begin_planes(a.R, bench.SIG, dr, bench.MINLOGTAU, dlog, numtau, [(0, N)])      # a time step's first iteration
-        lib.raytrace_range(0, hi - lo)
-        lib.synchronize()
-        best = None
         K = plan.common_chunks(a.chunks)
-        sched = plan.send_schedule(r, K)
+        sched, rsched = plan.send_schedule(r, K), plan.recv_schedule(r, K)
         cb = plan.chunk_bounds(hi - lo, K)
+        own_a, own_b = plan.own[r]
+        halo = [(x, y) for q in range(P) if q != r for x, y in plan.runs[r][q]]          # planes whose new xh_av arrives
+        lib.evolve_begin_slab(*chem, a.R, bench.SIG, dr, bench.MINLOGTAU, dlog, numtau, 0, hi - lo, -1.0, 0.0, own_a, own_b - own_a)
+        stand_in = lib.device_ptr(_capi.GRID_NDENS)          # "received" planes: any device memory of the right size
+
+        def iteration(marks=None, t0=None):
+            for c in range(K):
+                lib.evolve_slab_trace(cb[c], cb[c + 1] - cb[c])
+                for _, x, y in sched[c]:
+                    lib.evolve_slab_fold_out(x, y - x)
+                if marks is not None:
+                    lib.synchronize()
+                    marks.append(time.perf_counter() - t0)
+            lib.synchronize()
+            t_trace = time.perf_counter()
+            for c in range(K):
+                for _, x, y in rsched[c]:
+                    lib.evolve_slab_add(x, y - x, stand_in + 8 * N * N * x)
+            lib.evolve_slab_pass()
+            for x, y in halo:
+                lib.evolve_slab_nhi(x, y - x)
+            lib.evolve_slab_close(lib.chemistry_finish())
+            lib.synchronize()
+            return t_trace
+
+        for _ in range(2):
+            iteration()
+        lib.evolve_poll(0)
+        best = None
         for _ in range(a.reps):
             t0 = time.perf_counter()
-            lib.raytrace_begin_planes(a.R, bench.SIG, dr, bench.MINLOGTAU, dlog, numtau, work)
-            for c in range(K):                       # exactly what TorchComm.slab_iteration issues between the exchanges
-                lib.raytrace_range(cb[c], cb[c + 1] - cb[c])
-                for _, x, y in sched[c]:
-                    lib.raytrace_fold(x, y - x)
-            x, y = plan.own[r]
-            lib.raytrace_fold(x, y - x)
-            lib.synchronize()
-            t1 = time.perf_counter()
-            lib.chemistry_range(*chem, x, y - x, True)
-            lib.chemistry_finish()
+            t1 = iteration()
             t2 = time.perf_counter()
+            lib.evolve_poll(0)
             cur = (t2 - t0, t1 - t0, t2 - t1)
             best = cur if best is None or cur[0] < best[0] else best
         # when do the pieces of the rate exchange become available?  the same loop with a synchronisation after every chunk
         ready = None
         for _ in range(a.reps):
-            t0 = time.perf_counter()
-            lib.raytrace_begin_planes(a.R, bench.SIG, dr, bench.MINLOGTAU, dlog, numtau, work)
             marks = []
-            for c in range(K):
-                lib.raytrace_range(cb[c], cb[c + 1] - cb[c])
-                for _, x, y in sched[c]:
-                    lib.raytrace_fold(x, y - x)
-                lib.synchronize()
-                marks.append(time.perf_counter() - t0)
+            iteration(marks, time.perf_counter())
+            lib.evolve_poll(0)
             ready = marks if ready is None or marks[-1] < ready[-1] else ready
         # bytes per chunk on the busiest outgoing link of this rank
         plane = 8 * N * N
@@ -100,7 +111,7 @@ for P in (1, 2, 4, 8):
                 per_peer.setdefault(q, [0] * K)[c] += (y - x) * plane
         busiest = max(per_peer.values(), key=sum) if per_peer else [0] * K
         per_rank.append({"rank": r, "sources": hi - lo, "planes_worked_on": int(sum(c for _, c in work)), "own_planes": plan.own[r][1] - plan.own[r][0],
-                         "compute_ms": best[0] * 1e3, "prepare_trace_fold_ms": best[1] * 1e3, "slab_chemistry_ms": best[2] * 1e3,
+                         "compute_ms": best[0] * 1e3, "prepare_trace_fold_ms": best[1] * 1e3, "slab_chemistry_ms": best[2] * 1e3,       # (trace + out-box folds | adds + fused pass + halo nHI + test)
                          "bytes_sent_per_exchange": plan.bytes_per_rank(r)[0], "bytes_received_per_exchange": plan.bytes_per_rank(r)[1],
                          "chunk_ready_ms": [m * 1e3 for m in ready], "busiest_link_bytes_per_chunk": busiest})
     slow = max(per_rank, key=lambda q: q["compute_ms"])
