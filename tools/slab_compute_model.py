@@ -73,34 +73,43 @@ for P in (1, 2, 4, 8):
                 if marks is not None:
                     lib.synchronize()
                     marks.append(time.perf_counter() - t0)
-            lib.synchronize()
-            t_trace = time.perf_counter()
             for c in range(K):
                 for _, x, y in rsched[c]:
                     lib.evolve_slab_add(x, y - x, stand_in + 8 * N * N * x)
             lib.evolve_slab_pass()
             for x, y in halo:
                 lib.evolve_slab_nhi(x, y - x)
-            lib.evolve_slab_close(lib.chemistry_finish())
-            lib.synchronize()
-            return t_trace
+            lib.evolve_slab_close(None)           # (the rank's own sums stand in for the all-reduced ones: nothing waits on the host)
 
         for _ in range(2):
             iteration()
         lib.evolve_poll(0)
+        # the GPU's time per iteration: batches of 8 enqueued without a host synchronisation in between, as evolve3D_MPI does;
+        # split by the library's HIP-event timers (raytrace | out-box folds + adds | fused pass | halo nHI)
         best = None
         for _ in range(a.reps):
+            lib.set_option(_capi.OPT_TIMING, 1)
+            lib.kernel_time_reset()
+            lib.synchronize()
             t0 = time.perf_counter()
-            t1 = iteration()
-            t2 = time.perf_counter()
+            for _ in range(8):
+                iteration()
+            lib.synchronize()
+            wall = (time.perf_counter() - t0) / 8
+            rt = lib.kernel_time_ms(_capi.KERNEL_RAYTRACE)[0] / 8
+            fin = lib.kernel_time_ms(_capi.KERNEL_FINISH)[0] / 8
+            ch = lib.kernel_time_ms(_capi.KERNEL_CHEMISTRY)[0] / 8
+            pr = lib.kernel_time_ms(_capi.KERNEL_PREP)[0] / 8
+            lib.set_option(_capi.OPT_TIMING, 0)
             lib.evolve_poll(0)
-            cur = (t2 - t0, t1 - t0, t2 - t1)
+            cur = (wall, (rt + fin) * 1e-3, (ch + pr) * 1e-3)
             best = cur if best is None or cur[0] < best[0] else best
         # when do the pieces of the rate exchange become available?  the same loop with a synchronisation after every chunk
         ready = None
         for _ in range(a.reps):
             marks = []
             iteration(marks, time.perf_counter())
+            lib.synchronize()
             lib.evolve_poll(0)
             ready = marks if ready is None or marks[-1] < ready[-1] else ready
         # bytes per chunk on the busiest outgoing link of this rank
@@ -111,7 +120,7 @@ for P in (1, 2, 4, 8):
                 per_peer.setdefault(q, [0] * K)[c] += (y - x) * plane
         busiest = max(per_peer.values(), key=sum) if per_peer else [0] * K
         per_rank.append({"rank": r, "sources": hi - lo, "planes_worked_on": int(sum(c for _, c in work)), "own_planes": plan.own[r][1] - plan.own[r][0],
-                         "compute_ms": best[0] * 1e3, "prepare_trace_fold_ms": best[1] * 1e3, "slab_chemistry_ms": best[2] * 1e3,       # (trace + out-box folds | adds + fused pass + halo nHI + test)
+                         "compute_ms": best[0] * 1e3, "prepare_trace_fold_ms": best[1] * 1e3, "slab_chemistry_ms": best[2] * 1e3,       # (wall per iteration of a batch of 8 | kernels: trace + out-box folds + adds | fused pass + halo nHI)
                          "bytes_sent_per_exchange": plan.bytes_per_rank(r)[0], "bytes_received_per_exchange": plan.bytes_per_rank(r)[1],
                          "chunk_ready_ms": [m * 1e3 for m in ready], "busiest_link_bytes_per_chunk": busiest})
     slow = max(per_rank, key=lambda q: q["compute_ms"])
