@@ -261,6 +261,16 @@ def start_cpu_workers(cores, workload, N, R, sample_sources, tables):
         np.save(os.path.join(d, name + ".npy"), np.asfortranarray(g))
     np.savez(os.path.join(d, "meta.npz"), thin=tables[0], thick=tables[1], dlog=tables[2], dr=dr, pos=pos, flux=flux)
     procs = []
+    # whatever happens to this process afterwards: no worker and no file in shared memory (it is held in RAM) is left behind
+    import atexit
+    import shutil
+
+    def _cleanup():
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        shutil.rmtree(d, ignore_errors=True)
+    atexit.register(_cleanup)
     for w in range(cores):
         job = {"dir": d, "N": N, "R": R,
                "sources": [w * sample_sources // cores, (w + 1) * sample_sources // cores],
