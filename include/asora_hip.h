@@ -399,6 +399,8 @@ int asora_last_raytrace_variant(void);
  * launch shape (units x 8 when line-aligned); for 0 <= table < *ntables: `words` receives 8 uint32 per entry (the 16-byte
  * cell-A and cell-B records, raytrace.hip) for up to capacity_entries entries, *entries the table's entry count, *nsteps its
  * steps, *shells / *max_cells the launch's shell count and zero slot.  table = -1 only reports the counts. */
+/* Device memory the geometry tables of the last launch shape occupy (a part shared between tables counts once). */
+size_t asora_debug_geometry_bytes(void);
 int asora_debug_geometry_table(int table, uint32_t *words, size_t capacity_entries, size_t *entries, int *nsteps, int *ntables,
                                int *shells, int *max_cells, int *threads);
 

@@ -87,6 +87,7 @@ SIGNATURES = {
     "asora_last_raytrace_counts_ex": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "asora_debug_coldens": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int, _dp, C.c_int]),
     "asora_last_raytrace_variant": (C.c_int, []),
+    "asora_debug_geometry_bytes": (C.c_size_t, []),
     "asora_debug_geometry_table": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int),
                                              C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "asora_build_id": (C.c_char_p, []),

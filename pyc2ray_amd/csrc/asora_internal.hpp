@@ -137,6 +137,12 @@ struct State {
 
     // raytracing geometry tables (built once per (N, R, dr), see raytrace.hip)
     std::vector<void *> geom_owned;
+    // tables that share their inner shells (geometry_device.hip, share_prefixes): one physical allocation mapped at the start of
+    // several virtual ranges, each followed by pages of its own (HIP virtual memory management)
+    struct GeomMapping { void *va; size_t size; };
+    std::vector<GeomMapping> geom_mapped;
+    std::vector<hipMemGenericAllocationHandle_t> geom_handles;
+    size_t geom_bytes = 0;                  // device memory the current tables occupy (physical: a shared part counts once)
     OctGeomDev geom_host[MAX_UNITS];        // device pointers of the unit tables ([class * units + unit] when geom_aligned)
     bool geom_aligned = false;
     // how the radius has behaved across raytrace launches (launch_raytrace: the eight-fold tables only pay when they are reused)

@@ -261,31 +261,39 @@ void build_unit_geometry(HostGeom &h, const UnitSpec &us, double R, double dr, i
 // found by marking backwards from the outermost shell through the corner links of the full sector's tables, then
 // renumbering the shell-buffer slots of what is kept.  Evaluations double (each wedge re-derives the inner part of the
 // sector), workgroups quadruple: the single-source trace gets about twice as fast.
-HostGeom restrict_to_wedge(const HostGeom &full, int wedge, int RT_THREADS, uint32_t zero_slot_marker)
+struct WedgeEntry { uint4 a, b; };
+using WedgeKeep = std::vector<std::vector<char>>;          // [shell index = s - 1][slot]
+
+static std::vector<std::vector<WedgeEntry>> shells_of(const HostGeom &full, int RT_THREADS)
 {
-    struct Entry { uint4 a, b; };
-    std::vector<std::vector<Entry>> shells;
-    {
-        std::vector<Entry> cur;
-        const size_t nent = (size_t)full.nsteps * RT_THREADS;
-        for (size_t st0 = 0; st0 < nent; st0 += RT_THREADS) {
-            for (int q = 0; q < RT_THREADS; ++q)
-                if (full.cellA[st0 + q].y & CELL_VALID) cur.push_back({full.cellA[st0 + q], full.cellB[st0 + q]});
-            if (full.cellA[st0].y & CELL_LAST) { shells.push_back(cur); cur.clear(); }
-        }
+    std::vector<std::vector<WedgeEntry>> shells;
+    std::vector<WedgeEntry> cur;
+    const size_t nent = (size_t)full.nsteps * RT_THREADS;
+    for (size_t st0 = 0; st0 < nent; st0 += RT_THREADS) {
+        for (int q = 0; q < RT_THREADS; ++q)
+            if (full.cellA[st0 + q].y & CELL_VALID) cur.push_back({full.cellA[st0 + q], full.cellB[st0 + q]});
+        if (full.cellA[st0].y & CELL_LAST) { shells.push_back(cur); cur.clear(); }
     }
-    auto in_wedge = [wedge](const uint4 &a) -> bool {           // (own-face cells: rated, or on the sphere and possibly rated later)
-        if (!(a.y & (CELL_RATE | CELL_SPHERE))) return false;
-        const int ca = a.x & 1023, cb = (a.x >> 10) & 1023, cc = (a.x >> 20) & 1023, face = a.x >> 30;
-        const int s = std::max(ca, std::max(cb, cc));
-        const int U = face == 0 ? cb : ca, V = face == 2 ? cb : cc;
-        return ((2 * U > s ? 1 : 0) | (2 * V > s ? 2 : 0)) == wedge;
-    };
-    // backward marking: what the wedge's rated cells read, transitively
-    std::vector<std::vector<char>> keep(shells.size());
+    return shells;
+}
+
+static bool entry_in_wedge(const uint4 &a, int wedge)           // (own-face cells: rated, or on the sphere and possibly rated later)
+{
+    if (!(a.y & (CELL_RATE | CELL_SPHERE))) return false;
+    const int ca = a.x & 1023, cb = (a.x >> 10) & 1023, cc = (a.x >> 20) & 1023, face = a.x >> 30;
+    const int s = std::max(ca, std::max(cb, cc));
+    const int U = face == 0 ? cb : ca, V = face == 2 ? cb : cc;
+    return ((2 * U > s ? 1 : 0) | (2 * V > s ? 2 : 0)) == wedge;
+}
+
+// backward marking: what the wedge's rated cells read, transitively
+WedgeKeep wedge_keep(const HostGeom &full, int wedge, int RT_THREADS, uint32_t zero_slot_marker)
+{
+    const auto shells = shells_of(full, RT_THREADS);
+    WedgeKeep keep(shells.size());
     for (size_t si = 0; si < shells.size(); ++si) {
         keep[si].assign(shells[si].size(), 0);
-        for (size_t q = 0; q < shells[si].size(); ++q) keep[si][q] = in_wedge(shells[si][q].a) ? 1 : 0;
+        for (size_t q = 0; q < shells[si].size(); ++q) keep[si][q] = entry_in_wedge(shells[si][q].a, wedge) ? 1 : 0;
     }
     for (size_t si = shells.size(); si-- > 1;)
         for (size_t q = 0; q < shells[si].size(); ++q) {
@@ -293,6 +301,14 @@ HostGeom restrict_to_wedge(const HostGeom &full, int wedge, int RT_THREADS, uint
             const uint32_t c[4] = {shells[si][q].b.x, shells[si][q].b.y, shells[si][q].b.z, shells[si][q].b.w};
             for (uint32_t slot : c) if (slot != zero_slot_marker) keep[si - 1][slot] = 1;     // slot == rank in its shell
         }
+    return keep;
+}
+
+HostGeom restrict_to_wedge(const HostGeom &full, int wedge, int RT_THREADS, uint32_t zero_slot_marker, const WedgeKeep &keep)
+{
+    using Entry = WedgeEntry;
+    const auto shells = shells_of(full, RT_THREADS);
+    auto in_wedge = [wedge](const uint4 &a) -> bool { return entry_in_wedge(a, wedge); };
     HostGeom h;
     h.S = full.S; h.inconsistent = full.inconsistent; h.on_sphere = full.on_sphere;
     const uint4 pad_a = {0u, 0u, 0u, 0u};
@@ -371,6 +387,13 @@ void release_geometry(State &st)
 {
     for (void *q : st.geom_owned) (void)hipFree(q);
     st.geom_owned.clear();
+    st.geom_bytes = 0;
+    if (!st.geom_mapped.empty() || !st.geom_handles.empty()) {
+        (void)hipDeviceSynchronize();                 // nothing may still walk a range that is about to be unmapped
+        for (auto &m : st.geom_mapped) { (void)hipMemUnmap(m.va, m.size); (void)hipMemAddressFree(m.va, m.size); }
+        for (auto &h : st.geom_handles) (void)hipMemRelease(h);
+        st.geom_mapped.clear(); st.geom_handles.clear();
+    }
     st.geom_sphere.clear();
     st.geom_valid = false;
 }
@@ -583,10 +606,42 @@ int ensure_geometry(State &st, RtParams &p, int threads, int units, const Subbox
             for (auto &w : workers) w.join();
             workers.clear();
             t_sectors = now_s();
+            // what every wedge table keeps of its sector; the octant variants of one (sector, wedge) under a clipped window form a
+            // family whose sectors hold the same entries up to shell m = the smallest extent: there the UNION of the members' needs
+            // is kept, so that those shells come out identical in all members (geometry_device.hip shares their memory)
+            std::vector<WedgeKeep> keep(units);
             for (int u = 0; u < units; ++u) {
                 if (owner[u] != u) continue;
-                workers.emplace_back([&hg, &sector, &spec, &owner, u, threads]() {
-                    hg[u] = restrict_to_wedge(sector[owner[u % 24]], spec[u].wedge, threads, MARK);
+                workers.emplace_back([&keep, &sector, &spec, &owner, u, threads]() {
+                    keep[u] = wedge_keep(sector[owner[u % 24]], spec[u].wedge, threads, MARK);
+                });
+            }
+            for (auto &w : workers) w.join();
+            workers.clear();
+            if (!getenv("ASORA_GEOMETRY_NO_SHARING")) {
+                std::vector<char> taken(units, 0);
+                for (int u = 0; u < units; ++u) {
+                    if (owner[u] != u || taken[u]) continue;
+                    std::vector<int> fam;
+                    for (int v = u; v < units; ++v)
+                        if (owner[v] == v && !taken[v] && spec[v].face == spec[u].face && spec[v].wedge == spec[u].wedge) { fam.push_back(v); taken[v] = 1; }
+                    if (fam.size() < 2) continue;
+                    int m = 1 << 28;
+                    for (int v : fam) m = std::min(m, std::min(spec[v].ext[0], std::min(spec[v].ext[1], spec[v].ext[2])));
+                    bool ok = m >= 1;
+                    for (int v : fam) ok = ok && (int)keep[v].size() >= m;
+                    if (!ok) continue;
+                    for (int si = 0; si < m; ++si) {
+                        std::vector<char> &first = keep[fam[0]][(size_t)si];
+                        for (size_t q = 1; q < fam.size(); ++q) for (size_t c = 0; c < first.size(); ++c) first[c] |= keep[fam[q]][(size_t)si][c];
+                        for (size_t q = 1; q < fam.size(); ++q) keep[fam[q]][(size_t)si] = first;
+                    }
+                }
+            }
+            for (int u = 0; u < units; ++u) {
+                if (owner[u] != u) continue;
+                workers.emplace_back([&hg, &keep, &sector, &spec, &owner, u, threads]() {
+                    hg[u] = restrict_to_wedge(sector[owner[u % 24]], spec[u].wedge, threads, MARK, keep[u]);
                 });
             }
             for (auto &w : workers) w.join();
@@ -621,6 +676,7 @@ int ensure_geometry(State &st, RtParams &p, int threads, int units, const Subbox
         d.info = 0;
         if (int rc = upload(h.cellA, d.cellA, st.geom_owned)) return rc;
         if (int rc = upload(h.cellB, d.cellB, st.geom_owned)) return rc;
+        st.geom_bytes += 2 * h.cellA.size() * sizeof(uint4);
         od[v] = d;
         if (h.on_sphere)         // where the on-sphere cells of this table live on the device (see patch_sphere_cells)
             for (size_t e = 0; e < h.cellA.size(); ++e)
@@ -661,6 +717,8 @@ int ensure_geometry(State &st, RtParams &p, int threads, int units, const Subbox
 }
 
 } // namespace asora
+
+extern "C" size_t asora_debug_geometry_bytes(void) { return asora::state().geom_valid ? asora::state().geom_bytes : 0; }
 
 extern "C" int asora_debug_geometry_table(int table, uint32_t *words, size_t capacity_entries, size_t *entries, int *nsteps, int *ntables,
                                           int *shells, int *max_cells, int *threads)

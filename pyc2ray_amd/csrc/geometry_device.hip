@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -167,7 +168,8 @@ struct TableJob {
     GeomTableSpec spec;
     size_t cand_base;            // start of the table's candidates in the rank / pos arrays
     size_t meta_base;            // start of its per-shell records (S + 1 each)
-    int S_built;                 // pass B: shells 1..S_built are written
+    int S_built;                 // pass B: shells first_shell..S_built are written
+    int first_shell;             // 1, or m + 1 for a table whose shells 1..m live in memory it shares with its family (share_prefixes)
     uint4 *cellA, *cellB;        // pass B
 };
 
@@ -259,7 +261,7 @@ __global__ void __launch_bounds__(GB_THREADS) geometry_write_kernel(const TableJ
     __shared__ ShellBlocks B, Bp;
     const TableJob &J = jobs[blockIdx.y];
     const int s = blockIdx.x + 1;
-    if (s > J.S_built) return;
+    if (s > J.S_built || s < J.first_shell) return;
     const GeomTableSpec us = J.spec;
     if (threadIdx.x == 0) { shell_blocks(us, s, B); if (s > 1) shell_blocks(us, s - 1, Bp); }
     __syncthreads();
@@ -359,8 +361,16 @@ struct WedgeJob {
     size_t keep_base;                // this wedge's keep bytes (one per entry of the full table)
     size_t wmeta_base;               // the wedge table's per-shell records
     int S_built;
+    int first_shell;                 // as TableJob::first_shell
     uint4 *cellA, *cellB;
 };
+
+// keep[dst] |= keep[src] over n bytes: the inner shells of a family of wedge tables are kept as the UNION of what its members need
+// (a union of dependency-closed sets is closed), so that those shells come out identical and can share their memory
+__global__ void keep_or_kernel(unsigned char *keep, size_t dst, size_t src, size_t n)
+{
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) keep[dst + q] |= keep[src + q];
+}
 
 __global__ void wedge_seed_kernel(const WedgeJob *jobs, const size_t *shell_entry, const int *count, unsigned char *keep)
 {
@@ -418,7 +428,7 @@ __global__ void __launch_bounds__(GB_THREADS) wedge_write_kernel(const WedgeJob 
 {
     const WedgeJob &J = jobs[blockIdx.y];
     const int s = blockIdx.x + 1;
-    if (s > J.S_built) return;
+    if (s > J.S_built || s < J.first_shell) return;
     const size_t e0 = shell_entry[J.meta_base + s], ep = shell_entry[J.meta_base + s - 1];
     const size_t w0 = wshell_entry[J.wmeta_base + s];
     const int n = count[J.meta_base + s];
@@ -467,11 +477,12 @@ struct DevArray {
 
 // lay the shells of a table out: entry offset of every shell, entries of its steps proper, total steps; the host builder's
 // padding rules (whole steps per shell; whole triples behind a sub-box boundary; whole triples at the end; four closing steps)
-struct Layout { std::vector<size_t> entry; std::vector<int> len; std::vector<int> step_after_shell; int S_built = 0, nsteps = 0; uint32_t max_cells = 1; size_t entries = 0; };
+struct Layout { std::vector<size_t> entry, after; std::vector<int> len; std::vector<int> step_after_shell; int S_built = 0, nsteps = 0; uint32_t max_cells = 1; size_t entries = 0; };   // after[s]: entries up to and including shell s (its steps and any sub-box padding)
 Layout lay_out(const int *count, const int *packed, int S, int threads, int boxsize)
 {
     Layout L;
     L.entry.assign((size_t)S + 2, 0);
+    L.after.assign((size_t)S + 2, 0);
     L.len.assign((size_t)S + 2, 0);
     size_t at = 0;
     for (int s = 1; s <= S; ++s) {
@@ -482,6 +493,7 @@ Layout lay_out(const int *count, const int *packed, int S, int threads, int boxs
         L.len[(size_t)s] = (int)len;
         at += len;
         if (boxsize > 0 && s % boxsize == 0) while ((at / (size_t)threads) % 3) at += (size_t)threads;
+        L.after[(size_t)s] = at;
         L.max_cells = std::max<uint32_t>(L.max_cells, (uint32_t)count[s]);
         L.step_after_shell.resize((size_t)s + 1, 0);
         L.step_after_shell[(size_t)s] = (int)(at / (size_t)threads);
@@ -492,6 +504,103 @@ Layout lay_out(const int *count, const int *packed, int S, int threads, int boxs
     L.step_after_shell.back() = L.nsteps;
     L.entries = at + 4 * (size_t)threads;
     return L;
+}
+
+// ---- tables that share their inner shells ---------------------------------------------------------------------------
+// Tables of one family -- same face, merged axes, wedge, alignment class; window extents that differ -- hold the same entries
+// for every shell up to m = the smallest extent in the family: the window does not bind there (shell_blocks: min(maxmag <= s, ext)).
+// A trace beyond the box on an even mesh is the case that matters: the window is [-N/2, N/2 - 1], every sign variant of a unit
+// gets a table of its own, and they differ in the LAST shell only (0.56 GB of tables for 12 units at 256^3, 1.3 GB for 96).
+// The kernel walks a table as one array; so the shared part is ONE physical allocation mapped at the start of every member's
+// virtual range, followed by the member's own pages (hipMemCreate / hipMemAddressReserve / hipMemMap; tools/micro/vmm_alias.hip
+// shows the aliasing works on this device, granularity 4 KiB).  No change to the kernel, no change to a table's content.
+struct Family { std::vector<int> members; int m = 0; size_t prefix_entries = 0; };
+
+static std::vector<Family> find_families(const std::vector<GeomTableSpec> &specs, const std::vector<Layout> &L, int threads, size_t gran)
+{
+    std::vector<Family> fams;
+    std::vector<char> taken(specs.size(), 0);
+    auto min_ext = [](const GeomTableSpec &g) { int m = std::min(g.ext[0], std::min(g.ext[1], g.ext[2])); return g.merge_mask ? std::min(m, g.ext_neg) : m; };
+    for (size_t t = 0; t < specs.size(); ++t) {
+        if (taken[t]) continue;
+        Family f;
+        for (size_t u = t; u < specs.size(); ++u)
+            if (!taken[u] && specs[u].face == specs[t].face && specs[u].merge_mask == specs[t].merge_mask && specs[u].wedge == specs[t].wedge &&
+                specs[u].align_class == specs[t].align_class) { f.members.push_back((int)u); taken[u] = 1; }
+        if (f.members.size() < 2) continue;
+        f.m = min_ext(specs[(size_t)f.members[0]]);
+        for (int u : f.members) f.m = std::min(f.m, min_ext(specs[(size_t)u]));
+        // shared: the entries before shell m + 1 -- the same offset in every member's layout, a whole number of mapping granules
+        bool ok = f.m >= 1;
+        for (int u : f.members) ok = ok && L[(size_t)u].S_built >= f.m;
+        if (!ok) continue;
+        auto prefix_of = [&](int u) { return L[(size_t)u].after[(size_t)f.m]; };
+        f.prefix_entries = prefix_of(f.members[0]);
+        for (int u : f.members) ok = ok && prefix_of(u) == f.prefix_entries;
+        if (!ok || f.prefix_entries == 0 || (f.prefix_entries * sizeof(uint4)) % gran != 0) continue;
+        fams.push_back(f);
+    }
+    return fams;
+}
+
+// Allocate cellA / cellB of every table: families through mapped ranges (the first member writes the shared shells), everything else
+// with hipMalloc.  first_shell[t] = first shell table t writes itself.
+static int allocate_tables(State &st, const std::vector<GeomTableSpec> &specs, const std::vector<Layout> &L, int threads,
+                           std::vector<uint4 *> &A, std::vector<uint4 *> &B, std::vector<int> &first_shell, std::vector<size_t> &fill_from)
+{
+    const size_t nt = specs.size();
+    A.assign(nt, nullptr); B.assign(nt, nullptr); first_shell.assign(nt, 1); fill_from.assign(nt, 0);
+    std::vector<char> done(nt, 0);
+    static const bool no_sharing = getenv("ASORA_GEOMETRY_NO_SHARING") != nullptr;        // (A/B of the memory figure; tests)
+    int vmm = 0;
+    (void)hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, st.device);
+    if (vmm && !no_sharing) {
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = st.device;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) == hipSuccess && gran > 0) {
+            hipMemAccessDesc acc = {};
+            acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+            auto round_up = [gran](size_t b) { return (b + gran - 1) / gran * gran; };
+            for (const Family &f : find_families(specs, L, threads, gran)) {
+                const size_t pre = f.prefix_entries * sizeof(uint4);
+                for (int arr = 0; arr < 2; ++arr) {
+                    hipMemGenericAllocationHandle_t hp;
+                    ASORA_HIP_TRY(hipMemCreate(&hp, pre, &prop, 0));
+                    st.geom_handles.push_back(hp);
+                    st.geom_bytes += pre;
+                    for (int u : f.members) {
+                        const size_t tail = round_up(L[(size_t)u].entries * sizeof(uint4) - pre);
+                        hipMemGenericAllocationHandle_t ht;
+                        ASORA_HIP_TRY(hipMemCreate(&ht, tail, &prop, 0));
+                        st.geom_handles.push_back(ht);
+                        st.geom_bytes += tail;
+                        void *va = nullptr;
+                        ASORA_HIP_TRY(hipMemAddressReserve(&va, pre + tail, 0, nullptr, 0));
+                        st.geom_mapped.push_back({va, pre + tail});
+                        ASORA_HIP_TRY(hipMemMap(va, pre, 0, hp, 0));
+                        ASORA_HIP_TRY(hipMemMap((char *)va + pre, tail, 0, ht, 0));
+                        ASORA_HIP_TRY(hipMemSetAccess(va, pre + tail, &acc, 1));
+                        (arr == 0 ? A : B)[(size_t)u] = static_cast<uint4 *>(va);
+                    }
+                }
+                for (size_t q = 0; q < f.members.size(); ++q) {
+                    const int u = f.members[q];
+                    done[(size_t)u] = 1;
+                    if (q > 0) { first_shell[(size_t)u] = f.m + 1; fill_from[(size_t)u] = f.prefix_entries; }
+                }
+            }
+        }
+    }
+    for (size_t t = 0; t < nt; ++t) {
+        if (done[t]) continue;
+        uint4 *a = nullptr, *b = nullptr;
+        ASORA_HIP_TRY(hipMalloc(&a, L[t].entries * sizeof(uint4))); st.geom_owned.push_back(a);
+        ASORA_HIP_TRY(hipMalloc(&b, L[t].entries * sizeof(uint4))); st.geom_owned.push_back(b);
+        st.geom_bytes += 2 * L[t].entries * sizeof(uint4);
+        A[t] = a; B[t] = b;
+    }
+    return 0;
 }
 
 } // namespace
@@ -542,6 +651,7 @@ int build_geometry_on_device(State &st, const std::vector<GeomTableSpec> &specs,
             const size_t n = 4 * (size_t)threads;
             ASORA_HIP_TRY(hipMalloc(&a, n * sizeof(uint4))); st.geom_owned.push_back(a);
             ASORA_HIP_TRY(hipMalloc(&b, n * sizeof(uint4))); st.geom_owned.push_back(b);
+            st.geom_bytes += 2 * n * sizeof(uint4);
             ASORA_HIP_TRY(hipMemsetAsync(a, 0, n * sizeof(uint4), st.stream));
             hipLaunchKernelGGL(fill_pad_kernel, dim3(4), dim3(256), 0, st.stream, b, n, 1u);
             out[(size_t)t] = OctGeomDev{a, b, 0, 0};
@@ -559,7 +669,7 @@ int build_geometry_on_device(State &st, const std::vector<GeomTableSpec> &specs,
         jobs[(size_t)t].spec = full[(size_t)t];
         jobs[(size_t)t].cand_base = total_cand;
         jobs[(size_t)t].meta_base = (size_t)t * (S + 2);
-        jobs[(size_t)t].S_built = 0; jobs[(size_t)t].cellA = jobs[(size_t)t].cellB = nullptr;
+        jobs[(size_t)t].S_built = 0; jobs[(size_t)t].first_shell = 1; jobs[(size_t)t].cellA = jobs[(size_t)t].cellB = nullptr;
         size_t at = 0;
         shell_cand[jobs[(size_t)t].meta_base + 0] = 0;              // (shell 0 has no candidates: the corners of shell 1 are the source cell)
         for (int s = 1; s <= S; ++s) {
@@ -608,16 +718,24 @@ int build_geometry_on_device(State &st, const std::vector<GeomTableSpec> &specs,
     //  known only after their own count; the full sectors then keep MARK-free temporaries with their own zero slot)
     std::vector<void *> temp_tables;
     struct FreeTemps { std::vector<void *> &v; ~FreeTemps() { for (void *q : v) (void)hipFree(q); } } free_temps{temp_tables};
+    std::vector<uint4 *> tabA, tabB;
+    std::vector<int> first_shell((size_t)nf, 1);
+    std::vector<size_t> fill_from((size_t)nf, 0);
+    if (wedges) {           // the full sectors are temporaries
+        tabA.assign((size_t)nf, nullptr); tabB.assign((size_t)nf, nullptr);
+        for (int t = 0; t < nf; ++t) {
+            ASORA_HIP_TRY(hipMalloc(&tabA[(size_t)t], L[(size_t)t].entries * sizeof(uint4))); temp_tables.push_back(tabA[(size_t)t]);
+            ASORA_HIP_TRY(hipMalloc(&tabB[(size_t)t], L[(size_t)t].entries * sizeof(uint4))); temp_tables.push_back(tabB[(size_t)t]);
+        }
+    } else if (int rc = allocate_tables(st, full, L, threads, tabA, tabB, first_shell, fill_from)) return rc;
     for (int t = 0; t < nf; ++t) {
-        uint4 *a = nullptr, *b = nullptr;
-        const size_t n = L[(size_t)t].entries;
-        ASORA_HIP_TRY(hipMalloc(&a, n * sizeof(uint4)));
-        if (wedges) temp_tables.push_back(a); else st.geom_owned.push_back(a);
-        ASORA_HIP_TRY(hipMalloc(&b, n * sizeof(uint4)));
-        if (wedges) temp_tables.push_back(b); else st.geom_owned.push_back(b);
+        // padding everywhere first (a member of a family: behind the shells it shares, which the family's first member pads)
+        const size_t n = L[(size_t)t].entries - fill_from[(size_t)t];
+        uint4 *a = tabA[(size_t)t] + fill_from[(size_t)t], *b = tabB[(size_t)t] + fill_from[(size_t)t];
         ASORA_HIP_TRY(hipMemsetAsync(a, 0, n * sizeof(uint4), st.stream));
         hipLaunchKernelGGL(fill_pad_kernel, dim3((unsigned)std::min<size_t>(1024, (n + 255) / 256)), dim3(256), 0, st.stream, b, n, max_cells_full);
-        jobs[(size_t)t].cellA = a; jobs[(size_t)t].cellB = b; jobs[(size_t)t].S_built = L[(size_t)t].S_built;
+        jobs[(size_t)t].cellA = tabA[(size_t)t]; jobs[(size_t)t].cellB = tabB[(size_t)t]; jobs[(size_t)t].S_built = L[(size_t)t].S_built;
+        jobs[(size_t)t].first_shell = first_shell[(size_t)t];
     }
     ASORA_HIP_TRY(hipMemcpyAsync(d_jobs.p, jobs.data(), jobs.size() * sizeof(TableJob), hipMemcpyHostToDevice, st.stream));
     if (int rc = d_shell_entry.upload(shell_entry, st.stream)) return rc;
@@ -654,7 +772,7 @@ int build_geometry_on_device(State &st, const std::vector<GeomTableSpec> &specs,
             w.fullA = jobs[(size_t)f].cellA; w.fullB = jobs[(size_t)f].cellB;
             w.meta_base = jobs[(size_t)f].meta_base; w.S_full = L[(size_t)f].S_built; w.wedge = specs[(size_t)t].wedge;
             w.keep_base = keep_total; keep_total += L[(size_t)f].entries;
-            w.wmeta_base = (size_t)t * (S + 2); w.S_built = 0; w.cellA = w.cellB = nullptr;
+            w.wmeta_base = (size_t)t * (S + 2); w.S_built = 0; w.first_shell = 1; w.cellA = w.cellB = nullptr;
         }
         DevArray<WedgeJob> d_wj;
         DevArray<unsigned char> d_keep;
@@ -671,6 +789,23 @@ int build_geometry_on_device(State &st, const std::vector<GeomTableSpec> &specs,
         for (int s = S; s >= 2; --s)
             hipLaunchKernelGGL(wedge_mark_kernel, dim3(32, (unsigned)nt), dim3(256), 0, st.stream, (const WedgeJob *)d_wj.p,
                                (const size_t *)d_shell_entry.p, (const int *)d_count.p, d_keep.p, s, max_cells_full);
+        {   // Families of wedge tables (the octant variants of one sector and wedge under a clipped window): their full sectors
+            // hold the same entries up to shell m, but what a wedge KEEPS of them follows from its outer shells, which differ.  Keep
+            // the union of the members' needs there: the inner shells of all members then come out identical (and are shared below).
+            static const bool no_sharing = getenv("ASORA_GEOMETRY_NO_SHARING") != nullptr;
+            std::vector<Layout> FL((size_t)nt);                   // the layout of each wedge table's FULL sector
+            for (int t = 0; t < nt; ++t) FL[(size_t)t] = L[(size_t)full_of[(size_t)t]];
+            if (!no_sharing)
+                for (const Family &f : find_families(specs, FL, threads, 1)) {
+                    const size_t n = f.prefix_entries;               // (entries of the full sectors before shell m + 1)
+                    const unsigned blocks = (unsigned)std::min<size_t>(4096, (n + 255) / 256);
+                    const size_t first = wj[(size_t)f.members[0]].keep_base;
+                    for (size_t q = 1; q < f.members.size(); ++q)
+                        hipLaunchKernelGGL(keep_or_kernel, dim3(blocks), dim3(256), 0, st.stream, d_keep.p, first, wj[(size_t)f.members[q]].keep_base, n);
+                    for (size_t q = 1; q < f.members.size(); ++q)
+                        ASORA_HIP_TRY(hipMemcpyAsync(d_keep.p + wj[(size_t)f.members[q]].keep_base, d_keep.p + first, n, hipMemcpyDeviceToDevice, st.stream));
+                }
+        }
         hipLaunchKernelGGL(wedge_count_kernel, dim3((unsigned)S, (unsigned)nt), dim3(GB_THREADS), 0, st.stream, (const WedgeJob *)d_wj.p,
                            (const size_t *)d_shell_entry.p, (const int *)d_count.p, (const unsigned char *)d_keep.p, d_newslot.p, d_wcount.p);
         ASORA_HIP_TRY(hipGetLastError());
@@ -687,17 +822,20 @@ int build_geometry_on_device(State &st, const std::vector<GeomTableSpec> &specs,
             for (int s = 0; s <= S + 1; ++s) { wentry[mb + s] = WL[(size_t)t].entry[(size_t)s]; wlen[mb + s] = WL[(size_t)t].len[(size_t)s]; }
             max_cells_all = std::max(max_cells_all, WL[(size_t)t].max_cells);
         }
+        std::vector<uint4 *> wA, wB;
+        std::vector<int> wfirst;
+        std::vector<size_t> wfill;
+        if (int rc = allocate_tables(st, specs, WL, threads, wA, wB, wfirst, wfill)) return rc;
         for (int t = 0; t < nt; ++t) {
-            uint4 *a = nullptr, *b = nullptr;
-            const size_t n = WL[(size_t)t].entries;
-            ASORA_HIP_TRY(hipMalloc(&a, n * sizeof(uint4))); st.geom_owned.push_back(a);
-            ASORA_HIP_TRY(hipMalloc(&b, n * sizeof(uint4))); st.geom_owned.push_back(b);
+            const size_t n = WL[(size_t)t].entries - wfill[(size_t)t];
+            uint4 *a = wA[(size_t)t] + wfill[(size_t)t], *b = wB[(size_t)t] + wfill[(size_t)t];
             ASORA_HIP_TRY(hipMemsetAsync(a, 0, n * sizeof(uint4), st.stream));
             hipLaunchKernelGGL(fill_pad_kernel, dim3((unsigned)std::min<size_t>(1024, (n + 255) / 256)), dim3(256), 0, st.stream, b, n, max_cells_all);
-            wj[(size_t)t].cellA = a; wj[(size_t)t].cellB = b; wj[(size_t)t].S_built = WL[(size_t)t].S_built;
-            out[(size_t)t] = OctGeomDev{a, b, WL[(size_t)t].nsteps, 0};
+            wj[(size_t)t].cellA = wA[(size_t)t]; wj[(size_t)t].cellB = wB[(size_t)t]; wj[(size_t)t].S_built = WL[(size_t)t].S_built;
+            wj[(size_t)t].first_shell = wfirst[(size_t)t];
+            out[(size_t)t] = OctGeomDev{wA[(size_t)t], wB[(size_t)t], WL[(size_t)t].nsteps, 0};
             step_after[(size_t)t] = WL[(size_t)t].step_after_shell;
-            final_A[(size_t)t] = a;
+            final_A[(size_t)t] = wA[(size_t)t];
         }
         ASORA_HIP_TRY(hipMemcpyAsync(d_wj.p, wj.data(), wj.size() * sizeof(WedgeJob), hipMemcpyHostToDevice, st.stream));
         ASORA_HIP_TRY(hipMemsetAsync(d_nsphere.p, 0, sizeof(unsigned), st.stream));       // (the full sectors' pass counted theirs)

@@ -325,6 +325,10 @@ class _LibAsora:
         return {"paired": bool(v & 1), "aligned": bool(v & 2), "buffer_atomics": bool(v & 4), "split_descriptors": bool(v & 8),
                 "skip_zero": bool(v & 16), "global_shells": bool(v & 32), "units": (v >> 8) & 255, "threads": v >> 16}
 
+    def debug_geometry_bytes(self):
+        """Device memory of the current geometry tables (shared parts once)."""
+        return int(self._lib.asora_debug_geometry_bytes())
+
     def debug_geometry_tables(self):
         """The geometry tables of the last raytrace launch: (list of (entries x 8) uint32 arrays, dict(nsteps, shells, max_cells, threads))."""
         n, ns, nt, sh, mc, th = C.c_size_t(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)

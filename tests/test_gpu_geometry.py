@@ -72,6 +72,7 @@ SHAPES = [
     (64, 20, 20.0, {}),                         # 24 sectors
     (64, 1, 20.0, {}), (48, 2, 1000.0, {}),     # 96 quarter sectors; whole box, clipped window
     (64, 1000, 1000.0, {}), (33, 1000, 1000.0, {}), (40, 4, 15.0, {}),          # whole box: even and odd mesh
+    (64, 20, 1000.0, {}), (64, 3, 1000.0, {"OPT_SECTORS": 4, "OPT_BLOCK_THREADS": 256}), (64, 1000, 40.0, {}),   # clipped windows: tables that share their inner shells
     (64, 400, 14.0, {"OPT_SECTORS": 1, "OPT_BLOCK_THREADS": 64}), (64, 400, 14.0, {"OPT_SECTORS": 5, "OPT_BLOCK_THREADS": 128}),
     (64, 400, 17.0, {"OPT_SECTORS": 8}), (64, 400, 17.0, {"OPT_SECTORS": 9, "OPT_BLOCK_THREADS": 128}),
     (64, 400, 17.0, {"OPT_SECTORS": 2, "OPT_BLOCK_THREADS": 64}), (64, 400, 17.0, {"OPT_SECTORS": 7, "OPT_BLOCK_THREADS": 512}),
@@ -145,3 +146,36 @@ def test_cells_on_the_sphere_follow_dr_with_both_builders(asora):
     for q, (a, b) in enumerate(zip(out[False], out[True])):
         _same((a[0], a[1]), (b[0], b[1]), ("dr sequence", q))
         assert a[2] == b[2]
+
+
+
+@pytest.mark.parametrize("ns,limit_MB", [(1000, 30.0), (1, 45.0)])
+def test_whole_box_tables_share_their_inner_shells(asora, ns, limit_MB):
+    """A trace beyond the box on an even mesh: the periodic window is [-N/2, N/2 - 1], every sign variant of a unit needs a table of
+    its own, and they differ in the last shell only.  The variants' tables share the memory of everything before it (one physical
+    allocation mapped into each table's address range, geometry_device.hip): at 128^3 the twelve sector-pair tables of a many-source
+    trace take ~20 MB instead of 70, the 96 quarter-sector tables of a single source ~25 MB instead of 160 -- with the contents (checked
+    bit for bit against the host builder above) and the results (here: against the oracle) unchanged."""
+    from oracle import oracle as O
+    p, lib, capi = asora
+    N = 128
+    thin, dlog, dr = _setup(p, lib, capi, N, ns, seed=11)
+    R = 1000.0
+    lib.raytrace_device(R, cases.SIG, dr, 0, ns, cases.MINLOGTAU, dlog, thin.shape[0] - 1)
+    mb = lib.debug_geometry_bytes() / 1e6
+    v = lib.last_raytrace_variant()
+    assert v["units"] == (96 if ns == 1 else 12), v
+    assert 5.0 < mb < limit_MB, (mb, v)
+    if ns == 1:           # one source: the oracle is affordable
+        nd, xh, _ = cases.grid(N, "lognormal", 11, 0.1)
+        rng = np.random.default_rng(11)
+        pos = 1 + rng.integers(0, N, size=(3, ns))
+        flux = rng.uniform(0.5, 2.0, size=ns)
+        p0, f0 = cases.flat_sources(pos, flux)
+        phi = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+        ref = O.asora_do_all_sources(R, cases.SIG, dr, nd, xh, p0, f0, thin, cases.soft_tables()[1], cases.MINLOGTAU, dlog,
+                                     NumTau=thin.shape[0] - 1, flags=O.ASORA_MODE)["phi_ion"]
+        w = ref != 0
+        assert np.array_equal(phi != 0, w) and int(w.sum()) == N ** 3
+        np.testing.assert_allclose(phi[w], ref[w], rtol=1e-8, atol=0)
+

@@ -37,7 +37,8 @@ for N in a.N:
             lib.synchronize()
             times.append(time.perf_counter() - t0)
         print(json.dumps({"N": N, "sources": ns, "R": R, "first_call_s": times[0], "second_call_s": times[1], "third_call_s": times[2],
-                          "geometry_build_and_upload_s": times[0] - times[1]}), flush=True)
+                          "geometry_build_and_upload_s": times[0] - times[1], "geometry_table_MB": lib.debug_geometry_bytes() / 1e6,
+                          "variant": lib.last_raytrace_variant()}), flush=True)
 # dr-only change: 256^3, 1000 sources, integer radii (lattice points exactly on the sphere: 6 at R = 64, 30 at R = 25, ...)
 for R in (64.0, 30.0, 25.0):
     N, ns = 256, 1000
