@@ -17,6 +17,10 @@ struct OctGeomDev {
     const uint4 *cellB;          // shell-buffer slots of the four upstream corners in shell s-1
     int nsteps;
     int info;                    // sign bits of the unit | (merge axis + 1) << 3 | rates-the-source-cell << 5
+    int inner;                   // tables that share their inner shells (geometry_device.hip): steps [0, inner >> 8) are read through
+                                 // cellA / cellB of table (inner & 255) of the same array, the rest through this table's own
+                                 // pointers (which are shifted: entry e of the table is cellA[e] on either side).  0: all its own
+    int reserved_;
 };
 
 constexpr int MAX_UNITS = 96;   // workgroups per source: 8 octants, 12 mirrored sector pairs, 24 sectors or 96 sector wedges
@@ -137,12 +141,7 @@ struct State {
 
     // raytracing geometry tables (built once per (N, R, dr), see raytrace.hip)
     std::vector<void *> geom_owned;
-    // tables that share their inner shells (geometry_device.hip, share_prefixes): one physical allocation mapped at the start of
-    // several virtual ranges, each followed by pages of its own (HIP virtual memory management)
-    struct GeomMapping { void *va; size_t size; };
-    std::vector<GeomMapping> geom_mapped;
-    std::vector<hipMemGenericAllocationHandle_t> geom_handles;
-    size_t geom_bytes = 0;                  // device memory the current tables occupy (physical: a shared part counts once)
+    size_t geom_bytes = 0;                  // device memory the current tables occupy (shells shared by several tables count once)
     OctGeomDev geom_host[MAX_UNITS];        // device pointers of the unit tables ([class * units + unit] when geom_aligned)
     bool geom_aligned = false;
     // how the radius has behaved across raytrace launches (launch_raytrace: the eight-fold tables only pay when they are reused)

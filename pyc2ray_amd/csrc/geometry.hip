@@ -388,12 +388,6 @@ void release_geometry(State &st)
     for (void *q : st.geom_owned) (void)hipFree(q);
     st.geom_owned.clear();
     st.geom_bytes = 0;
-    if (!st.geom_mapped.empty() || !st.geom_handles.empty()) {
-        (void)hipDeviceSynchronize();                 // nothing may still walk a range that is about to be unmapped
-        for (auto &m : st.geom_mapped) { (void)hipMemUnmap(m.va, m.size); (void)hipMemAddressFree(m.va, m.size); }
-        for (auto &h : st.geom_handles) (void)hipMemRelease(h);
-        st.geom_mapped.clear(); st.geom_handles.clear();
-    }
     st.geom_sphere.clear();
     st.geom_valid = false;
 }
@@ -563,10 +557,13 @@ int ensure_geometry(State &st, RtParams &p, int threads, int units, const Subbox
             release_geometry(st);
             return rc;
         }
+        std::vector<int> at((size_t)specs.size(), -1);          // a place of every distinct table in od[]
+        for (int v = tables - 1; v >= 0; --v) at[(size_t)where[(size_t)((v / units) * units + owner[v % units])]] = v;
         for (int v = 0; v < tables; ++v) {
             const int src = where[(size_t)((v / units) * units + owner[v % units])];
             od[v] = built[(size_t)src];
             od[v].info = info[v % units];
+            if (od[v].inner) od[v].inner = (od[v].inner & ~255) | at[(size_t)(od[v].inner & 255)];        // (shared inner shells: which table holds them)
         }
         for (int u = 0; u < units && u < 12; ++u) steps_after[u] = after[(size_t)where[(size_t)owner[u]]];
     } else {
@@ -671,9 +668,8 @@ int ensure_geometry(State &st, RtParams &p, int threads, int units, const Subbox
             if (nb.z == MARK) nb.z = max_cells;
             if (nb.w == MARK) nb.w = max_cells;
         }
-        OctGeomDev d;
+        OctGeomDev d = {};
         d.nsteps = h.nsteps;
-        d.info = 0;
         if (int rc = upload(h.cellA, d.cellA, st.geom_owned)) return rc;
         if (int rc = upload(h.cellB, d.cellB, st.geom_owned)) return rc;
         st.geom_bytes += 2 * h.cellA.size() * sizeof(uint4);
@@ -742,8 +738,15 @@ extern "C" int asora_debug_geometry_table(int table, uint32_t *words, size_t cap
     if (capacity_entries < n) return fail(3, "debug_geometry_table: buffer too small");
     ASORA_HIP_TRY(hipStreamSynchronize(st.stream));
     std::vector<uint4> a(n), b(n);
-    ASORA_HIP_TRY(hipMemcpy(a.data(), g.cellA, n * sizeof(uint4), hipMemcpyDeviceToHost));
-    ASORA_HIP_TRY(hipMemcpy(b.data(), g.cellB, n * sizeof(uint4), hipMemcpyDeviceToHost));
+    // (the steps a table reads through another one -- shared inner shells -- come from there)
+    const size_t inner = std::min(n, (size_t)(g.inner >> 8) * (size_t)st.geom_threads);
+    const OctGeomDev &first = st.geom_host[g.inner & 255];
+    if (inner) {
+        ASORA_HIP_TRY(hipMemcpy(a.data(), first.cellA, inner * sizeof(uint4), hipMemcpyDeviceToHost));
+        ASORA_HIP_TRY(hipMemcpy(b.data(), first.cellB, inner * sizeof(uint4), hipMemcpyDeviceToHost));
+    }
+    ASORA_HIP_TRY(hipMemcpy(a.data() + inner, g.cellA + inner, (n - inner) * sizeof(uint4), hipMemcpyDeviceToHost));
+    ASORA_HIP_TRY(hipMemcpy(b.data() + inner, g.cellB + inner, (n - inner) * sizeof(uint4), hipMemcpyDeviceToHost));
     for (size_t q = 0; q < n; ++q) {
         std::memcpy(words + 8 * q, &a[q], 16);
         std::memcpy(words + 8 * q + 4, &b[q], 16);

@@ -511,14 +511,20 @@ Layout lay_out(const int *count, const int *packed, int S, int threads, int boxs
 // for every shell up to m = the smallest extent in the family: the window does not bind there (shell_blocks: min(maxmag <= s, ext)).
 // A trace beyond the box on an even mesh is the case that matters: the window is [-N/2, N/2 - 1], every sign variant of a unit
 // gets a table of its own, and they differ in the LAST shell only (0.56 GB of tables for 12 units at 256^3, 1.3 GB for 96).
-// The kernel walks a table as one array; so the shared part is ONE physical allocation mapped at the start of every member's
-// virtual range, followed by the member's own pages (hipMemCreate / hipMemAddressReserve / hipMemMap; tools/micro/vmm_alias.hip
-// shows the aliasing works on this device, granularity 4 KiB).  No change to the kernel, no change to a table's content.
+// The family's first member holds the whole table; every other member holds only what follows shell m and tells the kernel to
+// read the steps before through the first member (OctGeomDev::inner -- a wave-uniform choice between two base pointers per
+// step).  A member's own pointers are shifted back by the shared entries, so that entry e of a table is cellA[e] whichever side
+// it lies on and nothing below (write kernels, on-sphere patches) needs to know.
+// (Mapping one physical allocation into every member's address range -- hipMemCreate / hipMemMap -- needs no kernel change, and was
+//  how this was first done; ranges reserved after earlier ones had been unmapped and freed read back OTHER allocations' contents on
+//  this software stack: tools/micro/vmm_many_small.hip, profiles/r05_vmm_many_small.txt.)
 struct Family { std::vector<int> members; int m = 0; size_t prefix_entries = 0; };
 
-static std::vector<Family> find_families(const std::vector<GeomTableSpec> &specs, const std::vector<Layout> &L, int threads, size_t gran)
+static std::vector<Family> find_families(const std::vector<GeomTableSpec> &specs, const std::vector<Layout> &L, int threads)
 {
     std::vector<Family> fams;
+    static const bool no_sharing = getenv("ASORA_GEOMETRY_NO_SHARING") != nullptr;        // (A/B of the memory figure; tests)
+    if (no_sharing) return fams;
     std::vector<char> taken(specs.size(), 0);
     auto min_ext = [](const GeomTableSpec &g) { int m = std::min(g.ext[0], std::min(g.ext[1], g.ext[2])); return g.merge_mask ? std::min(m, g.ext_neg) : m; };
     for (size_t t = 0; t < specs.size(); ++t) {
@@ -530,75 +536,44 @@ static std::vector<Family> find_families(const std::vector<GeomTableSpec> &specs
         if (f.members.size() < 2) continue;
         f.m = min_ext(specs[(size_t)f.members[0]]);
         for (int u : f.members) f.m = std::min(f.m, min_ext(specs[(size_t)u]));
-        // shared: the entries before shell m + 1 -- the same offset in every member's layout, a whole number of mapping granules
+        // shared: the entries before shell m + 1 -- the same offset in every member's layout, whole steps
         bool ok = f.m >= 1;
         for (int u : f.members) ok = ok && L[(size_t)u].S_built >= f.m;
         if (!ok) continue;
         auto prefix_of = [&](int u) { return L[(size_t)u].after[(size_t)f.m]; };
         f.prefix_entries = prefix_of(f.members[0]);
         for (int u : f.members) ok = ok && prefix_of(u) == f.prefix_entries;
-        if (!ok || f.prefix_entries == 0 || (f.prefix_entries * sizeof(uint4)) % gran != 0) continue;
+        if (!ok || f.prefix_entries == 0 || f.prefix_entries % (size_t)threads != 0 || f.prefix_entries / (size_t)threads >= (1u << 23)) continue;
         fams.push_back(f);
     }
     return fams;
 }
 
-// Allocate cellA / cellB of every table: families through mapped ranges (the first member writes the shared shells), everything else
-// with hipMalloc.  first_shell[t] = first shell table t writes itself.
+// Allocate cellA / cellB of every table.  first_shell[t] = first shell table t writes itself, fill_from[t] = its first own entry,
+// inner[t] = OctGeomDev::inner with the index of the family's first member among `specs`.
 static int allocate_tables(State &st, const std::vector<GeomTableSpec> &specs, const std::vector<Layout> &L, int threads,
-                           std::vector<uint4 *> &A, std::vector<uint4 *> &B, std::vector<int> &first_shell, std::vector<size_t> &fill_from)
+                           std::vector<uint4 *> &A, std::vector<uint4 *> &B, std::vector<int> &first_shell, std::vector<size_t> &fill_from,
+                           std::vector<int> &inner)
 {
     const size_t nt = specs.size();
-    A.assign(nt, nullptr); B.assign(nt, nullptr); first_shell.assign(nt, 1); fill_from.assign(nt, 0);
-    std::vector<char> done(nt, 0);
-    static const bool no_sharing = getenv("ASORA_GEOMETRY_NO_SHARING") != nullptr;        // (A/B of the memory figure; tests)
-    int vmm = 0;
-    (void)hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, st.device);
-    if (vmm && !no_sharing) {
-        hipMemAllocationProp prop = {};
-        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = st.device;
-        size_t gran = 0;
-        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) == hipSuccess && gran > 0) {
-            hipMemAccessDesc acc = {};
-            acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
-            auto round_up = [gran](size_t b) { return (b + gran - 1) / gran * gran; };
-            for (const Family &f : find_families(specs, L, threads, gran)) {
-                const size_t pre = f.prefix_entries * sizeof(uint4);
-                for (int arr = 0; arr < 2; ++arr) {
-                    hipMemGenericAllocationHandle_t hp;
-                    ASORA_HIP_TRY(hipMemCreate(&hp, pre, &prop, 0));
-                    st.geom_handles.push_back(hp);
-                    st.geom_bytes += pre;
-                    for (int u : f.members) {
-                        const size_t tail = round_up(L[(size_t)u].entries * sizeof(uint4) - pre);
-                        hipMemGenericAllocationHandle_t ht;
-                        ASORA_HIP_TRY(hipMemCreate(&ht, tail, &prop, 0));
-                        st.geom_handles.push_back(ht);
-                        st.geom_bytes += tail;
-                        void *va = nullptr;
-                        ASORA_HIP_TRY(hipMemAddressReserve(&va, pre + tail, 0, nullptr, 0));
-                        st.geom_mapped.push_back({va, pre + tail});
-                        ASORA_HIP_TRY(hipMemMap(va, pre, 0, hp, 0));
-                        ASORA_HIP_TRY(hipMemMap((char *)va + pre, tail, 0, ht, 0));
-                        ASORA_HIP_TRY(hipMemSetAccess(va, pre + tail, &acc, 1));
-                        (arr == 0 ? A : B)[(size_t)u] = static_cast<uint4 *>(va);
-                    }
-                }
-                for (size_t q = 0; q < f.members.size(); ++q) {
-                    const int u = f.members[q];
-                    done[(size_t)u] = 1;
-                    if (q > 0) { first_shell[(size_t)u] = f.m + 1; fill_from[(size_t)u] = f.prefix_entries; }
-                }
+    A.assign(nt, nullptr); B.assign(nt, nullptr); first_shell.assign(nt, 1); fill_from.assign(nt, 0); inner.assign(nt, 0);
+    if (nt <= 256)
+        for (const Family &f : find_families(specs, L, threads))
+            for (size_t q = 1; q < f.members.size(); ++q) {
+                const size_t u = (size_t)f.members[q];
+                first_shell[u] = f.m + 1;
+                fill_from[u] = f.prefix_entries;
+                inner[u] = (int)(f.prefix_entries / (size_t)threads) << 8 | f.members[0];
             }
-        }
-    }
     for (size_t t = 0; t < nt; ++t) {
-        if (done[t]) continue;
+        const size_t own = L[t].entries - fill_from[t];
         uint4 *a = nullptr, *b = nullptr;
-        ASORA_HIP_TRY(hipMalloc(&a, L[t].entries * sizeof(uint4))); st.geom_owned.push_back(a);
-        ASORA_HIP_TRY(hipMalloc(&b, L[t].entries * sizeof(uint4))); st.geom_owned.push_back(b);
-        st.geom_bytes += 2 * L[t].entries * sizeof(uint4);
-        A[t] = a; B[t] = b;
+        ASORA_HIP_TRY(hipMalloc(&a, own * sizeof(uint4))); st.geom_owned.push_back(a);
+        ASORA_HIP_TRY(hipMalloc(&b, own * sizeof(uint4))); st.geom_owned.push_back(b);
+        st.geom_bytes += 2 * own * sizeof(uint4);
+        // (entry e >= fill_from of the table is own[e - fill_from]; the shifted pointer is never dereferenced below fill_from)
+        A[t] = reinterpret_cast<uint4 *>(reinterpret_cast<uintptr_t>(a) - fill_from[t] * sizeof(uint4));
+        B[t] = reinterpret_cast<uint4 *>(reinterpret_cast<uintptr_t>(b) - fill_from[t] * sizeof(uint4));
     }
     return 0;
 }
@@ -613,7 +588,7 @@ int build_geometry_on_device(State &st, const std::vector<GeomTableSpec> &specs,
                              uint32_t &max_cells_all)
 {
     const int nt = (int)specs.size();
-    out.assign((size_t)nt, OctGeomDev{nullptr, nullptr, 0, 0});
+    out.assign((size_t)nt, OctGeomDev{nullptr, nullptr, 0, 0, 0, 0});
     step_after.assign((size_t)nt, std::vector<int>());
     BuildParams P;
     P.R2 = R * R; P.R2hi = P.R2 * (1.0 + 1e-9) + 1e-9; P.R2lo = P.R2 * (1.0 - 1e-9) - 1e-9; P.dr = dr;
@@ -719,7 +694,7 @@ int build_geometry_on_device(State &st, const std::vector<GeomTableSpec> &specs,
     std::vector<void *> temp_tables;
     struct FreeTemps { std::vector<void *> &v; ~FreeTemps() { for (void *q : v) (void)hipFree(q); } } free_temps{temp_tables};
     std::vector<uint4 *> tabA, tabB;
-    std::vector<int> first_shell((size_t)nf, 1);
+    std::vector<int> first_shell((size_t)nf, 1), inner((size_t)nf, 0);
     std::vector<size_t> fill_from((size_t)nf, 0);
     if (wedges) {           // the full sectors are temporaries
         tabA.assign((size_t)nf, nullptr); tabB.assign((size_t)nf, nullptr);
@@ -727,7 +702,7 @@ int build_geometry_on_device(State &st, const std::vector<GeomTableSpec> &specs,
             ASORA_HIP_TRY(hipMalloc(&tabA[(size_t)t], L[(size_t)t].entries * sizeof(uint4))); temp_tables.push_back(tabA[(size_t)t]);
             ASORA_HIP_TRY(hipMalloc(&tabB[(size_t)t], L[(size_t)t].entries * sizeof(uint4))); temp_tables.push_back(tabB[(size_t)t]);
         }
-    } else if (int rc = allocate_tables(st, full, L, threads, tabA, tabB, first_shell, fill_from)) return rc;
+    } else if (int rc = allocate_tables(st, full, L, threads, tabA, tabB, first_shell, fill_from, inner)) return rc;
     for (int t = 0; t < nf; ++t) {
         // padding everywhere first (a member of a family: behind the shells it shares, which the family's first member pads)
         const size_t n = L[(size_t)t].entries - fill_from[(size_t)t];
@@ -758,7 +733,7 @@ int build_geometry_on_device(State &st, const std::vector<GeomTableSpec> &specs,
     if (!wedges) {
         max_cells_all = max_cells_full;
         for (int t = 0; t < nt; ++t) {
-            out[(size_t)t] = OctGeomDev{jobs[(size_t)t].cellA, jobs[(size_t)t].cellB, L[(size_t)t].nsteps, 0};
+            out[(size_t)t] = OctGeomDev{jobs[(size_t)t].cellA, jobs[(size_t)t].cellB, L[(size_t)t].nsteps, 0, inner[(size_t)t], 0};
             step_after[(size_t)t] = L[(size_t)t].step_after_shell;
             final_A[(size_t)t] = jobs[(size_t)t].cellA;
         }
@@ -792,11 +767,9 @@ int build_geometry_on_device(State &st, const std::vector<GeomTableSpec> &specs,
         {   // Families of wedge tables (the octant variants of one sector and wedge under a clipped window): their full sectors
             // hold the same entries up to shell m, but what a wedge KEEPS of them follows from its outer shells, which differ.  Keep
             // the union of the members' needs there: the inner shells of all members then come out identical (and are shared below).
-            static const bool no_sharing = getenv("ASORA_GEOMETRY_NO_SHARING") != nullptr;
             std::vector<Layout> FL((size_t)nt);                   // the layout of each wedge table's FULL sector
             for (int t = 0; t < nt; ++t) FL[(size_t)t] = L[(size_t)full_of[(size_t)t]];
-            if (!no_sharing)
-                for (const Family &f : find_families(specs, FL, threads, 1)) {
+            for (const Family &f : find_families(specs, FL, threads)) {
                     const size_t n = f.prefix_entries;               // (entries of the full sectors before shell m + 1)
                     const unsigned blocks = (unsigned)std::min<size_t>(4096, (n + 255) / 256);
                     const size_t first = wj[(size_t)f.members[0]].keep_base;
@@ -823,9 +796,9 @@ int build_geometry_on_device(State &st, const std::vector<GeomTableSpec> &specs,
             max_cells_all = std::max(max_cells_all, WL[(size_t)t].max_cells);
         }
         std::vector<uint4 *> wA, wB;
-        std::vector<int> wfirst;
+        std::vector<int> wfirst, winner;
         std::vector<size_t> wfill;
-        if (int rc = allocate_tables(st, specs, WL, threads, wA, wB, wfirst, wfill)) return rc;
+        if (int rc = allocate_tables(st, specs, WL, threads, wA, wB, wfirst, wfill, winner)) return rc;
         for (int t = 0; t < nt; ++t) {
             const size_t n = WL[(size_t)t].entries - wfill[(size_t)t];
             uint4 *a = wA[(size_t)t] + wfill[(size_t)t], *b = wB[(size_t)t] + wfill[(size_t)t];
@@ -833,7 +806,7 @@ int build_geometry_on_device(State &st, const std::vector<GeomTableSpec> &specs,
             hipLaunchKernelGGL(fill_pad_kernel, dim3((unsigned)std::min<size_t>(1024, (n + 255) / 256)), dim3(256), 0, st.stream, b, n, max_cells_all);
             wj[(size_t)t].cellA = wA[(size_t)t]; wj[(size_t)t].cellB = wB[(size_t)t]; wj[(size_t)t].S_built = WL[(size_t)t].S_built;
             wj[(size_t)t].first_shell = wfirst[(size_t)t];
-            out[(size_t)t] = OctGeomDev{wA[(size_t)t], wB[(size_t)t], WL[(size_t)t].nsteps, 0};
+            out[(size_t)t] = OctGeomDev{wA[(size_t)t], wB[(size_t)t], WL[(size_t)t].nsteps, 0, winner[(size_t)t], 0};
             step_after[(size_t)t] = WL[(size_t)t].step_after_shell;
             final_A[(size_t)t] = wA[(size_t)t];
         }

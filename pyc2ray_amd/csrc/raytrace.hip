@@ -322,6 +322,12 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     const uint4 *__restrict__ cellA = p.geom[table].cellA;
     const uint4 *__restrict__ cellB = p.geom[table].cellB;
     const int nsteps = p.geom[table].nsteps;
+    // Tables that share their inner shells (clipped windows, geometry_device.hip): the steps before `inner_steps` are read through
+    // the family's first table.  The step index is wave-uniform: a scalar compare and two scalar selects per table load.
+    const int inner_info = p.geom[table].inner;
+    const int inner_steps = inner_info >> 8;
+    const uint4 *__restrict__ innerA = p.geom[inner_info & 255].cellA;
+    const uint4 *__restrict__ innerB = p.geom[inner_info & 255].cellB;
     const int sa = (uinfo & 1) ? -1 : 1, sb = (uinfo & 2) ? -1 : 1, sc = (uinfo & 4) ? -1 : 1;
 
     // LDS: the small tables sit first, at compile-time offsets (TABCAP entries each), then the shell buffers
@@ -502,14 +508,14 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
 
     // `first_c`: std::true_type for the steps of a unit's first triple -- the only ones that can hold shell 1, whose cells next to
     // the source get the diagonal factors of raytracing.cu:431-441; every other step is compiled without that block.
-    auto step = [&](auto first_c, unsigned e_pf, const uint4 &cur_A, const uint4 &cur_B, const double (&cur_nhi)[NSRC], const unsigned (&cur_idx)[NSRC],
+    auto step = [&](auto first_c, int k_pf, unsigned e_pf, const uint4 &cur_A, const uint4 &cur_B, const double (&cur_nhi)[NSRC], const unsigned (&cur_idx)[NSRC],
                     const uint4 &nxt_A, double (&nxt_nhi)[NSRC], unsigned (&nxt_idx)[NSRC], uint4 &pf_A, uint4 &pf_B) {
         constexpr bool FIRST_TRIPLE = decltype(first_c)::value;
 #if ASORA_STEP_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);      // nothing of this step is scheduled into the previous one (see the macro)
 #endif
-        pf_A = cellA[e_pf];                      // two steps ahead
-        pf_B = cellB[e_pf];
+        pf_A = (k_pf < inner_steps ? innerA : cellA)[e_pf];                      // two steps ahead (step k_pf)
+        pf_B = (k_pf < inner_steps ? innerB : cellB)[e_pf];
 #ifdef ASORA_DIAG_EXTRA_TABLE_LOAD      // diagnostic build only: 16 more bytes per lane and step from ANOTHER unit's table (equal sizes: octants)
         {
             const uint4 extra = p.geom[(unit + 1) % p.units].cellA[e_pf];
@@ -807,8 +813,8 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     // SUBBOX: the steps of this launch's sub-box only (whole triples: the tables are padded at every box boundary)
     const int k_first = SUBBOX ? p.sb_k0[unit] : 0, k_last = SUBBOX ? p.sb_k1[unit] : nsteps;
     unsigned e = (unsigned)k_first * RT_THREADS + threadIdx.x;
-    uint4 A0 = cellA[e], B0 = cellB[e];
-    uint4 A1 = cellA[e + RT_THREADS], B1 = cellB[e + RT_THREADS];
+    uint4 A0 = (k_first < inner_steps ? innerA : cellA)[e], B0 = (k_first < inner_steps ? innerB : cellB)[e];
+    uint4 A1 = (k_first + 1 < inner_steps ? innerA : cellA)[e + RT_THREADS], B1 = (k_first + 1 < inner_steps ? innerB : cellB)[e + RT_THREADS];
     uint4 A2, B2;
     unsigned idx0[NSRC], idx1[NSRC], idx2[NSRC];
     double nhi0[NSRC], nhi1[NSRC], nhi2[NSRC];
@@ -849,15 +855,15 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     // Shell 1 (at most 26 cells) is step 0 of a unit's table: the first triple is peeled off with the shell-1 block in it.
     int k = k_first;
     if (k == 0 && k < k_last) {
-        step(std::true_type{}, e + 2 * RT_THREADS, A0, B0, nhi0, idx0, A1, nhi1, idx1, A2, B2);
-        step(std::true_type{}, e + 3 * RT_THREADS, A1, B1, nhi1, idx1, A2, nhi2, idx2, A0, B0);
-        step(std::true_type{}, e + 4 * RT_THREADS, A2, B2, nhi2, idx2, A0, nhi0, idx0, A1, B1);
+        step(std::true_type{}, k + 2, e + 2 * RT_THREADS, A0, B0, nhi0, idx0, A1, nhi1, idx1, A2, B2);
+        step(std::true_type{}, k + 3, e + 3 * RT_THREADS, A1, B1, nhi1, idx1, A2, nhi2, idx2, A0, B0);
+        step(std::true_type{}, k + 4, e + 4 * RT_THREADS, A2, B2, nhi2, idx2, A0, nhi0, idx0, A1, B1);
         k += 3; e += 3 * RT_THREADS;
     }
     for (; k < k_last; k += 3, e += 3 * RT_THREADS) {
-        step(std::false_type{}, e + 2 * RT_THREADS, A0, B0, nhi0, idx0, A1, nhi1, idx1, A2, B2);
-        step(std::false_type{}, e + 3 * RT_THREADS, A1, B1, nhi1, idx1, A2, nhi2, idx2, A0, B0);
-        step(std::false_type{}, e + 4 * RT_THREADS, A2, B2, nhi2, idx2, A0, nhi0, idx0, A1, B1);
+        step(std::false_type{}, k + 2, e + 2 * RT_THREADS, A0, B0, nhi0, idx0, A1, nhi1, idx1, A2, B2);
+        step(std::false_type{}, k + 3, e + 3 * RT_THREADS, A1, B1, nhi1, idx1, A2, nhi2, idx2, A0, B0);
+        step(std::false_type{}, k + 4, e + 4 * RT_THREADS, A2, B2, nhi2, idx2, A0, nhi0, idx0, A1, B1);
     }
 #pragma unroll
     for (int q = 0; q < NSRC; ++q) {

@@ -152,8 +152,8 @@ def test_cells_on_the_sphere_follow_dr_with_both_builders(asora):
 @pytest.mark.parametrize("ns,limit_MB", [(1000, 30.0), (1, 60.0)])
 def test_whole_box_tables_share_their_inner_shells(asora, ns, limit_MB):
     """A trace beyond the box on an even mesh: the periodic window is [-N/2, N/2 - 1], every sign variant of a unit needs a table of
-    its own, and they differ in the last shell only.  The variants' tables share the memory of everything before it (one physical
-    allocation mapped into each table's address range, geometry_device.hip): at 128^3 the twelve sector-pair tables of a many-source
+    its own, and they differ in the last shell only.  The variants' tables share the memory of everything before it (the first
+    one holds it, the kernel reads the others' inner steps through it; geometry_device.hip): at 128^3 the twelve sector-pair tables of a many-source
     trace take 21 MB instead of 70, the 96 quarter-sector tables of a single source 52 MB instead of 160 -- with the contents (checked
     bit for bit against the host builder above) and the results (here: against the oracle) unchanged."""
     from oracle import oracle as O
