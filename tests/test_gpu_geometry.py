@@ -78,6 +78,9 @@ SHAPES = [
     (64, 400, 17.0, {"OPT_SECTORS": 2, "OPT_BLOCK_THREADS": 64}), (64, 400, 17.0, {"OPT_SECTORS": 7, "OPT_BLOCK_THREADS": 512}),
     (64, 400, 26.0, {"OPT_SECTORS": 3, "OPT_BLOCK_THREADS": 1024}), (64, 3, 30.0, {"OPT_SECTORS": 4, "OPT_BLOCK_THREADS": 256}),
     (32, 50, 0.5, {}), (32, 50, 1.0, {}), (32, 50, 1.8, {}),
+    # a sphere that touches the window of a tiny mesh (r = N/2): families of small tables that share their inner shells, one after the
+    # other in one process -- every forced shape, aligned ones among them
+    *[(16, 1, 8.0, {"OPT_SECTORS": m, "OPT_BLOCK_THREADS": 256}) for m in (1, 2, 3, 4, 6, 9)],
 ]
 
 
