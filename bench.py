@@ -433,8 +433,8 @@ def self_launch(gpus, argv, timeout_s):
     `python -m torch.distributed.run --standalone --nnodes=1 --nproc-per-node N bench.py <same arguments>` as a CHILD process --
     before this process has imported anything that touches the GPU, and never by replacing this process --, pass rank 0's
     single JSON line through to stdout, and exit with the child's return code.  A child that fails or prints no JSON line
-    gives a non-zero exit with the tail of its stderr; a child that outlives `timeout_s` is killed (its whole process
-    group) and the exit code is 124.  (pyc2ray's own multi-rank test needs an external mpirun,
+    gives a non-zero exit with the tail of its stderr; a child that outlives `timeout_s` is killed with its ranks
+    (each of which is a session of its own) and the exit code is 124; so are they when this process is told to end.  (pyc2ray's own multi-rank test needs an external mpirun,
     test/unit_tests_hackathon/4_multiple_sources_mpi/run_test.py:30-34; this one does not.)"""
     import signal
     import socket
@@ -453,6 +453,47 @@ def self_launch(gpus, argv, timeout_s):
                              start_new_session=True)
     tail, lines = [], []
 
+    def descendants(pid):
+        """pids of the processes below `pid` (torch.distributed.run puts every rank into a session of its own: a signal to
+        the launcher's process group does not reach them, and once the launcher is gone they cannot be found through it)."""
+        found, frontier = [], [pid]
+        while frontier:
+            parent = frontier.pop()
+            try:
+                with open(f"/proc/{parent}/task/{parent}/children") as f:
+                    kids = [int(k) for k in f.read().split()]
+            except (OSError, ValueError):
+                kids = []
+            found += kids
+            frontier += kids
+        return found
+
+    def kill_ranks():
+        ranks = descendants(child.pid)
+        try:
+            os.killpg(child.pid, signal.SIGTERM)          # the elastic agent ends its workers when asked to
+        except OSError:
+            pass
+        try:
+            child.wait(timeout=5)
+        except subprocess.TimeoutExpired:
+            pass
+        for pid in ranks + descendants(child.pid):
+            try:
+                os.kill(pid, signal.SIGKILL)
+            except OSError:
+                pass
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except OSError:
+            pass
+
+    def forward(signum, _frame):        # whoever started THIS process gives up: the ranks must not outlive it
+        kill_ranks()
+        os._exit(128 + signum)
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, forward)
+
     def pump_err():
         for line in child.stderr:
             sys.stderr.write(line)
@@ -469,10 +510,7 @@ def self_launch(gpus, argv, timeout_s):
     try:
         rc = child.wait(timeout=timeout_s)
     except subprocess.TimeoutExpired:
-        try:
-            os.killpg(child.pid, signal.SIGKILL)
-        except OSError:
-            pass
+        kill_ranks()
         child.wait()
         print(f"bench: the {gpus}-rank child did not finish within {timeout_s:g} s and was killed", file=sys.stderr, flush=True)
         return 124

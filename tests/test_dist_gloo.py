@@ -136,6 +136,49 @@ def test_bench_self_launch_kills_a_child_that_hangs():
     r = _bench(["--gpus", "2", "--launch-check", "--launch-timeout", "8"], PYC2RAY_AMD_BENCH_TEST_HANG="1")
     assert r.returncode == 124, (r.returncode, r.stderr[-2000:])
     assert r.stdout.strip() == ""
+    assert _rank_processes("--launch-timeout 8") == []
+
+
+def _rank_processes(marker):
+    found = []
+    for pid in (d for d in os.listdir("/proc") if d.isdigit()):
+        try:
+            with open(f"/proc/{pid}/cmdline", "rb") as f:
+                args = f.read().replace(b"\0", b" ").decode(errors="replace")
+        except OSError:
+            continue
+        if marker in args and "bench.py" in args and int(pid) != os.getpid():
+            found.append(int(pid))
+    return found
+
+
+def test_bench_self_launch_takes_its_ranks_along_when_it_is_terminated():
+    """Whoever started the self-launching bench.py gives up (SIGTERM, as a driver's timeout sends): the ranks -- each a session of
+    its own under torch.distributed.run, out of reach of a signal to the launcher's group -- are ended with it instead of being
+    left on the GPUs.  The same holds for --launch-timeout (the test above): no rank is left behind either way."""
+    import signal
+    import time
+    marker = "--launch-timeout 201"          # (recognises this test's processes among everything else that runs)
+    e = dict(os.environ, PYC2RAY_AMD_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1", PYC2RAY_AMD_BENCH_TEST_HANG="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    p = subprocess.Popen([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--launch-check"] + marker.split(),
+                         env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        deadline = time.time() + 90
+        while time.time() < deadline and len(_rank_processes(marker)) < 4:        # this process, the launcher, two ranks
+            time.sleep(0.5)
+        assert len(_rank_processes(marker)) >= 4, "the ranks never started"
+        time.sleep(2.0)
+        p.send_signal(signal.SIGTERM)
+        assert p.wait(timeout=40) == 128 + signal.SIGTERM
+        time.sleep(1.0)
+        assert _rank_processes(marker) == []
+    finally:
+        if p.poll() is None:
+            p.kill()
+        for pid in _rank_processes(marker):
+            os.kill(pid, signal.SIGKILL)
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
