@@ -862,7 +862,9 @@ def main():
                 print(f"bench: one-GPU reference run failed: {type(e).__name__}: {e}", file=sys.stderr)
         comm.Barrier()
     lib.source_data_to_device(p0, f0, n_local)
-    state = {"slab": slab, "unpolled": 0, "rows": [], "host_enqueue_s": 0.0, "host_enqueued": 0}
+    # "loop": the multi-rank step runs on the device-resident loop -- slab exchange, or the full-grid all-reduce when it is not pipelined
+    state = {"slab": slab, "loop": comm is not None and (slab or (not overlap and getattr(comm, "device_loop", False))), "unpolled": 0, "rows": [], "host_enqueue_s": 0.0,
+             "host_enqueued": 0}
 
     def begin_time_step():
         # conv_criterion = -1 and convergence_fraction = 0 can never be met: every enqueued iteration does its work
@@ -871,6 +873,9 @@ def main():
         elif state["slab"]:
             poll_slab()
             comm.slab_begin(lib, plan, N, args.R, SIG, dr, n_local, MINLOGTAU, dlog, numtau, chem, -1.0, 0.0)
+        elif state["loop"]:
+            poll_slab()
+            comm.reduce_begin(lib, N, args.R, SIG, dr, n_local, MINLOGTAU, dlog, numtau, chem, -1.0, 0.0)
         else:
             lib.grid_copy(_capi.GRID_XH_AV, _capi.GRID_XH)              # evolve.py:136-137
             lib.grid_copy(_capi.GRID_XH_INTERMED, _capi.GRID_XH)
@@ -884,7 +889,7 @@ def main():
                 state["rows"] = r_
 
     def step():
-        if state["slab"]:              # what evolve3D_MPI does per outer iteration with a TorchComm: the sharded device loop
+        if state["loop"]:              # what evolve3D_MPI does per outer iteration with a TorchComm: the device loop over the ranks
             t_ = time.perf_counter()
             comm.slab_enqueue(lib, 1)
             state["host_enqueue_s"] += time.perf_counter() - t_       # host time to ISSUE an iteration (nothing in it waits for the GPU)
@@ -900,7 +905,7 @@ def main():
         return None
 
     def fence():
-        if comm is not None and state["slab"]:
+        if comm is not None and state["loop"]:
             poll_slab()                # a region ends with the poll of its last batch, as on one GPU
         lib.synchronize()
         if comm is not None:
@@ -921,6 +926,7 @@ def main():
             ok = False
         if not all_ranks_ok(ok):
             state["slab"] = False
+            state["unpolled"] = 0
             slab = False
             comm.exchange = "allreduce"
             fell_back = "first slab step"
@@ -972,11 +978,12 @@ def main():
 
     gamma_cells, eval_cells = lib.last_raytrace_counts()
     zero_cells = lib.last_raytrace_zero_rates()
-    if slab:
-        # the counters of the sharded device loop run on from slab_begin, like the one-GPU loop's
+    if comm is not None and state["loop"]:
+        # the counters of the device loop over the ranks run on from its begin, like the one-GPU loop's
         n_done, _, _ = comm.slab_poll(lib, 0)
         n_done = max(n_done, 1)
         gamma_cells, eval_cells, zero_cells = gamma_cells // n_done, eval_cells // n_done, zero_cells // n_done
+    if slab:
         comm.slab_gather(lib, plan, _capi.GRID_XH_INTERMED, N)
         comm.slab_gather(lib, plan, _capi.GRID_PHI_ION, N)
     if comm is None:
@@ -1045,7 +1052,7 @@ def main():
     ch_launch_s = (ch_ms / max(ch_n, 1)) * 1e-3
     chem_cells = N ** 3 if (comm is None or not slab) else (plan.own[0][1] - plan.own[0][0]) * N * N
     ch_achieved = CHEM_BYTES_PER_UPDATE * chem_cells / ch_launch_s / 1e9 if ch_n else None
-    fused_pass = comm is None or slab           # (the sharded device loop runs the same fused pass on the own planes)
+    fused_pass = comm is None or state["loop"]   # (the device loop over the ranks runs the same fused pass: on the own planes, or -- behind the all-reduce -- on all)
     ch_actual = (CHEM_FUSED_BYTES_PER_UPDATE if fused_pass else CHEM_BYTES_PER_UPDATE) * chem_cells / ch_launch_s / 1e9 if ch_n else None
     comm_bytes = None
     if slab:
@@ -1084,7 +1091,8 @@ def main():
                             f"sources sharded over {world} ranks by slab of the first coordinate; rates sent plane-wise to the "
                             f"owners of the planes (trace in {plan.common_chunks(comm.slab_chunks)} chunks, final planes sent while the next "
                             "chunk is traced), slab chemistry, xh_av sent back (pyc2ray_amd/dist.py SlabPlan)" if slab else
-                            f"sources x{world}, rate-grid all-reduce " + ("pipelined with the trace" if overlap else "after the trace")
+                            f"sources x{world}, rate-grid all-reduce " + ("pipelined with the trace" if overlap else
+                                                                        "after the trace, on the device-resident loop" if state["loop"] else "after the trace")
                             + ", chemistry on every rank"),
             "comm_bytes_per_rank_per_step": comm_bytes,
             "exchange_requested": args.exchange if world > 1 else None,
@@ -1106,7 +1114,9 @@ def main():
                                 "iteration's rate accumulators into phi_ion)" % poll_every) if comm is None else
                                "one outer iteration of evolve3D_MPI through the calls it makes (TorchComm.slab_enqueue -- the sharded "
                                "device loop: trace, rates to the owners, ONE fused pass on the own planes, xh_av back, convergence test "
-                               "on the device -- with one slab_poll per %d steps inside the timed region; or raytrace_and_allreduce): "
+                               "on the device; or, with --exchange allreduce, trace, fold, in-place all-reduce of the rate grid, ONE fused "
+                               "pass on the whole grid on every rank, test on the device -- with one slab_poll per %d steps inside the "
+                               "timed region; with --overlap 1 the pipelined raytrace_and_allreduce): "
                                "see phases_ms" % poll_every,
         },
         "roofline": {

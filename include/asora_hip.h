@@ -257,8 +257,17 @@ int asora_evolve_begin_slab(double dt, double bh00, double albpow, double colh0,
                             int own_begin, int own_count);
 int asora_evolve_slab_trace(int src_begin, int src_count);
 int asora_evolve_slab_fold_out(int i_begin, int i_count);
+/* The full-grid exchange of the reference (pyc2ray/evolve.py:433-437: MPI Allreduce of the rate grid, chemistry on identical data)
+ * on the same loop, for a step begun with own_begin = 0, own_count = N on every rank: asora_evolve_slab_fold_all sums the two
+ * accumulator layouts of ALL planes into the out-box; the caller all-reduces the out-box over the ranks IN PLACE (ordered on
+ * asora_stream()); asora_evolve_slab_pass then takes the rates from the out-box, keeps them in ASORA_GRID_PHI_ION, and its three
+ * sums are those of the whole grid already: asora_evolve_slab_close(NULL) without a reduction.  One iteration:
+ * trace, fold_all, [all-reduce], pass, close; asora_evolve_poll then has nothing left to fold.  asora_evolve_slab_outbox_from_host: the out-box planes written from the host (for
+ * transports that sum on the host). */
+int asora_evolve_slab_fold_all(void);
 void *asora_evolve_slab_outbox(void);
 int asora_evolve_slab_outbox_to_host(int i_begin, int i_count, double *host);
+int asora_evolve_slab_outbox_from_host(int i_begin, int i_count, const double *host);
 int asora_evolve_slab_add(int i_begin, int i_count, const double *dev_planes);
 int asora_evolve_slab_add_host(int i_begin, int i_count, const double *host_planes);
 int asora_evolve_slab_pass(void);

@@ -1395,6 +1395,7 @@ static int evolve_begin_impl(double dt, double bh00, double albpow, double colh0
     st.ev_reported = 0;
     st.ev_enqueued = 0;
     st.ev_slab = slab; st.ev_own_begin = own_begin; st.ev_own_count = own_count; st.ev_slab_passed = false;
+    st.ev_rates_in_outbox = false; st.ev_folded_all = false;
     st.ev_open = true;
     return 0;
 }
@@ -1474,7 +1475,39 @@ int asora_evolve_slab_fold_out(int i_begin, int i_count)
     return launch_fold_out(st, cur, cur + st.ncell, st.staging, nxt, nxt + st.ncell, i_begin, i_count, &st.ev_status->done);
 }
 
+// The full-grid exchange (pyc2ray/evolve.py:433-437: every rank all-reduces the rate grid) on the same loop: ALL planes folded
+// into the out-box, which the caller then sums over the ranks in place; the pass reads the out-box (one layout, nothing left to
+// fold) and keeps the summed rates in PHI_ION itself.  (An all-reduce is not gated by `done`: iterations enqueued beyond convergence
+// sum the stale out-box once more.  The pass is gated, so PHI_ION keeps what the last iteration carried out has read.)
+int asora_evolve_slab_fold_all(void)
+{
+    clear_error();
+    if (int rc = require_slab("evolve_slab_fold_all")) return rc;
+    State &st = g_state;
+    if (st.ev_slab_passed) return fail(4, "evolve_slab_fold_all: the iteration's pass has been enqueued already");
+    if (st.ev_own_begin != 0 || st.ev_own_count != st.N)
+        return fail(4, "evolve_slab_fold_all: the step must own every plane (asora_evolve_begin_slab(..., 0, N)): the chemistry is replicated");
+    st.ev_sets_known = false;
+    st.ev_rates_in_outbox = true; st.ev_folded_all = true;
+    double *cur = slab_pair(0), *nxt = slab_pair(1);
+    // (the pass zeroes the other pair's [i][j][k] layout as it goes; the transposed layout is zeroed here)
+    return launch_fold_out(st, cur, cur + st.ncell, st.staging, nullptr, nxt + st.ncell, 0, st.N, &st.ev_status->done);
+}
+
 void *asora_evolve_slab_outbox(void) { return g_state.init ? (void *)g_state.staging : nullptr; }
+
+int asora_evolve_slab_outbox_from_host(int i_begin, int i_count, const double *host)
+{
+    clear_error();
+    if (int rc = require_init("evolve_slab_outbox_from_host")) return rc;
+    State &st = g_state;
+    if (i_begin < 0 || i_count < 0 || i_begin + i_count > st.N || (i_count > 0 && !host)) return fail(3, "evolve_slab_outbox_from_host: bad arguments");
+    if (i_count == 0) return 0;
+    const size_t plane = (size_t)st.N * st.N;
+    ASORA_HIP_TRY(hipMemcpyAsync(st.staging + (size_t)i_begin * plane, host, (size_t)i_count * plane * sizeof(double), hipMemcpyHostToDevice, st.stream));
+    ASORA_HIP_TRY(hipStreamSynchronize(st.stream));              // (the host buffer may be pageable)
+    return 0;
+}
 
 int asora_evolve_slab_outbox_to_host(int i_begin, int i_count, double *host)
 {
@@ -1524,6 +1557,8 @@ int asora_evolve_slab_pass(void)
     if (int rc = require_slab("evolve_slab_pass")) return rc;
     State &st = g_state;
     if (st.ev_slab_passed) return fail(4, "evolve_slab_pass: already enqueued for this iteration");
+    if (st.ev_rates_in_outbox && !st.ev_folded_all)
+        return fail(4, "evolve_slab_pass: this step exchanges whole grids (asora_evolve_slab_fold_all), and this iteration's fold has not been enqueued");
     st.ev_sets_known = false;
     st.ev_slab_passed = true;
     st.grid_valid[ASORA_GRID_XH_AV] = st.grid_valid[ASORA_GRID_XH_INTERMED] = true;
@@ -1540,13 +1575,14 @@ int asora_evolve_slab_pass(void)
     c.ndens = st.grid[ASORA_GRID_NDENS]; c.temp = st.grid[ASORA_GRID_TEMP]; c.xh = st.grid[ASORA_GRID_XH];
     c.xh_av_in = st.ev_first ? st.grid[ASORA_GRID_XH] : st.grid[ASORA_GRID_XH_AV];
     c.gamma = cur; c.gamma_t = cur + st.ncell; c.phi_out = nullptr;
+    if (st.ev_rates_in_outbox) { c.gamma = st.staging; c.gamma_t = nullptr; c.phi_out = st.grid[ASORA_GRID_PHI_ION]; }
     c.zero_a = nxt; c.zero_t = nxt + st.ncell;
     c.xh_av = st.grid[ASORA_GRID_XH_AV]; c.xh_intermed = st.grid[ASORA_GRID_XH_INTERMED];
     c.nhi = st.nhi; c.nhi_t = st.nhi_t;
     if (int rc = ensure_red_capacity(3 * chemistry_tile_blocks(st, st.N, st.ev_own_count))) return rc;    // (sized for every range at init)
     c.red_partial = st.red_partial; c.red_final = st.red_final;
     c.status = st.ev_status; c.local_sums = true;
-    c.fold = true; c.emit = true;
+    c.fold = !st.ev_rates_in_outbox; c.emit = true;
     set_uniform_temperature(c);
     return launch_chemistry_tiles(st, c, st.stream);
 }
@@ -1573,7 +1609,7 @@ int asora_evolve_slab_close(const double *host_sums)
     }
     if (int rc = launch_convergence_test(st, st.red_final, st.ev_status)) return rc;
     st.ev_first = false;
-    st.ev_slab_passed = false;
+    st.ev_slab_passed = false; st.ev_folded_all = false;
     st.ev_enqueued += 1;
     return 0;
 }
@@ -1642,6 +1678,7 @@ int asora_evolve_poll(int *niter, int *converged, double *history, int history_r
     // of that iteration zeroed it; iterations enqueued beyond convergence did nothing).  Fold them into PHI_ION now.
     if (h.niter > 0) {
         const int set = (st.ev_base + h.niter - 1) & 1;
+        if (st.ev_slab && st.ev_rates_in_outbox) st.ev_folded_iter = h.niter;      // (the pass has kept the summed rates in PHI_ION)
         if (st.ev_folded_iter != h.niter) {
             const double *a = st.acc + (size_t)set * 2 * st.ncell;
             if (int rc = launch_fold_sum(st, a, a + st.ncell, st.grid[ASORA_GRID_PHI_ION])) return rc;

@@ -240,6 +240,8 @@ struct State {
     bool ev_slab = false;
     int ev_own_begin = 0, ev_own_count = 0;
     bool ev_slab_passed = false;            // the current iteration's pass has been enqueued (close comes next)
+    bool ev_folded_all = false;             // ... and this iteration's has been enqueued
+    bool ev_rates_in_outbox = false;        // asora_evolve_slab_fold_all: the passes of this step read the out-box and keep PHI_ION
     // Which 64-byte lines of the rate accumulators the sources of the current step can touch at all (round 4): one byte per
     // line of 8 cells, [i][j][k >> 3] for the plain layout and, behind it, [k][j][i >> 3] for the transposed one.  The fused
     // pass neither reads nor zeroes the lines no source reaches (they are zero and stay zero): 32 of its 88 bytes per cell.

@@ -240,7 +240,8 @@ __global__ void __launch_bounds__(CH_THREADS, ASORA_CHEM_MIN_WAVES) chemistry_ti
                 const size_t idx = ((size_t)i * N + j) * N + k;
                 const bool reached = !FOLD || !p.reach_a || p.reach_a[((size_t)i * N + j) * NL + (k >> 3)] != 0;
                 double g = reached ? p.gamma[idx] : 0.0;
-                if (FOLD) { g += tile_g[tx][r]; if (p.phi_out) p.phi_out[idx] = g; }
+                if (FOLD) g += tile_g[tx][r];
+                if (p.phi_out) p.phi_out[idx] = g;            // (the summed rates, where someone keeps them: all-reduce loop)
                 if (EMIT && reached) p.zero_a[idx] = 0.0;
                 const double n = p.ndens[idx];
                 double xav = p.xh_av_in[idx], xint;
@@ -451,6 +452,9 @@ int launch_chemistry_tiles(State &st, ChemTileParams &p, hipStream_t stream)
         } else if (!p.fold && !p.emit) {
             if (u) hipLaunchKernelGGL((chemistry_tile_kernel<false, false, true>), grid, dim3(CH_THREADS), 0, stream, q);
             else   hipLaunchKernelGGL((chemistry_tile_kernel<false, false, false>), grid, dim3(CH_THREADS), 0, stream, q);
+        } else if (!p.fold && p.emit) {       // rates already summed over both layouts (and over the ranks): asora_evolve_slab_fold_all
+            if (u) hipLaunchKernelGGL((chemistry_tile_kernel<false, true, true>), grid, dim3(CH_THREADS), 0, stream, q);
+            else   hipLaunchKernelGGL((chemistry_tile_kernel<false, true, false>), grid, dim3(CH_THREADS), 0, stream, q);
         } else return fail(11, "chemistry: unsupported fold/emit combination (internal error)");
         ASORA_HIP_TRY(hipGetLastError());
     }

@@ -167,12 +167,12 @@ __global__ void __launch_bounds__(256) fold_out_kernel(const double *__restrict_
     const int kb = blockIdx.z * 32, ib = i_begin + blockIdx.x * 32;       // a_t tile: rows k, columns i
     for (int r = threadIdx.y; r < 32; r += 8) {
         const int k = kb + r, i = ib + threadIdx.x;
-        if (k < N && i < i_end) { const size_t o = ((size_t)k * N + j) * N + i; tile[r][threadIdx.x] = a_t[o]; z_t[o] = 0.0; }
+        if (k < N && i < i_end) { const size_t o = ((size_t)k * N + j) * N + i; tile[r][threadIdx.x] = a_t[o]; if (z_t) z_t[o] = 0.0; }
     }
     __syncthreads();
     for (int r = threadIdx.y; r < 32; r += 8) {
         const int i = ib + r, k = kb + threadIdx.x;
-        if (i < i_end && k < N) { const size_t o = ((size_t)i * N + j) * N + k; out[o] = a[o] + tile[threadIdx.x][r]; z_a[o] = 0.0; }
+        if (i < i_end && k < N) { const size_t o = ((size_t)i * N + j) * N + k; out[o] = a[o] + tile[threadIdx.x][r]; if (z_a) z_a[o] = 0.0; }
     }
 }
 

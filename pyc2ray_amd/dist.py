@@ -304,6 +304,9 @@ class TorchComm:
         #: how the per-rank rate grids are summed: "slab" (SlabPlan: planes to their owners, slab chemistry, xh_av
         #: back) or "allreduce" (full-grid all-reduce, chemistry replicated on every rank)
         self.exchange = os.environ.get("PYC2RAY_AMD_EXCHANGE", "slab")
+        #: "allreduce" without `overlap`: True = on the device-resident loop (``reduce_begin``: batches of iterations per host round
+        #: trip, as the slab exchange and the one-GPU loop); False = three calls and a host read-back per iteration
+        self.device_loop = os.environ.get("PYC2RAY_AMD_REDUCE_LOOP", "1") != "0"
         #: slab exchange: trace chunks per iteration; planes that are final after a chunk travel while the next is traced
         # (measured per-rank compute + modelled links, tools/slab_compute_model.py, profiles/r03_slab_model_chunks.txt: splitting
         #  the trace costs more than the early sends hide from four ranks on -- 125 sources per launch no longer fill the chip
@@ -415,8 +418,8 @@ class TorchComm:
     def phase_report(self, reduce_max=True):
         """Mean milliseconds per iteration of every phase booked since ``phase_reset`` -- the MAXIMUM over the ranks when
         `reduce_max` (a collective: every rank must call it), plus "iterations".  Phase names: slab exchange --
-        trace_fold_post, wait_rates_add, slab_pass, xh_av_exchange_nhi, scalar_allreduce_test; all-reduce path -- trace,
-        rate_allreduce, chemistry."""
+        trace_fold_post, wait_rates_add, slab_pass, xh_av_exchange_nhi, scalar_allreduce_test; all-reduce loop -- trace_fold,
+        rate_allreduce, pass_test; pipelined all-reduce (raytrace_and_allreduce) -- trace, rate_allreduce, chemistry."""
         import torch
         self._phase_resolve()
         names = sorted(self._phase_ms)
@@ -610,6 +613,41 @@ class TorchComm:
                                    convergence_fraction, a, b - a)
         self._slab = (plan, int(N), int(num_src_local))
 
+    def reduce_begin(self, libasora, N, R, sig, dr, num_src_local, minlogtau, dlogtau, NumTau, chemistry, conv_criterion,
+                     convergence_fraction):
+        """Start a time step of the same device-resident loop with the reference's exchange (pyc2ray/evolve.py:433-437): every
+        rank traces its sources, the rate grid is all-reduced, every rank runs the chemistry of the WHOLE grid on identical
+        rates (and so takes the same decisions without exchanging anything else).  ``slab_enqueue`` / ``slab_poll`` drive it."""
+        libasora.evolve_begin_slab(*chemistry, R, sig, dr, minlogtau, dlogtau, NumTau, 0, num_src_local, conv_criterion,
+                                   convergence_fraction, 0, N)
+        self._slab = (None, int(N), int(num_src_local))
+
+    def _reduce_one(self, libasora):
+        """One iteration of the loop begun with ``reduce_begin``: trace -> both accumulator layouts of all planes folded into
+        the out-box -> the out-box summed over the ranks in place -> the fused pass on the whole grid reading the out-box (it
+        keeps the summed rates in PHI_ION) -> convergence test on the pass's own sums.  With RCCL the all-reduce is ordered on
+        the library's stream and nothing waits on the host; with gloo the out-box goes through the host."""
+        import torch
+        _, N, num_src_local = self._slab
+        ph = _Phases(self, libasora) if self.phase_timing else None
+        libasora.evolve_slab_trace(0, num_src_local)
+        libasora.evolve_slab_fold_all()
+        if ph: ph.mark("trace_fold")
+        if self.Get_size() > 1 or os.environ.get("PYC2RAY_AMD_FORCE_COLLECTIVE", "0") == "1":
+            if self._backend() == "nccl":
+                with torch.cuda.stream(self._library_stream(libasora)):
+                    self._dist.all_reduce(self._outbox_view(libasora, N), op=self._dist.ReduceOp.SUM, group=self._group)
+            else:
+                host = libasora.evolve_slab_outbox_to_host(0, N, N)
+                self._dist.all_reduce(torch.from_numpy(host), op=self._dist.ReduceOp.SUM, group=self._group)
+                libasora.evolve_slab_outbox_from_host(0, host)
+        if ph: ph.mark("rate_allreduce")
+        libasora.evolve_slab_pass()
+        libasora.evolve_slab_close(None)             # (the pass's sums are those of the whole grid, the same on every rank)
+        if ph:
+            ph.mark("pass_test")
+            ph.close()
+
     def slab_enqueue(self, libasora, iterations=1):
         """Enqueue outer iterations of the step begun with ``slab_begin``.  One iteration = what the one-GPU loop does -- the
         trace and ONE fused pass -- with two plane exchanges in between:
@@ -624,8 +662,9 @@ class TorchComm:
         launch is gated by the device's `done` flag, and every rank evaluates the test on identical bits, so all ranks stop
         at the same iteration; ``slab_poll`` reads the status back once per batch.  With gloo (CPU rehearsals) the planes
         and the sums are staged through the host, one synchronisation per exchange."""
+        one = self._reduce_one if self._slab[0] is None else self._slab_one
         for _ in range(int(iterations)):
-            self._slab_one(libasora)
+            one(libasora)
 
     def slab_poll(self, libasora, max_rows=32):
         """(iterations carried out, converged, rows) -- asora_evolve_poll; folds the last iteration's rates into PHI_ION

@@ -310,7 +310,31 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
                                f"Relative change in ionfrac: {rel_change_xh1 : .2e}", '\n')]
             printlog_lines(lines, logfile, quiet)
 
-    while distributed and not slab and not converged:
+    # full-grid all-reduce on the same device-resident loop (TorchComm.reduce_begin): trace, fold, all-reduce of the rate grid in
+    # place, ONE fused pass on the whole grid on every rank, test on the device -- batches of iterations per host round trip
+    reduce_loop = (distributed and not slab and not pipelined and getattr(comm, "device_loop", False)
+                   and hasattr(comm, "reduce_begin") and hasattr(libasora, "evolve_slab_fold_all"))
+    if reduce_loop:
+        comm.reduce_begin(libasora, N, R_max_LLS, sig, dr, NumSrc_local, minlogtau, dlogtau, NumTau, chem, conv_criterion,
+                          convergence_fraction)
+        batch = max(1, min(EVOLVE_BATCH, 32)) if comm._backend() == "nccl" else 1
+        while not converged:
+            trt0 = time.time()
+            comm.slab_enqueue(libasora, batch)
+            _, converged, rows = comm.slab_poll(libasora, batch)
+            per_iteration = (time.time() - trt0) / max(len(rows), 1)
+            lines = []
+            for conv_flag, _s1, _s0, rel_change_xh1, _rel0 in rows:
+                niter += 1
+                conv_flag = int(conv_flag)
+                lines += [(f"Doing Raytracing, all-reduce and Chemistry (rank={rank:n})...", ' '),
+                          (f"rank={rank:n} took {per_iteration : .1e} s.", '\n')]
+                if rank == 0:
+                    lines += [(f"Number of non-converged points: {conv_flag} of {NumCells} ({conv_flag / NumCells * 100 : .3f} % ), "
+                               f"Relative change in ionfrac: {rel_change_xh1 : .2e}", '\n')]
+            printlog_lines(lines, logfile, quiet)
+
+    while distributed and not slab and not reduce_loop and not converged:
         niter += 1
 
         # (1) raytracing, evolve.py:174-196

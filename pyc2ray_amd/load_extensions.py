@@ -254,6 +254,13 @@ class _LibAsora:
         _capi.check(self._lib.asora_evolve_slab_outbox_to_host(int(i_begin), int(i_count), _capi.dptr(out)), "evolve_slab_outbox_to_host")
         return out
 
+    def evolve_slab_outbox_from_host(self, i_begin, planes):
+        a = np.ascontiguousarray(planes, dtype=np.float64)
+        _capi.check(self._lib.asora_evolve_slab_outbox_from_host(int(i_begin), int(a.shape[0]), _capi.dptr(a)), "evolve_slab_outbox_from_host")
+
+    def evolve_slab_fold_all(self):
+        _capi.check(self._lib.asora_evolve_slab_fold_all(), "evolve_slab_fold_all")
+
     def evolve_slab_add(self, i_begin, i_count, dev_ptr):
         """dev_ptr: device address of i_count*N*N doubles (e.g. torch tensor .data_ptr())."""
         _capi.check(self._lib.asora_evolve_slab_add(int(i_begin), int(i_count), C.c_void_p(int(dev_ptr))), "evolve_slab_add")

@@ -38,6 +38,8 @@ def main():
     assert (r, w) == (rank, world)
     comm = pd.TorchComm(overlap=overlap, chunks=4, pipeline_chemistry=overlap)
     comm.exchange = "slab" if slab else "allreduce"
+    # "..._legacy" / ":legacy": the all-reduce exchange with three calls and a host read-back per iteration instead of the device loop
+    comm.device_loop = not (mode.endswith("_legacy") or "legacy" in spec[1:])
     for item in spec[1:]:
         if item.startswith("k") and item[1:].isdigit():
             comm.slab_chunks = int(item[1:])              # trace chunks of the overlapped slab exchange
@@ -169,8 +171,8 @@ def main():
     extra = {}
     if diag:
         import json
-        if comm.exchange == "allreduce":
-            # evolve3D_MPI makes the three calls itself on this path; bench.py goes through raytrace_and_allreduce: two steps of it
+        if comm.exchange == "allreduce" and not comm.device_loop:
+            # evolve3D_MPI makes the three calls itself on this path; bench.py --overlap 1 goes through raytrace_and_allreduce: two steps of it
             lib_ = ev.load_asora()
             NumTau = thin.shape[0]
             lib_.source_data_to_device(*__import__("pyc2ray_amd.utils.sourceutils", fromlist=["format_sources"]).format_sources(pos, flux), ns)

@@ -158,6 +158,21 @@ class OracleAsora:
         self._phi_own = np.zeros((N, N, N))
         self._folded = np.zeros(N, dtype=bool)
         self._first = True
+        self._rates_in_outbox = False
+
+    def evolve_slab_fold_all(self):
+        """All planes into the out-box (the full-grid exchange on the same loop); the pass then reads the out-box."""
+        e = self._ev
+        assert not e["passed"] and e["own"].start == 0 and e["own"].stop == self.g[0].shape[0]
+        self._rates_in_outbox = True
+        if e["done"]:
+            return
+        self._outbox = self._acc.copy()
+        self._acc[:] = 0.0
+
+    def evolve_slab_outbox_from_host(self, i_begin, planes):
+        planes = np.asarray(planes)
+        self._outbox[i_begin:i_begin + planes.shape[0]] = planes.reshape(planes.shape[0], *self._outbox.shape[1:])
 
     def evolve_slab_trace(self, src_begin, src_count):
         e = self._ev
@@ -203,10 +218,11 @@ class OracleAsora:
         sl = e["own"]
         if sl.stop > sl.start:
             xav_in = self.g[4][sl] if self._first else self.g[1][sl]
+            rates = self._outbox if self._rates_in_outbox else self._acc
             xa, xi, conv, _ = O.global_pass(e["chem"][0], self.g[0][sl], self.g[3][sl], self.g[4][sl], xav_in, self.g[5][sl],
-                                            self._acc[sl], *e["chem"][1:])
+                                            rates[sl], *e["chem"][1:])
             self.g[1][sl], self.g[5][sl] = xa, xi
-            self._phi_own[sl] = self._acc[sl]
+            self._phi_own[sl] = rates[sl]
             self._acc[sl] = 0.0
             self._nhi[sl] = self.g[0][sl] * (1.0 - xa)
             self._red = [conv, float(np.sum(xi)), float(np.sum(1.0 - xi))]
@@ -224,7 +240,9 @@ class OracleAsora:
 
     def evolve_slab_close(self, sums=None):
         e = self._ev
-        assert e["passed"] and sums is not None
+        assert e["passed"] and (sums is not None or self._rates_in_outbox)
+        if sums is None:
+            sums = self._red                 # (every rank passed over the whole grid: the sums are the totals already)
         e["passed"] = False
         self._folded[:] = False
         if e["done"]:

@@ -46,7 +46,7 @@ def test_final_plane_runs_cover_every_plane_once_and_never_early():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["real_plain", "real_overlap", "real_cpu_semantics"])
+@pytest.mark.parametrize("mode", ["real_plain", "real_plain_legacy", "real_overlap", "real_cpu_semantics"])
 def test_two_ranks_on_one_gpu_with_the_hip_library(tmp_path, mode):
     """The same two-rank runs with the HIP library itself under both ranks (both on GPU 0, sums staged through the
     host by gloo): the sharded evolve3D_MPI -- plain, pipelined, and with use_gpu=False semantics -- against the
@@ -54,7 +54,7 @@ def test_two_ranks_on_one_gpu_with_the_hip_library(tmp_path, mode):
     test_two_ranks_match_single_process(tmp_path, mode)
 
 
-@pytest.mark.parametrize("mode", ["plain", "overlap", "cpu_semantics"])
+@pytest.mark.parametrize("mode", ["plain", "plain_legacy", "overlap", "cpu_semantics"])
 def test_two_ranks_match_single_process(tmp_path, mode):
     world = 2
     port = _free_port()
@@ -341,14 +341,14 @@ def test_slab_exchange_matches_single_process(tmp_path, world, N, ns, R):
     np.testing.assert_allclose(res[0]["phi"], phi_ref, rtol=1e-10, atol=0)
 
 
-@pytest.mark.parametrize("world,exchange", [(2, "slab"), (3, "slab"), (2, "allreduce")])
+@pytest.mark.parametrize("world,exchange", [(2, "slab"), (3, "slab"), (2, "allreduce"), (3, "allreduce"), (2, "allreduce:legacy")])
 def test_phase_times_and_link_rates_of_a_multi_rank_run(tmp_path, world, exchange):
     """What bench.py --gpus N prints beside its value: per-phase milliseconds of an iteration -- booked by
     TorchComm.slab_enqueue / raytrace_and_allreduce when `phase_timing` is set, maximum over the ranks -- and the rates a
     point-to-point ring and an all-reduce reach in this job (TorchComm.measure_links).  Every rank reports the same numbers
     (they drive `--exchange auto`, which all ranks must decide alike); switching the timers on changes no result."""
     import json
-    res = _run_workers(tmp_path, world, f"slab:16:5:6.0:phases" + (":allreduce" if exchange == "allreduce" else ""))
+    res = _run_workers(tmp_path, world, f"slab:16:5:6.0:phases" + (":" + exchange if exchange != "slab" else ""))
     x_ref, phi_ref, niter_ref, _ = _slab_reference(16, 5, 6.0)
     for r in res:
         assert int(r["niter"]) == niter_ref
@@ -357,9 +357,10 @@ def test_phase_times_and_link_rates_of_a_multi_rank_run(tmp_path, world, exchang
     ln = [json.loads(str(r["links"])) for r in res]
     assert all(q == ph[0] for q in ph[1:]) and all(q == ln[0] for q in ln[1:])
     want = ({"trace_fold_post", "wait_rates_add", "slab_pass", "xh_av_exchange_nhi", "scalar_allreduce_test"}
-            if exchange == "slab" else {"trace", "rate_allreduce", "chemistry"})
+            if exchange == "slab" else {"trace_fold", "rate_allreduce", "pass_test"} if exchange == "allreduce"     # (the device loop)
+            else {"trace", "rate_allreduce", "chemistry"})
     assert set(ph[0]) == want | {"iterations"}
-    assert ph[0]["iterations"] == (niter_ref if exchange == "slab" else 2)
+    assert ph[0]["iterations"] == (2 if exchange.endswith("legacy") else niter_ref)
     assert all(ph[0][k] >= 0.0 for k in want) and sum(ph[0][k] for k in want) > 0.0
     for key in ("p2p_ms", "p2p_GBs", "allreduce_ms", "allreduce_busbw_GBs"):
         assert ln[0][key] > 0.0
@@ -411,7 +412,7 @@ def _check_against_reference_mpi(res, name, world, rtol_x, rtol_phi):
     assert done == len(g[f"{name}__P{world}__rows"])        # outer iterations over all time steps, from the reference's log
 
 
-@pytest.mark.parametrize("world,name,exchange", [(2, "l16_gpu_F", "slab"), (3, "l16_gpu_F", "allreduce"),
+@pytest.mark.parametrize("world,name,exchange", [(2, "l16_gpu_F", "slab"), (3, "l16_gpu_F", "allreduce"), (2, "l16_gpu_F", "allreduce:legacy"),
                                                  (2, "l24_gpu_F_37src", "allreduce"), (3, "l24_gpu_F_37src", "slab")])
 def test_evolve3D_MPI_reproduces_the_reference_evolve3D_MPI(tmp_path, world, name, exchange):
     """The fixture is the reference's own evolve3D_MPI (pyc2ray/evolve.py:249-498) run with 1, 2 and 3 ranks over its
@@ -422,10 +423,12 @@ def test_evolve3D_MPI_reproduces_the_reference_evolve3D_MPI(tmp_path, world, nam
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,name", [(2, "l24_gpu_F_37src"), (3, "l16_gpu_F")])
-def test_evolve3D_MPI_with_the_hip_library_reproduces_the_reference_evolve3D_MPI(tmp_path, world, name):
-    """The same with the HIP library under every rank (all ranks on GPU 0, exchanges staged through the host by gloo)."""
-    res = _run_workers(tmp_path, world, f"mpigolden:{name}:slab:real")
+@pytest.mark.parametrize("world,name,exchange", [(2, "l24_gpu_F_37src", "slab"), (3, "l16_gpu_F", "slab"), (2, "l24_gpu_F_37src", "allreduce"),
+                                                 (3, "l16_gpu_F", "allreduce")])
+def test_evolve3D_MPI_with_the_hip_library_reproduces_the_reference_evolve3D_MPI(tmp_path, world, name, exchange):
+    """The same with the HIP library under every rank (all ranks on GPU 0, exchanges staged through the host by gloo): the slab
+    exchange and the full-grid all-reduce, both on the device-resident loop."""
+    res = _run_workers(tmp_path, world, f"mpigolden:{name}:{exchange}:real")
     _check_against_reference_mpi(res, name, world, 1e-8, 1e-7)
 
 

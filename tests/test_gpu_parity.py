@@ -556,6 +556,83 @@ def test_slab_iteration_over_rccl_world1_equals_the_single_gpu_loop(asora, tmp_p
     p.device_close()
 
 
+def test_allreduce_loop_over_rccl_world1_equals_the_single_gpu_loop(asora, tmp_path, monkeypatch):
+    """The reference's exchange (pyc2ray/evolve.py:433-437: the rate grid all-reduced, chemistry on identical data) on the
+    device-resident loop (TorchComm.reduce_begin; asora_evolve_slab_fold_all): trace, both accumulator layouts folded into the
+    out-box, the out-box all-reduced IN PLACE by RCCL on the library's stream (one rank here, forced), ONE fused pass on the
+    whole grid reading the out-box, test on the device; batches of 8 iterations per poll.  Same iteration count and fields as
+    evolve3D.  Iterations enqueued beyond convergence still all-reduce the (stale) out-box -- PHI_ION must not change."""
+    import socket
+    import torch.distributed as dist
+    from pyc2ray_amd import dist as pd
+    from pyc2ray_amd.utils.sourceutils import format_sources
+    p, lib, capi = asora
+    monkeypatch.setenv("PYC2RAY_AMD_FORCE_COLLECTIVE", "1")
+    N = 32
+    nd, xh, dr = cases.grid(N, "lognormal", 91, 0.15, xlo=1e-4, xhi=2e-3)
+    temp = np.full((N, N, N), 1e4)
+    pos, flux = cases.sources(N, 11, 92, flux=3e-4 * (N / 16.0) ** 3 / 11)
+    thin, thick, dlog = cases.soft_tables()
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 8)
+    p.photo_table_to_device(thin, thick)
+    if not dist.is_initialized():
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        pd.init_process_group_from_env("nccl")
+    args = (3.15576e13 * 3, dr, flux, pos, True, 1000, N, 1e-2)
+    rest = (temp, nd, xh, thin, thick, cases.MINLOGTAU, dlog, 7.0, 1e-4, cases.SIG, cases.BH00, cases.ALBPOW, cases.COLH0,
+            cases.TEMPH0, cases.ABU_C)
+    x1, phi1 = p.evolve3D(*args, *rest, logfile=str(tmp_path / "a"), quiet=True)
+    n1 = p.evolve._evolve.last_niter
+    comm = pd.TorchComm()
+    comm.exchange = "allreduce"
+    p0, f0 = format_sources(pos, flux)
+    lib.source_data_to_device(p0, f0, 11)
+    for which, a in ((capi.GRID_NDENS, nd), (capi.GRID_TEMP, temp), (capi.GRID_XH, xh)):
+        lib.grid_to_device(which, a)
+    chem = (3.15576e13 * 3, cases.BH00, cases.ALBPOW, cases.COLH0, cases.TEMPH0, cases.ABU_C)
+    crit = min(int(1e-4 * N ** 3), (11 - 1) / 3)
+    comm.phase_timing = True
+    comm.reduce_begin(lib, N, 7.0, cases.SIG, dr, 11, cases.MINLOGTAU, dlog, thin.shape[0], chem, crit, 1e-4)
+    done, rows_all = False, []
+    while not done:
+        comm.slab_enqueue(lib, 8)
+        n2, done, rows = comm.slab_poll(lib, 8)
+        rows_all += list(rows)
+        assert n2 < 100
+    assert n2 == n1 == len(rows_all), (n2, n1, len(rows_all))
+    x2 = lib.grid_to_host(capi.GRID_XH_INTERMED, np.empty((N, N, N)))
+    phi2 = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+    np.testing.assert_allclose(x2, x1, rtol=1e-10, atol=0)
+    np.testing.assert_allclose(phi2, phi1, rtol=1e-10, atol=0)
+    assert np.array_equal(phi2 != 0, phi1 != 0)
+    comm.slab_enqueue(lib, 3)                                   # beyond convergence
+    n3, done3, rows3 = comm.slab_poll(lib, 8)
+    assert (n3, done3, len(rows3)) == (n1, True, 0)
+    assert np.array_equal(lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N))), phi2)
+    assert np.array_equal(lib.grid_to_host(capi.GRID_XH_INTERMED, np.empty((N, N, N))), x2)
+    ph = comm.phase_report()
+    assert set(ph) == {"trace_fold", "rate_allreduce", "pass_test", "iterations"} and ph["iterations"] >= n1
+    # call order: a step that exchanges whole grids must own every plane, and folds before every pass
+    with pytest.raises(RuntimeError, match="must own every plane"):
+        lib.evolve_begin_slab(*chem, 7.0, cases.SIG, dr, cases.MINLOGTAU, dlog, thin.shape[0], 0, 11, -1.0, 0.0, 8, 8)
+        lib.evolve_slab_fold_all()
+    lib.evolve_begin_slab(*chem, 7.0, cases.SIG, dr, cases.MINLOGTAU, dlog, thin.shape[0], 0, 11, -1.0, 0.0, 0, N)
+    lib.evolve_slab_trace(0, 11); lib.evolve_slab_fold_all(); lib.evolve_slab_pass(); lib.evolve_slab_close(None)
+    lib.evolve_slab_trace(0, 11)
+    with pytest.raises(RuntimeError, match="this iteration's fold has not been enqueued"):
+        lib.evolve_slab_pass()
+    lib.evolve_slab_fold_all(); lib.evolve_slab_pass(); lib.evolve_slab_close(None)
+    assert lib.evolve_poll(4)[0] == 2
+    # the out-box written from the host (transports that sum on the host)
+    box = np.arange(2 * N * N, dtype=np.float64).reshape(2, N, N)
+    lib.evolve_slab_outbox_from_host(5, box)
+    assert np.array_equal(lib.evolve_slab_outbox_to_host(5, 2, N), box)
+    p.device_close()
+
+
 # ---- edge cases -----------------------------------------------------------------------------------------
 def _edge_case(p, lib, capi, N, pos, flux, R, tau_cell=0.1, seed=71, tables="soft", xh_override=None):
     nd, xh, dr = cases.grid(N, "lognormal", seed, tau_cell)
