@@ -197,6 +197,23 @@ __global__ void __launch_bounds__(RED_THREADS) chemistry_reduce_kernel(const dou
 #ifndef ASORA_CHEM_MIN_WAVES
 #define ASORA_CHEM_MIN_WAVES 1
 #endif
+// The grids the pass reads are streams: every element once, nothing another workgroup wants again.  Loaded non-temporal they do not
+// take the place of the lines the seven write streams are being combined in: a bare kernel with the pass's 5 read and 7 write streams
+// moves 6.3 TB/s instead of 5.3 (tools/micro/stream_peak.hip; non-temporal STORES cost 2-5 % there, and in the pass itself -- any of
+// its three groups of write streams -- change nothing beyond the noise: profiles/r05_ab_chem_ntstores.txt).  The pass: -8 % in either
+// state of a box (0.248 -> 0.229 ms, 0.306 -> 0.281 ms; profiles/r05_ab_chem_ntloads.txt).
+#ifndef ASORA_CHEM_NT_LOADS
+#define ASORA_CHEM_NT_LOADS 1
+#endif
+__device__ __forceinline__ double stream_load(const double *q)
+{
+#if ASORA_CHEM_NT_LOADS
+    return __builtin_nontemporal_load(q);
+#else
+    return *q;
+#endif
+}
+
 template <bool FOLD, bool EMIT, bool UNIFORM_T>
 __global__ void __launch_bounds__(CH_THREADS, ASORA_CHEM_MIN_WAVES) chemistry_tile_kernel(const ChemTileParams p)
 {
@@ -228,7 +245,7 @@ __global__ void __launch_bounds__(CH_THREADS, ASORA_CHEM_MIN_WAVES) chemistry_ti
                     const size_t o = ((size_t)k * N + j) * N + i;
                     // a line no source reaches holds zeros in both accumulator pairs and keeps them: neither read nor zeroed
                     const bool reached = !p.reach_t || p.reach_t[((size_t)k * N + j) * NL + (i >> 3)] != 0;
-                    tile_g[r][tx] = reached ? p.gamma_t[o] : 0.0;
+                    tile_g[r][tx] = reached ? stream_load(p.gamma_t + o) : 0.0;
                     if (EMIT && reached) p.zero_t[o] = 0.0;
                 }
             }
@@ -239,14 +256,14 @@ __global__ void __launch_bounds__(CH_THREADS, ASORA_CHEM_MIN_WAVES) chemistry_ti
             if (i < p.i_end && k < N) {
                 const size_t idx = ((size_t)i * N + j) * N + k;
                 const bool reached = !FOLD || !p.reach_a || p.reach_a[((size_t)i * N + j) * NL + (k >> 3)] != 0;
-                double g = reached ? p.gamma[idx] : 0.0;
+                double g = reached ? stream_load(p.gamma + idx) : 0.0;
                 if (FOLD) g += tile_g[tx][r];
                 if (p.phi_out) p.phi_out[idx] = g;            // (the summed rates, where someone keeps them: all-reduce loop)
                 if (EMIT && reached) p.zero_a[idx] = 0.0;
-                const double n = p.ndens[idx];
-                double xav = p.xh_av_in[idx], xint;
-                if (!UNIFORM_T) temperature_factors(cp, p.temp[idx], tf);
-                chemistry_cell(cp, n, p.xh[idx], g, xav, xint, nconv, tf);
+                const double n = stream_load(p.ndens + idx);
+                double xav = stream_load(p.xh_av_in + idx), xint;
+                if (!UNIFORM_T) temperature_factors(cp, stream_load(p.temp + idx), tf);
+                chemistry_cell(cp, n, stream_load(p.xh + idx), g, xav, xint, nconv, tf);
                 p.xh_intermed[idx] = xint;                           // chemistry.f90:107-108
                 p.xh_av[idx] = xav;
                 sum1 += xint; sum0 += 1.0 - xint;                    // evolve.py:216-217
