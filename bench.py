@@ -1086,6 +1086,9 @@ def main():
             "launched_by": ("bench.py itself (child torch.distributed.run)" if os.environ.get("PYC2RAY_AMD_BENCH_SELF_LAUNCHED") == "1"
                             else "an external launcher" if "WORLD_SIZE" in os.environ else "plain python"),
             "library_build_id": lib.build_id(),
+            # where device_init put the grids: allocations of the whole arena tried, probe time (a kernel with the fused pass's stream
+            # mix) of the one kept and of the slowest -- placements differ by ~15 % on one box (csrc/api.hip choose_arena)
+            "grid_placement": lib.debug_placement(),
             "ranks_agree_on_rates_and_ionised_fraction": ranks_agree,
             "parallelism": ("single GPU" if world == 1 else
                             f"sources sharded over {world} ranks by slab of the first coordinate; rates sent plane-wise to the "

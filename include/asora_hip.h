@@ -410,6 +410,8 @@ int asora_last_raytrace_variant(void);
  * steps, *shells / *max_cells the launch's shell count and zero slot.  table = -1 only reports the counts. */
 /* Device memory the geometry tables of the last launch shape occupy (a part shared between tables counts once). */
 size_t asora_debug_geometry_bytes(void);
+/* How device_init placed the grids (api.hip choose_arena): allocations tried, probe time of the one kept and of the slowest. */
+void asora_debug_placement(int *candidates, double *chosen_probe_ms, double *slowest_probe_ms);
 int asora_debug_geometry_table(int table, uint32_t *words, size_t capacity_entries, size_t *entries, int *nsteps, int *ntables,
                                int *shells, int *max_cells, int *threads);
 

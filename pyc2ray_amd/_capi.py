@@ -73,6 +73,7 @@ SIGNATURES = {
     "asora_evolve_slab_outbox_to_host": (C.c_int, [C.c_int, C.c_int, _dp]),
     "asora_evolve_slab_outbox_from_host": (C.c_int, [C.c_int, C.c_int, _dp]),
     "asora_evolve_slab_fold_all": (C.c_int, []),
+    "asora_debug_placement": (None, [C.POINTER(C.c_int), _dp, _dp]),
     "asora_evolve_slab_add": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
     "asora_evolve_slab_add_host": (C.c_int, [C.c_int, C.c_int, _dp]),
     "asora_evolve_slab_pass": (C.c_int, []),

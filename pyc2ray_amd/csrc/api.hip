@@ -142,8 +142,12 @@ static int release_all()
 {
     State &st = g_state;
     auto drop = [](auto *&ptr) { if (ptr) { (void)hipFree(ptr); ptr = nullptr; } };
-    for (int g = 0; g < ASORA_GRID_COUNT; ++g) { drop(st.grid[g]); st.grid_valid[g] = false; }
-    drop(st.nhi); drop(st.staging); drop(st.acc); st.ev_clean[0] = st.ev_clean[1] = false; st.ev_sets_known = false;
+    // (the grids of the hot loop are parts of the arena; the heating grid is an allocation of its own)
+    drop(st.grid[ASORA_GRID_PHI_HEAT]);
+    for (int g = 0; g < ASORA_GRID_COUNT; ++g) { st.grid[g] = nullptr; st.grid_valid[g] = false; }
+    st.nhi = st.staging = st.acc = nullptr;
+    drop(st.arena); st.arena_bytes = 0;
+    st.ev_clean[0] = st.ev_clean[1] = false; st.ev_sets_known = false;
     drop(st.reach_mask); drop(st.reach_count_dev); st.reach_bytes = 0; st.reach_valid = false; st.reach_in_use = false; st.reach_pays = false;
     st.ev_open = false;
     st.temp_probe_valid = false;
@@ -682,6 +686,94 @@ using namespace asora;
 
 extern "C" {
 
+// ---------------------------------------------------------------------------------------------
+// Where the grids lie.  The fused pass streams 5 grids in and 6-7 out at once, and how fast the memory side takes that mix depends
+// on WHERE those grids lie physically: the same kernel on the same box moves 5.2-5.4 TB/s on most placements and 6.0-6.2 TB/s on
+// a fifth to a third of them, stable for the life of the allocation (tools/micro/placement_probe.hip; some boxes offer one kind only;
+// with one hipMalloc per grid the sets spread between the two, which is what earlier rounds recorded as the "state of the box":
+// fused pass 0.25 ... 0.31 ms from run to run).  Nothing a process can read tells the two kinds apart beforehand, so device_init
+// tries: up to ARENA_CANDIDATES allocations of the whole arena, three launches of a kernel with the pass's stream mix on each, the
+// fastest is kept and the others are freed (8 ms at 256^3, 30-80 ms at 512^3).  It stops early once it holds a candidate clearly
+// faster than another (both kinds seen).  On a box with both kinds, alternating processes (profiles/r05_ab_placement.txt): first
+// allocation taken 1.392-1.395 ms per step in five runs of six (fused pass 0.282, trace 1.079), probed 1.333-1.337 in six of six
+// (0.245, 1.060).  Meshes below 128^3 take the first allocation (their grids sit in the caches); ASORA_PLACEMENT_CANDIDATES=1 does
+// so always.
+// ---------------------------------------------------------------------------------------------
+constexpr int ARENA_CANDIDATES = 16;       // about one placement in five is of the fast kind where both occur: 0.8^16 = 3 % to miss it
+constexpr int ARENA_SLOTS = 14;            // ndens, xh, xh_av, temp, xh_intermed, 4 accumulators, nhi x 2, phi_ion x 2, staging
+__global__ void __launch_bounds__(256) placement_probe_kernel(char *arena, size_t slot, size_t n)
+{
+    // 5 read streams (non-temporal, as the pass loads them) and 7 write streams over the first 12 slots
+    const double *in[5]; double *out[7];
+    for (int q = 0; q < 5; ++q) in[q] = reinterpret_cast<const double *>(arena + q * slot);
+    for (int q = 0; q < 7; ++q) out[q] = reinterpret_cast<double *>(arena + (5 + q) * slot);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) s += __builtin_nontemporal_load(in[q] + i);
+#pragma unroll
+        for (int q = 0; q < 7; ++q) out[q][i] = s;
+    }
+}
+
+static int choose_arena(State &st, size_t slot, int slots)
+{
+    const size_t total = slot * (size_t)slots;
+    int want = ARENA_CANDIDATES;
+    if (const char *e = getenv("ASORA_PLACEMENT_CANDIDATES")) want = std::max(1, atoi(e));
+    if (st.N < 128) want = 1;
+    size_t free_b = 0, all_b = 0;
+    if (hipMemGetInfo(&free_b, &all_b) == hipSuccess && total > 0)
+        want = (int)std::max<size_t>(1, std::min<size_t>((size_t)want, (size_t)(0.5 * (double)free_b) / total));
+    st.arena_candidates = 0; st.arena_probe_ms = st.arena_probe_worst_ms = 0.0;
+    if (want == 1) {
+        ASORA_HIP_TRY(hipMalloc(&st.arena, total));
+        st.arena_bytes = total; st.arena_candidates = 1;
+        return 0;
+    }
+    hipEvent_t t0, t1;
+    ASORA_HIP_TRY(hipEventCreate(&t0)); ASORA_HIP_TRY(hipEventCreate(&t1));
+    std::vector<char *> cand;
+    std::vector<float> ms;
+    int best = -1;
+    float worst = 0.0f;
+    const size_t n = st.ncell;
+    for (int c = 0; c < want; ++c) {
+        char *a = nullptr;
+        if (hipMalloc(&a, total) != hipSuccess) { (void)hipGetLastError(); break; }
+        cand.push_back(a);
+        float t = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            (void)hipEventRecord(t0, st.stream);
+            hipLaunchKernelGGL(placement_probe_kernel, dim3(1024), dim3(256), 0, st.stream, a, slot, n);
+            (void)hipEventRecord(t1, st.stream);
+            if (hipEventSynchronize(t1) != hipSuccess) { t = 1e30f; break; }
+            float e = 0.0f;
+            (void)hipEventElapsedTime(&e, t0, t1);
+            if (rep >= 1) t = std::min(t, e);              // (the first launch maps the pages)
+        }
+        ms.push_back(t);
+        if (best < 0 || t < ms[(size_t)best]) best = c;
+        worst = std::max(worst, t);
+        if (c >= 1 && ms[(size_t)best] <= 0.93f * worst) break;     // both kinds seen, and one of the fast kind in hand
+    }
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    if (best < 0) return fail(2, "device_init: out of device memory for the grids");
+    for (size_t c = 0; c < cand.size(); ++c) if ((int)c != best) (void)hipFree(cand[c]);
+    st.arena = cand[(size_t)best];
+    st.arena_bytes = total;
+    st.arena_candidates = (int)cand.size();
+    st.arena_probe_ms = ms[(size_t)best]; st.arena_probe_worst_ms = worst;
+    return 0;
+}
+
+void asora_debug_placement(int *candidates, double *chosen_probe_ms, double *slowest_probe_ms)
+{
+    if (candidates) *candidates = g_state.arena_candidates;
+    if (chosen_probe_ms) *chosen_probe_ms = g_state.arena_probe_ms;
+    if (slowest_probe_ms) *slowest_probe_ms = g_state.arena_probe_worst_ms;
+}
+
 const char *asora_last_error(void) { return g_error.c_str(); }
 
 int asora_device_init_ex(int N, int num_src_par, int device_id)
@@ -699,16 +791,27 @@ int asora_device_init_ex(int N, int num_src_par, int device_id)
     st.num_src_par = num_src_par;
     st.auto_init = false;
     const size_t bytes = st.ncell * sizeof(double);
-    // the rate grids and nHI carry their [k][j][i] twin directly behind them (one 32-bit index reaches both)
-    for (int g = 0; g < ASORA_GRID_COUNT; ++g) {
-        if (g == ASORA_GRID_PHI_HEAT) continue;                     // on first use: ensure_heat_grid
-        ASORA_HIP_TRY(hipMalloc(&st.grid[g], g == ASORA_GRID_PHI_ION ? 2 * bytes : bytes));
+    // ONE allocation for every N^3 grid of the hot loop (choose_arena); the rate grids and nHI carry their [k][j][i] twin directly
+    // behind them (one 32-bit index reaches both)
+    const size_t slot = (bytes + 4095) / 4096 * 4096;
+    if (int rc = choose_arena(st, slot, ARENA_SLOTS)) return rc;
+    {
+        size_t at = 0;
+        auto take = [&](size_t grids) { double *q = reinterpret_cast<double *>(st.arena + at); at += grids * slot; return q; };
+        // (two-grid buffers: the second half starts ncell doubles behind the first -- inside the two slots either way)
+        st.grid[ASORA_GRID_NDENS] = take(1); st.grid[ASORA_GRID_XH] = take(1); st.grid[ASORA_GRID_XH_AV] = take(1);
+        st.grid[ASORA_GRID_TEMP] = take(1); st.grid[ASORA_GRID_XH_INTERMED] = take(1);
+        st.acc = take(4);
+        st.nhi = take(2);
+        st.grid[ASORA_GRID_PHI_ION] = take(2);
+        st.staging = take(1);
     }
-    ASORA_HIP_TRY(hipMalloc(&st.nhi, 2 * bytes));
+    for (int g = 0; g < ASORA_GRID_COUNT; ++g)
+        if (g != ASORA_GRID_PHI_HEAT && !st.grid[g]) return fail(11, "device_init: a grid without a place in the arena (internal error)");
     st.nhi_t = st.nhi + st.ncell;
     st.phi_t = st.grid[ASORA_GRID_PHI_ION] + st.ncell;
     st.heat_t = nullptr;
-    ASORA_HIP_TRY(hipMalloc(&st.staging, bytes));
+    st.ev_sets_known = false;
     {   // per-workgroup partials of the tiled chemistry pass: the j-chunk count is rounded up per (k tile x i tile), so a
         // RANGE of planes (asora_chemistry_range: a multi-GPU rank's slab) can need more workgroups than the whole grid
         size_t worst = 0;
@@ -1307,7 +1410,6 @@ static int evolve_begin_impl(double dt, double bh00, double albpow, double colh0
     const size_t bytes = st.ncell * sizeof(double);
     // two accumulator pairs (State::acc): the first trace needs a zeroed pair; every fused pass zeroes the pair the next
     // trace adds into, iterations beyond convergence touch nothing
-    if (!st.acc) { ASORA_HIP_TRY(hipMalloc(&st.acc, 4 * bytes)); st.ev_sets_known = false; }
     if (!st.ev_sets_known) {          // iterations were enqueued and never polled: which pair holds what is not known
         ASORA_HIP_TRY(hipMemsetAsync(st.acc, 0, 4 * bytes, st.stream));                      // raytracing.cu:113
         st.ev_clean[0] = st.ev_clean[1] = true;

@@ -219,6 +219,11 @@ struct State {
     // other one for iteration k + 1.  The rates of the last iteration carried out therefore survive in their set until the
     // host asks for them (asora_evolve_poll folds them into PHI_ION): the pass writes no rate grid (88 instead of 96 B per cell).
     double *acc = nullptr;
+    // every N^3 grid of the hot loop lives in ONE allocation (api.hip: choose_arena), picked among several candidates by a probe
+    char *arena = nullptr;
+    size_t arena_bytes = 0;
+    int arena_candidates = 0;               // how many were tried
+    double arena_probe_ms = 0.0, arena_probe_worst_ms = 0.0;     // the chosen one's probe time, the slowest candidate's
     int ev_base = 0;                        // set of the first iteration of the current time step
     bool ev_clean[2] = {false, false};      // set known to be all zero (when nothing is enqueued)
     bool ev_sets_known = false;             // the bookkeeping above is valid (a poll has happened since the last enqueue)

@@ -258,6 +258,12 @@ class _LibAsora:
         a = np.ascontiguousarray(planes, dtype=np.float64)
         _capi.check(self._lib.asora_evolve_slab_outbox_from_host(int(i_begin), int(a.shape[0]), _capi.dptr(a)), "evolve_slab_outbox_from_host")
 
+    def debug_placement(self):
+        """How device_init placed the grids: {candidates tried, probe ms of the allocation kept, of the slowest one}."""
+        n, a, b = C.c_int(0), C.c_double(0.0), C.c_double(0.0)
+        self._lib.asora_debug_placement(C.byref(n), C.byref(a), C.byref(b))
+        return {"candidates": n.value, "chosen_probe_ms": a.value, "slowest_probe_ms": b.value}
+
     def evolve_slab_fold_all(self):
         _capi.check(self._lib.asora_evolve_slab_fold_all(), "evolve_slab_fold_all")
 

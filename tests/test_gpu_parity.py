@@ -633,6 +633,45 @@ def test_allreduce_loop_over_rccl_world1_equals_the_single_gpu_loop(asora, tmp_p
     p.device_close()
 
 
+def test_grids_placed_by_probe_give_the_same_results(asora, tmp_path, monkeypatch):
+    """device_init puts every N^3 grid of the hot loop into ONE allocation chosen among several by a streaming probe (api.hip
+    choose_arena: placements differ by ~15 % in what the memory side delivers).  From 128^3 on several candidates are tried;
+    ASORA_PLACEMENT_CANDIDATES=1 takes the first.  Whichever is kept, the grids are where the library thinks they are: a time step
+    gives the same result either way, and re-initialising at another size leaves nothing behind."""
+    p, lib, capi = asora
+    N = 128
+    nd, xh, dr = cases.grid(N, "lognormal", 23, 0.15, xlo=1e-4, xhi=2e-3)
+    temp = np.full((N, N, N), 1e4)
+    pos, flux = cases.sources(N, 40, 24, flux=3e-4 * (N / 16.0) ** 3 / 40)
+    thin, thick, dlog = cases.soft_tables()
+    args = (3.15576e13 * 3, dr, flux, pos, True, 1000, N, 1e-2)
+    rest = (temp, nd, xh, thin, thick, cases.MINLOGTAU, dlog, 9.0, 1e-4, cases.SIG, cases.BH00, cases.ALBPOW, cases.COLH0,
+            cases.TEMPH0, cases.ABU_C)
+    out = {}
+    for cand in ("1", "6"):
+        monkeypatch.setenv("ASORA_PLACEMENT_CANDIDATES", cand)
+        if p.cuda_is_init():
+            p.device_close()
+        p.device_init(N, 8)
+        pl = lib.debug_placement()
+        assert 1 <= pl["candidates"] <= int(cand), pl
+        if cand == "1":
+            assert pl["candidates"] == 1
+        else:
+            assert pl["candidates"] >= 2 and 0.0 < pl["chosen_probe_ms"] <= pl["slowest_probe_ms"], pl
+        p.photo_table_to_device(thin, thick)
+        x, phi = p.evolve3D(*args, *rest, logfile=str(tmp_path / cand), quiet=True)
+        out[cand] = (x, phi, p.evolve._evolve.last_niter)
+    assert out["1"][2] == out["6"][2]
+    np.testing.assert_allclose(out["6"][0], out["1"][0], rtol=1e-10, atol=0)
+    np.testing.assert_allclose(out["6"][1], out["1"][1], rtol=1e-10, atol=0)
+    monkeypatch.delenv("ASORA_PLACEMENT_CANDIDATES")
+    p.device_close()
+    p.device_init(16, 8)                                   # small meshes: the first allocation
+    assert lib.debug_placement()["candidates"] == 1
+    p.device_close()
+
+
 # ---- edge cases -----------------------------------------------------------------------------------------
 def _edge_case(p, lib, capi, N, pos, flux, R, tau_cell=0.1, seed=71, tables="soft", xh_override=None):
     nd, xh, dr = cases.grid(N, "lognormal", seed, tau_cell)
