@@ -693,13 +693,13 @@ extern "C" {
 // with one hipMalloc per grid the sets spread between the two, which is what earlier rounds recorded as the "state of the box":
 // fused pass 0.25 ... 0.31 ms from run to run).  Nothing a process can read tells the two kinds apart beforehand, so device_init
 // tries: up to ARENA_CANDIDATES allocations of the whole arena, three launches of a kernel with the pass's stream mix on each, the
-// fastest is kept and the others are freed (8 ms at 256^3, 30-80 ms at 512^3).  It stops early once it holds a candidate clearly
+// fastest is kept and the others are freed (8-30 ms at 256^3, 30-80 ms at 512^3, where a quarter of the free memory holds five candidates).  It stops early once it holds a candidate clearly
 // faster than another (both kinds seen).  On a box with both kinds, alternating processes (profiles/r05_ab_placement.txt): first
 // allocation taken 1.392-1.395 ms per step in five runs of six (fused pass 0.282, trace 1.079), probed 1.333-1.337 in six of six
 // (0.245, 1.060).  Meshes below 128^3 take the first allocation (their grids sit in the caches); ASORA_PLACEMENT_CANDIDATES=1 does
 // so always.
 // ---------------------------------------------------------------------------------------------
-constexpr int ARENA_CANDIDATES = 16;       // about one placement in five is of the fast kind where both occur: 0.8^16 = 3 % to miss it
+constexpr int ARENA_CANDIDATES = 32;       // one placement in eight to one in three is of the fast kind where both occur: (7/8)^32 = 1.4 % to miss it
 constexpr int ARENA_SLOTS = 14;            // ndens, xh, xh_av, temp, xh_intermed, 4 accumulators, nhi x 2, phi_ion x 2, staging
 __global__ void __launch_bounds__(256) placement_probe_kernel(char *arena, size_t slot, size_t n)
 {
@@ -724,7 +724,7 @@ static int choose_arena(State &st, size_t slot, int slots)
     if (st.N < 128) want = 1;
     size_t free_b = 0, all_b = 0;
     if (hipMemGetInfo(&free_b, &all_b) == hipSuccess && total > 0)
-        want = (int)std::max<size_t>(1, std::min<size_t>((size_t)want, (size_t)(0.5 * (double)free_b) / total));
+        want = (int)std::max<size_t>(1, std::min<size_t>((size_t)want, (size_t)(0.25 * (double)free_b) / total));     // (several ranks may share a GPU in tests)
     st.arena_candidates = 0; st.arena_probe_ms = st.arena_probe_worst_ms = 0.0;
     if (want == 1) {
         ASORA_HIP_TRY(hipMalloc(&st.arena, total));
