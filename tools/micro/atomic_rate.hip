@@ -40,9 +40,22 @@ int main(int argc, char **argv)
             requests += lines.size();
         }
     double *g; unsigned *d;
-    hipMalloc(&g, ncell * sizeof(double)); hipMemset(g, 0, ncell * sizeof(double));
     hipMalloc(&d, n * sizeof(unsigned)); hipMemcpy(d, h.data(), n * sizeof(unsigned), hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    // argv[3] = PLACEMENTS: the same stream of atomics on that many allocations of the target, all kept (each lies elsewhere):
+    // does the rate at which the memory side takes the requests depend on WHERE the target lies, as streaming does (placement_probe.hip)?
+    const int placements = argc > 3 ? atoi(argv[3]) : 1;
+    for (int pl = 0; pl + 1 < placements; ++pl) {
+        hipMalloc(&g, ncell * sizeof(double)); hipMemset(g, 0, ncell * sizeof(double));
+        adds<<<blocks, threads>>>(g, d, per_lane, 1.0);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int r = 0; r < 3; ++r) adds<<<blocks, threads>>>(g, d, per_lane, 1.0);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+        printf("placement %2d: %.3f ms per launch, %.3e requests/s\n", pl, ms, requests / (ms * 1e-3));
+    }
+    hipMalloc(&g, ncell * sizeof(double)); hipMemset(g, 0, ncell * sizeof(double));
     adds<<<blocks, threads>>>(g, d, per_lane, 1.0);
     hipDeviceSynchronize();
     hipEventRecord(e0);
