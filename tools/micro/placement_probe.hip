@@ -23,6 +23,15 @@ __global__ void __launch_bounds__(256) read_one(const double *__restrict__ a, do
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += __builtin_nontemporal_load(a + i);
     if (s == 12345.678) out[0] = s;
 }
+// one load per PAGE_BYTES of the twelve buffers (argv[2] = "t"): what address translation costs on this placement
+__global__ void __launch_bounds__(256) touch_pages(const double *const *bufs, size_t n, size_t stride, double *out)
+{
+    double s = 0.0;
+    const size_t pages = n / stride;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < 12 * pages; i += (size_t)gridDim.x * 256)
+        s += __builtin_nontemporal_load(bufs[i % 12] + (i / 12) * stride);
+    if (s == 12345.678) out[0] = s;
+}
 __global__ void __launch_bounds__(256) write_one(double *a, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a[i] = 0.0;
@@ -63,6 +72,21 @@ int main(int argc, char **argv)
             float best, worst;
             if (time_set(buf, best, worst)) return 1;
             printf("round %d set %d (first buffer at %p): %.3f ... %.3f ms = %.2f TB/s\n", round, s, (void *)buf[0], best, worst, 12.0 * n * 8 / best * 1e-9);
+            if (argc > 2 && argv[2][0] == 't') {
+                const double **dl = nullptr; CK(hipMalloc(&dl, 12 * sizeof(double *))); CK(hipMemcpy(dl, buf, 12 * sizeof(double *), hipMemcpyHostToDevice));
+                printf("   one load per 4 KiB / 64 KiB / 2 MiB of every buffer, us:");
+                for (size_t stride : {(size_t)512, (size_t)8192, (size_t)262144}) {
+                    float b = 1e9f;
+                    for (int rep = 0; rep < 6; ++rep) {
+                        float ms;
+                        CK(hipEventRecord(t0)); hipLaunchKernelGGL(touch_pages, dim3(256), dim3(256), 0, 0, (const double *const *)dl, n, stride, buf[0]); CK(hipEventRecord(t1)); CK(hipEventSynchronize(t1));
+                        CK(hipEventElapsedTime(&ms, t0, t1)); if (rep && ms < b) b = ms;
+                    }
+                    printf(" %.1f", b * 1e3);
+                }
+                printf("\n");
+                CK(hipFree(dl));
+            }
             if (argc > 2 && argv[2][0] == 'p') {       // every buffer of the set by itself: read it, write it (microseconds, best of 6)
                 printf("   per buffer read/write us:");
                 for (int q = 0; q < 12; ++q) {
