@@ -56,10 +56,13 @@ CHEM_FUSED_BYTES_PER_UPDATE = 88                   # the fused pass on a uniform
                                                    # + 6 stores; 96 with a temperature grid that has to be read
 
 
-def make_tables():
+def make_tables(numtau=NUMTAU):
+    """Teff = 1e5 K black-body tables over log10(tau) in [-20, 4].  numtau = 20000: the benchmark's parameter file
+    (ref: test/paper_tests/raytracing_benchmark/parameters.yml:73-77); 2000: the reference's production parameter files
+    (ref: test/paper_eor_simulation/parameters.yml:75)."""
     from pyc2ray_amd.radiation import BlackBodySource, make_tau_table
     ev2fr = 0.241838e15
-    tau, dlog = make_tau_table(MINLOGTAU, MAXLOGTAU, NUMTAU)
+    tau, dlog = make_tau_table(MINLOGTAU, MAXLOGTAU, numtau)
     src = BlackBodySource(1e5, False, ev2fr * 13.598, 2.8)
     thin, thick = src.make_photo_table(tau, ev2fr * 13.598, 10 * ev2fr * 54.416, 1e48)
     return thin, thick, dlog
@@ -372,7 +375,18 @@ def evolving_state(lib, p, _capi, N, R, thin, thick, dlog, numtau, flux_scale=1e
     lib.set_option(_capi.OPT_TIMING, 0)
     rt = [r[0] for r in rows2]
     ch = [r[1] for r in rows2]
+    # the same accounting as the headline's roofline: 32 B per rate-receiving pair, 16 B for a pair whose exactly-zero rate was
+    # not added
+    # (summed over the launches since evolve_begin: per launch)
+    gamma_cells = lib.last_raytrace_counts()[0] // max(len(rows2), 1)
+    zero_cells = lib.last_raytrace_zero_rates() // max(len(rows2), 1)
+    rt_bytes = RT_BYTES_PER_UPDATE * (gamma_cells - zero_cells) + (RT_BYTES_PER_UPDATE - 16) * zero_cells
+    rt_GBs = rt_bytes / (float(np.mean(rt)) * 1e-3) / 1e9
+    ch_GBs = CHEM_BYTES_PER_UPDATE * N ** 3 / (float(np.mean(ch)) * 1e-3) / 1e9
     return {
+        "roofline_frac": rt_GBs / HBM_PEAK_GBS, "raytrace_achieved_GBs": rt_GBs,
+        "fused_pass_roofline_frac": ch_GBs / HBM_PEAK_GBS,
+        "raytrace_pairs_per_launch": int(gamma_cells), "exact_zero_rates_not_added": int(zero_cells), "numtau": int(numtau),
         "workload": f"BASELINE configs[3] ({N}^3 log-normal, {nsrc} sources on the densest cells, r_RT={R:g}), fluxes x {flux_scale:g}, "
                     "dt = 1 Myr: the SECOND time step, which starts with the fronts of the first",
         "ionised_volume_fraction_at_start": float((x1 > 0.5).mean()), "mean_x_at_start": float(x1.mean()),
@@ -590,6 +604,9 @@ def main():
                     help="N>1, slab exchange: trace chunks per step; planes final after a chunk travel while the next is traced "
                          "(1 = no overlap; 0 = TorchComm's default: 2 with two ranks, else 1)")
     ap.add_argument("--R", type=float, default=32.0)
+    ap.add_argument("--numtau", type=int, default=NUMTAU,
+                    help="entries of the rate tables: 20000 = the benchmark's parameter file (default, BASELINE configs[2]); 2000 = the "
+                         "reference's production parameter files (the tables then fit LDS: ASORA_OPT_LDS_TABLES)")
     ap.add_argument("--workload", choices=["uniform", "cosmo"], default=None,
                     help="default: uniform (configs[2]) on one GPU, cosmo (configs[3]) on several")
     ap.add_argument("--cpu-sources", type=int, default=512,
@@ -649,7 +666,7 @@ def main():
                 cpu_note = f"{cpu_cores} workers wanted, {capped} fit half of the {room / 2**30:.0f} GiB this process may use"
                 cpu_cores = capped
             if cpu_cores > 1:
-                tables = make_tables()
+                tables = make_tables(args.numtau)
                 workload = make_workload(args.workload, N, nsrc_total)
                 cpu_workers, cpu_dir = start_cpu_workers(cpu_cores, workload, N, args.R,
                                                          min(nsrc_total, max(args.cpu_sources, 16 * cpu_cores)), tables)
@@ -723,7 +740,7 @@ def main():
         pass
     lib = load_asora()
     p.device_init(N, 64, device_id=int(os.environ.get("PYC2RAY_AMD_BENCH_DEVICE", local_rank)))
-    thin, thick, dlog = tables if tables is not None else make_tables()
+    thin, thick, dlog = tables if tables is not None else make_tables(args.numtau)
     p.photo_table_to_device(thin, thick)
     numtau = thin.shape[0] - 1                  # as raytracing_benchmark/run_test.py:85 passes it
 
@@ -1043,7 +1060,7 @@ def main():
     achieved = rt_bytes / rt_launch_s / 1e9 if rt_n else None
     achieved_all32 = RT_BYTES_PER_UPDATE * gamma_cells / rt_launch_s / 1e9 if rt_n else None
     insphere = 4.0 * np.pi * args.R ** 3 / 3.0
-    default_job = (args.workload == "uniform" and args.R == 32.0 and N == 256 and args.nsrc == 1000 and world == 1)
+    default_job = (args.workload == "uniform" and args.R == 32.0 and N == 256 and args.nsrc == 1000 and world == 1 and args.numtau == NUMTAU)
     # counters: only from a committed summary collected on THIS build of the library (find_pmc_summary)
     build_id = lib.build_id()
     pmc_summary, pmc_missing = find_pmc_summary(build_id) if default_job else (None, "counters are committed for the default job only")
@@ -1080,14 +1097,15 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": workload_label(args.workload, N, nsrc_total, args.R, world, strong),
-            "grid": N, "sources_total": nsrc_total, "sources_rank0": n_local, "R_cells": args.R, "numtau": NUMTAU,
+            "grid": N, "sources_total": nsrc_total, "sources_rank0": n_local, "R_cells": args.R, "numtau": args.numtau,
             "host_cores": topo["logical_cpus"], "host_cpus_this_process_may_use": topo["usable_cpus"],
             "visible_gpus": visible_gpus, "world_size_reported_by_backend": backend_world,
             "launched_by": ("bench.py itself (child torch.distributed.run)" if os.environ.get("PYC2RAY_AMD_BENCH_SELF_LAUNCHED") == "1"
                             else "an external launcher" if "WORLD_SIZE" in os.environ else "plain python"),
             "library_build_id": lib.build_id(),
-            # where device_init put the grids: allocations of the whole arena tried, probe time (a kernel with the fused pass's stream
-            # mix) of the one kept and of the slowest -- placements differ by ~15 % on one box (csrc/api.hip choose_arena)
+            # where device_init put the grids: allocations of the whole arena tried (at most 8 by default), probe time (a kernel with
+            # the fused pass's stream mix) of the one kept and of the slowest -- placements differ by ~15 % on some boxes, not at all
+            # on others (csrc/api.hip choose_arena) -- and what device_init and, inside it, the probe cost on the host clock
             "grid_placement": lib.debug_placement(),
             "ranks_agree_on_rates_and_ionised_fraction": ranks_agree,
             "parallelism": ("single GPU" if world == 1 else
@@ -1142,14 +1160,22 @@ def main():
                                 f"({zero_cells} of {gamma_cells} pairs in this launch)",
             "avg_launch_ms": rt_ms / max(rt_n, 1),
             "launches_timed": rt_n,
-            "binding_resource": ("the memory-side rate atomics: every double added to the rate grid leaves the L2 in a 64-B atomic request "
-                                 "(TCC_EA0_ATOMIC %.3g per launch, %s: %.2f doubles each; 6.41 is what whole rows of the sphere give), and "
-                                 "the memory side takes %.3g of them per second (%s); `atomic_requests.frac` in roofline_kernels is this "
-                                 "launch against that ceiling.  Next the FP64/integer VALU stream (%.3g wave-instructions per launch, "
-                                 "`valu_issue`); HBM bytes are not close (`traffic`).  DESIGN.md 7"
-                                 % (rt_counters.get("TCC_EA0_ATOMIC_sum", float("nan")), PMC_SUMMARY,
+            # what the launch is bound by, as this build's OWN ablation has it (a diagnostic build of the same kernel,
+            # make EXTRA=-DASORA_ENABLE_ABLATION: profiles/r04_ablate_R16_R32.txt, `--R 32 ablate 0/1/3`)
+            "binding_resource": ("co-limited three ways within 10 %%, none saturated.  Ablation on this workload (diagnostic build, wrong results by "
+                                 "design): 1.107 ms as built, 1.010 ms with the rate atomics removed, 0.993 ms with the rates removed as well -- the "
+                                 "floor is the SWEEP ITSELF: %.3g VALU wave-instructions per launch (`valu_issue.frac` of issue at 4 cycles each) "
+                                 "run at two waves per SIMD -- the four shell buffers of a workgroup (two sources x two shells, 13.4 KB each) cap a "
+                                 "CU at two workgroups of four waves, 128 VGPRs cap a SIMD at four -- so every wave waits out its own chain LDS "
+                                 "read -> interpolation -> division -> LDS write -> shell barrier.  Second, the memory-side rate atomics: every double "
+                                 "added to the rate grid leaves the L2 in a 64-B atomic request (TCC_EA0_ATOMIC %.3g per launch, %s: %.2f doubles each; "
+                                 "6.41 is what whole rows of the sphere give) against %.3g per second the memory side takes (%s; "
+                                 "`atomic_requests.frac`): worth the 9 %% the ablation shows, not more.  Third, the four divergent 16-B rate-table "
+                                 "gathers per cell: +20 %% on a field with fronts (`evolving_state.roofline_frac`).  HBM bytes are not close "
+                                 "(`traffic` = 0.97 x algorithmic).  DESIGN.md 7"
+                                 % (rt_counters.get("SQ_INSTS_VALU", float("nan")), rt_counters.get("TCC_EA0_ATOMIC_sum", float("nan")), PMC_SUMMARY,
                                     gamma_cells / rt_counters.get("TCC_EA0_ATOMIC_sum", float("nan")), ATOMIC_REQUEST_CEILING,
-                                    ATOMIC_CEILING_SOURCE, rt_counters.get("SQ_INSTS_VALU", float("nan"))))
+                                    ATOMIC_CEILING_SOURCE))
                                 if (default_job and "TCC_EA0_ATOMIC_sum" in rt_counters) else None,
         },
         "roofline_kernels": [
@@ -1164,8 +1190,8 @@ def main():
                              "achieved_per_s": rt_counters["SQ_INSTS_VALU"] / rt_launch_s, "peak_per_s": 1024 * 2.4e9 / 4.0,
                              "frac": rt_counters["SQ_INSTS_VALU"] / rt_launch_s / (1024 * 2.4e9 / 4.0), "source": PMC_SUMMARY}
                             if (default_job and "SQ_INSTS_VALU" in rt_counters and rt_n) else None),
-             # what binds the launch: 64-B atomic requests leaving the L2 (committed counters) over this run's launch time,
-             # against the rate a bare stream of such atomics reaches (tools/micro/atomic_rate.hip)
+             # one of the launch's three co-limits (`roofline.binding_resource`): 64-B atomic requests leaving the L2 (committed counters)
+             # over this run's launch time, against the rate a bare stream of such atomics reaches (tools/micro/atomic_rate.hip)
              "atomic_requests": ({"requests_per_launch": rt_counters["TCC_EA0_ATOMIC_sum"],
                                   "achieved_per_s": rt_counters["TCC_EA0_ATOMIC_sum"] / rt_launch_s, "ceiling_per_s": ATOMIC_REQUEST_CEILING,
                                   "frac": rt_counters["TCC_EA0_ATOMIC_sum"] / rt_launch_s / ATOMIC_REQUEST_CEILING,

@@ -364,7 +364,17 @@ enum {
      * holds, and the checker of the device-side builder, geometry_device.hip, which is what runs by default and produces the
      * same tables bit for bit -- tests/test_gpu_geometry.py) */
     ASORA_OPT_GEOMETRY_ON_HOST = 16,
-    ASORA_OPT_COUNT = 17
+    /* How many allocations of the grid arena asora_device_init may try before it keeps the one on which a kernel with the fused
+     * pass's stream mix runs fastest (api.hip choose_arena; set BEFORE device_init): 0 (default) = up to 8, 1 = take the first
+     * allocation (memory-tight or shared-GPU runs), n = up to n (at most 32).  Whatever the value, what is held during the probe
+     * stays within an eighth of the free device memory, and the probe stops once it holds a placement 7 % faster than another
+     * or has seen four within 3 % of each other.  Same results on any placement. */
+    ASORA_OPT_PLACEMENT_CANDIDATES = 17,
+    /* raytrace: the photo-ionisation rate tables in LDS instead of global memory when both fit (NumTau <= 2048, the size of the
+     * reference's production parameter files: ref test/paper_eor_simulation/parameters.yml:75), so that the four table gathers
+     * of a cell never leave the CU.  0 = the library decides, 1 = never, 2 = whenever the variant exists.  Same bits. */
+    ASORA_OPT_LDS_TABLES = 18,
+    ASORA_OPT_COUNT = 19
 };
 int asora_set_option(int option, int value);
 int asora_get_option(int option);
@@ -412,6 +422,8 @@ int asora_last_raytrace_variant(void);
 size_t asora_debug_geometry_bytes(void);
 /* How device_init placed the grids (api.hip choose_arena): allocations tried, probe time of the one kept and of the slowest. */
 void asora_debug_placement(int *candidates, double *chosen_probe_ms, double *slowest_probe_ms);
+/* Host wall clock (ms) of the last asora_device_init and, inside it, of the placement probe (0 when the first allocation was taken). */
+void asora_debug_init_cost(double *device_init_ms, double *placement_probe_ms);
 int asora_debug_geometry_table(int table, uint32_t *words, size_t capacity_entries, size_t *entries, int *nsteps, int *ntables,
                                int *shells, int *max_cells, int *threads);
 

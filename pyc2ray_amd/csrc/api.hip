@@ -5,6 +5,7 @@
 #include "rates_device.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
@@ -692,14 +693,21 @@ extern "C" {
 // a fifth to a third of them, stable for the life of the allocation (tools/micro/placement_probe.hip; some boxes offer one kind only;
 // with one hipMalloc per grid the sets spread between the two, which is what earlier rounds recorded as the "state of the box":
 // fused pass 0.25 ... 0.31 ms from run to run).  Nothing a process can read tells the two kinds apart beforehand, so device_init
-// tries: up to ARENA_CANDIDATES allocations of the whole arena, three launches of a kernel with the pass's stream mix on each, the
-// fastest is kept and the others are freed (8-30 ms at 256^3, 30-80 ms at 512^3, where a quarter of the free memory holds five candidates).  It stops early once it holds a candidate clearly
-// faster than another (both kinds seen).  On a box with both kinds, alternating processes (profiles/r05_ab_placement.txt): first
-// allocation taken 1.392-1.395 ms per step in five runs of six (fused pass 0.282, trace 1.079), probed 1.333-1.337 in six of six
-// (0.245, 1.060).  Meshes below 128^3 take the first allocation (their grids sit in the caches); ASORA_PLACEMENT_CANDIDATES=1 does
-// so always.
+// tries a FEW allocations of the whole arena, three launches of a kernel with the pass's stream mix on each, keeps the fastest and
+// frees the others.  Round 6 bounds (round 5 tried up to 32 within a quarter of the free memory: 56 GB and 96 probe launches on a
+// box of one kind, for a 4 % spread):
+//   * at most ASORA_OPT_PLACEMENT_CANDIDATES allocations (0 = default 8; 1 = take the first; the environment variable
+//     ASORA_PLACEMENT_CANDIDATES does the same for a process that cannot call asora_set_option before device_init);
+//   * what is held during the probe stays within an EIGHTH of the free device memory (512^3: two candidates of 14 GiB);
+//   * it stops as soon as it holds a candidate 7 % faster than another (both kinds seen, one of the fast kind in hand), and after
+//     four candidates within 3 % of each other (a box of one kind: nothing to find).
+// The losers are held until the probe ends: a freed arena's pages are what the next allocation of that size gets back, so
+// freeing as it goes would time the same placement again and again.  Meshes below 128^3 take the first allocation (their grids
+// sit in the caches).  asora_debug_placement reports what was tried and what the probe cost.
+// On a box with both kinds, alternating processes (profiles/r05_ab_placement.txt): first allocation taken 1.392-1.395 ms per step
+// in five runs of six (fused pass 0.282, trace 1.079), probed 1.333-1.337 in six of six (0.245, 1.060; 2-6 candidates tried).
 // ---------------------------------------------------------------------------------------------
-constexpr int ARENA_CANDIDATES = 32;       // one placement in eight to one in three is of the fast kind where both occur: (7/8)^32 = 1.4 % to miss it
+constexpr int ARENA_CANDIDATES = 8;        // default bound (one placement in eight to one in three is of the fast kind where both occur)
 constexpr int ARENA_SLOTS = 14;            // ndens, xh, xh_av, temp, xh_intermed, 4 accumulators, nhi x 2, phi_ion x 2, staging
 __global__ void __launch_bounds__(256) placement_probe_kernel(char *arena, size_t slot, size_t n)
 {
@@ -718,14 +726,16 @@ __global__ void __launch_bounds__(256) placement_probe_kernel(char *arena, size_
 
 static int choose_arena(State &st, size_t slot, int slots)
 {
+    const auto wall0 = std::chrono::steady_clock::now();
     const size_t total = slot * (size_t)slots;
-    int want = ARENA_CANDIDATES;
+    int want = st.opt[ASORA_OPT_PLACEMENT_CANDIDATES] > 0 ? st.opt[ASORA_OPT_PLACEMENT_CANDIDATES] : ARENA_CANDIDATES;
     if (const char *e = getenv("ASORA_PLACEMENT_CANDIDATES")) want = std::max(1, atoi(e));
+    want = std::min(want, 32);
     if (st.N < 128) want = 1;
     size_t free_b = 0, all_b = 0;
-    if (hipMemGetInfo(&free_b, &all_b) == hipSuccess && total > 0)
-        want = (int)std::max<size_t>(1, std::min<size_t>((size_t)want, (size_t)(0.25 * (double)free_b) / total));     // (several ranks may share a GPU in tests)
-    st.arena_candidates = 0; st.arena_probe_ms = st.arena_probe_worst_ms = 0.0;
+    if (want > 1 && hipMemGetInfo(&free_b, &all_b) == hipSuccess && total > 0)
+        want = (int)std::max<size_t>(1, std::min<size_t>((size_t)want, (size_t)(0.125 * (double)free_b) / total));     // (several ranks may share a GPU)
+    st.arena_candidates = 0; st.arena_probe_ms = st.arena_probe_worst_ms = st.arena_probe_wall_ms = 0.0;
     if (want == 1) {
         ASORA_HIP_TRY(hipMalloc(&st.arena, total));
         st.arena_bytes = total; st.arena_candidates = 1;
@@ -756,6 +766,7 @@ static int choose_arena(State &st, size_t slot, int slots)
         if (best < 0 || t < ms[(size_t)best]) best = c;
         worst = std::max(worst, t);
         if (c >= 1 && ms[(size_t)best] <= 0.93f * worst) break;     // both kinds seen, and one of the fast kind in hand
+        if (c >= 3 && ms[(size_t)best] >= 0.97f * worst) break;     // four of one kind: a box that has nothing else to offer
     }
     (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
     if (best < 0) return fail(2, "device_init: out of device memory for the grids");
@@ -764,6 +775,7 @@ static int choose_arena(State &st, size_t slot, int slots)
     st.arena_bytes = total;
     st.arena_candidates = (int)cand.size();
     st.arena_probe_ms = ms[(size_t)best]; st.arena_probe_worst_ms = worst;
+    st.arena_probe_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     return 0;
 }
 
@@ -774,12 +786,19 @@ void asora_debug_placement(int *candidates, double *chosen_probe_ms, double *slo
     if (slowest_probe_ms) *slowest_probe_ms = g_state.arena_probe_worst_ms;
 }
 
+void asora_debug_init_cost(double *device_init_ms, double *placement_probe_ms)
+{
+    if (device_init_ms) *device_init_ms = g_state.device_init_wall_ms;
+    if (placement_probe_ms) *placement_probe_ms = g_state.arena_probe_wall_ms;
+}
+
 const char *asora_last_error(void) { return g_error.c_str(); }
 
 int asora_device_init_ex(int N, int num_src_par, int device_id)
 {
     clear_error();
     State &st = g_state;
+    const auto init_wall0 = std::chrono::steady_clock::now();
     // validate everything first: a refused re-initialisation leaves the working state as it was
     if (N < 2 || N > 1280) return fail(1, "device_init: N must be in [2, 1280] (32-bit cell indices over 2 N^3)");
     if (st.stream && device_id != st.device) return fail(1, "device_init: the device cannot change within a process");
@@ -819,6 +838,7 @@ int asora_device_init_ex(int N, int num_src_par, int device_id)
         if (int rc = ensure_red_capacity(3 * worst)) return rc;
     }
     st.init = true;
+    st.device_init_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - init_wall0).count();
     return 0;
 }
 
@@ -1438,7 +1458,8 @@ static int evolve_begin_impl(double dt, double bh00, double albpow, double colh0
                           st.reach_src_count == src_count && st.reach_R == R;
         // where the spheres together hold more cells than the box, (nearly) every line is reached: the mask can not pay and is
         // not built (in a cosmological run R changes every step, and every build ends with a blocking read-back)
-        const bool covers = possible && (double)src_count * (4.0 / 3.0) * 3.14159265358979 * R * R * R >= (double)st.ncell;
+        // (forced use, ASORA_REACH_MASK=2, always builds it: a mask in use must be the mask of THIS source set and radius)
+        const bool covers = possible && mode != 2 && (double)src_count * (4.0 / 3.0) * 3.14159265358979 * R * R * R >= (double)st.ncell;
         if (possible && !same && covers) {
             st.reach_pays = false;
             st.reach_valid = true; st.reach_src_generation = st.src_generation; st.reach_src_begin = src_begin;

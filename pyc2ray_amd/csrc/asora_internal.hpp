@@ -224,6 +224,7 @@ struct State {
     size_t arena_bytes = 0;
     int arena_candidates = 0;               // how many were tried
     double arena_probe_ms = 0.0, arena_probe_worst_ms = 0.0;     // the chosen one's probe time, the slowest candidate's
+    double arena_probe_wall_ms = 0.0, device_init_wall_ms = 0.0; // host wall clock of the whole probe / of the last device_init
     int ev_base = 0;                        // set of the first iteration of the current time step
     bool ev_clean[2] = {false, false};      // set known to be all zero (when nothing is enqueued)
     bool ev_sets_known = false;             // the bookkeeping above is valid (a poll has happened since the last enqueue)
@@ -265,7 +266,7 @@ struct State {
     struct PendingTimer { int which; hipEvent_t e0, e1; };
     std::vector<PendingTimer> pending_timers;     // recorded, not yet resolved
     std::vector<hipEvent_t> free_events;
-    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
+    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0};
     double k_ms[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
     long k_n[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
 };

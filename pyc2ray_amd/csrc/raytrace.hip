@@ -387,17 +387,19 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     // fourth wave per SIMD of the paired kernels).
     const bool unit_in_twin = SPLIT && ztr_desc(p, uinfo);
     const unsigned desc_cells = SPLIT ? p.ncell : 2u * p.ncell;
-    const int desc_off8 = (SPLIT && unit_in_twin) ? -(int)(8u * p.ncell) : 0;
+    // (subtracted in UNSIGNED arithmetic and cast once: at N = 576 idx * 8 reaches 3.0e9 and the layout's offset 1.5e9 -- as signed
+    //  ints their sum would overflow, which the hardware wraps but the language leaves undefined)
+    const unsigned desc_off8 = (SPLIT && unit_in_twin) ? 8u * (unsigned)p.ncell : 0u;
     __amdgpu_buffer_rsrc_t rs_phi = __builtin_amdgcn_make_buffer_rsrc(p.phi + (unit_in_twin ? p.ncell : 0u), 0, BUFATOM ? (int)(8u * desc_cells) : 0, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_heat = __builtin_amdgcn_make_buffer_rsrc((HEAT ? p.heat : p.phi) + (unit_in_twin ? p.ncell : 0u), 0, (BUFATOM && HEAT) ? (int)(8u * desc_cells) : 0, 0x00020000);
     auto add_phi = [&](bool ok, unsigned idx, double v) {
         if (ASORA_ABLATED(1)) ok = ok && v == 1.2345e-300;
         if (ASORA_ABLATED(64)) idx &= 0xFFFFu;            // diagnostic: all rates into a 512 KiB window (wrong results)
-        if (BUFATOM) (void)asora_buffer_atomic_fadd_f64(v, rs_phi, ok ? (int)(idx * 8u) + desc_off8 : ASORA_OOB_OFFSET, 0, 0);
+        if (BUFATOM) (void)asora_buffer_atomic_fadd_f64(v, rs_phi, ok ? (int)(idx * 8u - desc_off8) : ASORA_OOB_OFFSET, 0, 0);
         else if (ok) unsafeAtomicAdd(p.phi + idx, v);
     };
     auto add_heat = [&](bool ok, unsigned idx, double v) {
-        if (BUFATOM) (void)asora_buffer_atomic_fadd_f64(v, rs_heat, ok ? (int)(idx * 8u) + desc_off8 : ASORA_OOB_OFFSET, 0, 0);
+        if (BUFATOM) (void)asora_buffer_atomic_fadd_f64(v, rs_heat, ok ? (int)(idx * 8u - desc_off8) : ASORA_OOB_OFFSET, 0, 0);
         else if (ok) unsafeAtomicAdd(p.heat + idx, v);
     };
     // BUFATOM: a pending rate is carried as the byte offset its atomic will use -- ASORA_OOB_OFFSET when the lane has nothing
@@ -773,7 +775,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
 #pragma unroll
                 for (int q = 0; q < NSRC; ++q) {
                     pend_A[q] = A2[q]; pend_B[q] = B2[q]; pend_thick[q] = thick[q]; pend_pref[q] = pref[q]; pend_dtau[q] = dtau[q];
-                    if (BUFATOM) late_off[q] = add[q] ? (int)(dst_idx[q] * 8u) + desc_off8 : ASORA_OOB_OFFSET;
+                    if (BUFATOM) late_off[q] = add[q] ? (int)(dst_idx[q] * 8u - desc_off8) : ASORA_OOB_OFFSET;
                     else { late_idx[q] = dst_idx[q]; late_ok[q] = add[q]; }
                 }
             }

@@ -343,6 +343,11 @@ class TorchComm:
     def _backend(self):
         return self._dist.get_backend(self._group)
 
+    @property
+    def backend(self):
+        """"nccl" (RCCL: exchanges on the device, batches of iterations per host round trip) or "gloo" (through the host)."""
+        return self._backend()
+
     def _tensor_of(self, arr):
         import torch
         t = torch.from_numpy(np.ascontiguousarray(arr))

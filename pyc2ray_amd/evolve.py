@@ -27,6 +27,45 @@ __all__ = ['evolve3D', 'evolve3D_MPI', 'evolve3D_resident']
 EVOLVE_BATCH = int(os.environ.get("PYC2RAY_AMD_EVOLVE_BATCH", "8"))
 
 
+def _comm_backend(comm):
+    """"nccl" / "gloo" of a pyc2ray_amd.dist.TorchComm-shaped communicator (public `backend`; older objects: `_backend()`);
+    anything else exchanges through the host like gloo."""
+    b = getattr(comm, "backend", None)
+    if callable(b):
+        b = b()
+    if b is None and hasattr(comm, "_backend"):
+        b = comm._backend()
+    return b if isinstance(b, str) else "gloo"
+
+
+def _next_batch(history, batch_max, conv_criterion, convergence_fraction):
+    """How many iterations of a multi-rank device loop to enqueue before the next poll.  The launches of an iteration are gated
+    by the device's `done` flag, its collectives are not: an iteration enqueued beyond convergence still exchanges its planes
+    (slab path) or all-reduces the N^3 out-box (all-reduce path).  So the batch follows the distance to the test of
+    evolve.py:232: `history` = the rows polled so far (conv_flag, sum1, sum0, rel1, rel0); both criteria decay roughly
+    geometrically from iteration to iteration, and the batch is the number of iterations the faster of the two still needs at
+    the rate of the last two rows -- at least 1, at most batch_max, and 2 while there is nothing to extrapolate from.  Every
+    rank sees the same rows, hence the same batch."""
+    import math
+    if batch_max <= 1:
+        return 1
+    if len(history) < 2:
+        return min(2, batch_max)
+
+    def remaining(prev, last, target):
+        if last < target:
+            return 0
+        if not (0.0 < last < prev):
+            return batch_max
+        rate = last / prev
+        return max(1, int(math.ceil(math.log(max(target, 1e-300) / last) / math.log(rate))))
+
+    (f0, _, _, r10, r00), (f1, _, _, r11, r01) = history[-2], history[-1]
+    by_change = max(remaining(r10, r11, convergence_fraction), remaining(r00, r01, convergence_fraction))
+    by_count = remaining(float(f0), float(f1), float(conv_criterion)) if conv_criterion > 0 else batch_max
+    return max(1, min(batch_max, by_change, by_count))
+
+
 def _agree_on_convergence(comm, converged):
     """Rank 0 decides, everyone follows (pyc2ray/evolve.py:484-489).  Every rank derives `converged` from the same
     summed rates, but a collective that sums in a rank-dependent order could leave them one ulp apart; a rank that
@@ -225,8 +264,9 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
     niter = 0
 
     # source shard of this rank, evolve.py:360-371
+    # (the sharded device loop needs the [k][j][i] twins, asora_evolve_begin_slab: not with ASORA_OPT_Z_TRANSPOSED = 0)
     slab = (distributed and hasattr(comm, "slab_enqueue") and getattr(comm, "exchange", "") == "slab"
-            and not getattr(comm, "overlap", False))
+            and not getattr(comm, "overlap", False) and libasora.get_option(_capi.OPT_Z_TRANSPOSED) != 0)
     plan = None
     all_pos, all_flux = np.asarray(src_pos), src_flux
     if slab:
@@ -293,11 +333,14 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
         # goes through the host anyway and the batch is one.
         comm.slab_begin(libasora, plan, N, R_max_LLS, sig, dr, NumSrc_local, minlogtau, dlogtau, NumTau, chem,
                         conv_criterion, convergence_fraction)
-        batch = max(1, min(EVOLVE_BATCH, 32)) if comm._backend() == "nccl" else 1
+        batch_max = max(1, min(EVOLVE_BATCH, 32)) if _comm_backend(comm) == "nccl" else 1
+        history = []
         while not converged:
             trt0 = time.time()
+            batch = _next_batch(history, batch_max, conv_criterion, convergence_fraction)
             comm.slab_enqueue(libasora, batch)
             _, converged, rows = comm.slab_poll(libasora, batch)
+            history += list(rows)
             per_iteration = (time.time() - trt0) / max(len(rows), 1)
             lines = []
             for conv_flag, _s1, _s0, rel_change_xh1, _rel0 in rows:
@@ -312,16 +355,23 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
 
     # full-grid all-reduce on the same device-resident loop (TorchComm.reduce_begin): trace, fold, all-reduce of the rate grid in
     # place, ONE fused pass on the whole grid on every rank, test on the device -- batches of iterations per host round trip
+    # (asora_evolve_begin_slab needs the [k][j][i] twins: with ASORA_OPT_Z_TRANSPOSED = 0 the three-call loop below runs)
     reduce_loop = (distributed and not slab and not pipelined and getattr(comm, "device_loop", False)
-                   and hasattr(comm, "reduce_begin") and hasattr(libasora, "evolve_slab_fold_all"))
+                   and hasattr(comm, "reduce_begin") and hasattr(libasora, "evolve_slab_fold_all")
+                   and libasora.get_option(_capi.OPT_Z_TRANSPOSED) != 0)
     if reduce_loop:
         comm.reduce_begin(libasora, N, R_max_LLS, sig, dr, NumSrc_local, minlogtau, dlogtau, NumTau, chem, conv_criterion,
                           convergence_fraction)
-        batch = max(1, min(EVOLVE_BATCH, 32)) if comm._backend() == "nccl" else 1
+        batch_max = max(1, min(EVOLVE_BATCH, 32)) if _comm_backend(comm) == "nccl" else 1
+        history = []
         while not converged:
             trt0 = time.time()
+            # (an all-reduce is not gated by the device's `done` flag: every iteration enqueued beyond convergence still sums
+            #  the N^3 out-box over the ranks, so the batch shrinks as the test comes within reach)
+            batch = _next_batch(history, batch_max, conv_criterion, convergence_fraction)
             comm.slab_enqueue(libasora, batch)
             _, converged, rows = comm.slab_poll(libasora, batch)
+            history += list(rows)
             per_iteration = (time.time() - trt0) / max(len(rows), 1)
             lines = []
             for conv_flag, _s1, _s0, rel_change_xh1, _rel0 in rows:

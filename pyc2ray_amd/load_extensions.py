@@ -44,17 +44,23 @@ class _LibAsora:
 
     # ---- the six reference methods --------------------------------------------------------
     def device_init(self, N, num_src_par, device_id=None):
+        # PYC2RAY_AMD_OPTIONS="13=2,14=2": library options (asora_set_option; the numbers are those of include/asora_hip.h) applied
+        # around every device_init -- before it for the ones device_init itself reads (17: placement candidates), after it as
+        # well.  For running an existing script or the test suite with a non-default variant.
+        import os
+
+        def apply_env_options():
+            for item in filter(None, os.environ.get("PYC2RAY_AMD_OPTIONS", "").split(",")):
+                opt, _, val = item.partition("=")
+                self.set_option(int(opt), int(val))
+
+        apply_env_options()
         if device_id is None:
             _capi.check(self._lib.asora_device_init(int(N), int(num_src_par)), "device_init")
         else:
             _capi.check(self._lib.asora_device_init_ex(int(N), int(num_src_par), int(device_id)), "device_init")
         self._N = int(N)
-        # PYC2RAY_AMD_OPTIONS="13=2,14=2": library options applied after every device_init (asora_set_option; the numbers are
-        # those of include/asora_hip.h).  For running an existing script or the test suite with a non-default variant.
-        import os
-        for item in filter(None, os.environ.get("PYC2RAY_AMD_OPTIONS", "").split(",")):
-            opt, _, val = item.partition("=")
-            self.set_option(int(opt), int(val))
+        apply_env_options()
 
     def device_close(self):
         _capi.check(self._lib.asora_device_close(), "device_close")
@@ -262,7 +268,10 @@ class _LibAsora:
         """How device_init placed the grids: {candidates tried, probe ms of the allocation kept, of the slowest one}."""
         n, a, b = C.c_int(0), C.c_double(0.0), C.c_double(0.0)
         self._lib.asora_debug_placement(C.byref(n), C.byref(a), C.byref(b))
-        return {"candidates": n.value, "chosen_probe_ms": a.value, "slowest_probe_ms": b.value}
+        t, pr = C.c_double(0.0), C.c_double(0.0)
+        self._lib.asora_debug_init_cost(C.byref(t), C.byref(pr))
+        return {"candidates": n.value, "chosen_probe_ms": a.value, "slowest_probe_ms": b.value,
+                "device_init_ms": t.value, "probe_cost_ms": pr.value}
 
     def evolve_slab_fold_all(self):
         _capi.check(self._lib.asora_evolve_slab_fold_all(), "evolve_slab_fold_all")

@@ -44,5 +44,5 @@ for resident in (False, True):
     out["device_resident" if resident else "default"] = {"ms_per_time_step": t / a.steps * 1e3, "outer_iterations": iters,
                                                          "mean_x_after": mean_x}
 out["speedup"] = out["default"]["ms_per_time_step"] / out["device_resident"]["ms_per_time_step"]
-print(json.dumps(out))
+print(json.dumps(out))          # (the log lines of C2Ray_Test go to its logfile and to stdout: keep the LAST line)
 pc2r.device_close()
