@@ -134,6 +134,9 @@ int asora_grid_to_device(int which, const double *host, int N, char order);
 int asora_grid_to_host(int which, double *host, int N, char order);
 /* Device-to-device copy between two grids (e.g. xh -> xh_av at the start of a step). */
 int asora_grid_copy(int dst, int src);
+/* grid *= factor on the device: the dilution of a device-resident density in a cosmological run
+ * (ref: pyc2ray/c2ray_base.py:244-248 scales the host array). */
+int asora_grid_scale(int which, double factor);
 /* Sum over all cells of a grid, evaluated on the device in a fixed order (the two means of the reference's log line,
  * pyc2ray/evolve.py:160 `ndens.mean()`, `xh.mean()`, without a host pass over N^3 values). */
 int asora_grid_sum(int which, double *sum);
@@ -410,7 +413,8 @@ enum {
     ASORA_VARIANT_BUFFER_ATOMICS = 4,     /* rate atomics through buffer descriptors (else global_atomic_add_f64 under a branch) */
     ASORA_VARIANT_SPLIT_DESCRIPTORS = 8,  /* N > 512: one descriptor per layout of the rate grid */
     ASORA_VARIANT_SKIP_ZERO = 16,         /* the form that leaves exact-zero rates out */
-    ASORA_VARIANT_GLOBAL_SHELLS = 32      /* shell buffers in global memory (they exceed LDS) */
+    ASORA_VARIANT_GLOBAL_SHELLS = 32,     /* shell buffers in global memory (they exceed LDS) */
+    ASORA_VARIANT_LDS_TABLES = 64         /* the rate tables in LDS (ASORA_OPT_LDS_TABLES) */
 };
 int asora_last_raytrace_variant(void);
 

@@ -43,6 +43,7 @@ SIGNATURES = {
     "asora_grid_to_device": (C.c_int, [C.c_int, _dp, C.c_int, C.c_char]),
     "asora_grid_to_host": (C.c_int, [C.c_int, _dp, C.c_int, C.c_char]),
     "asora_grid_copy": (C.c_int, [C.c_int, C.c_int]),
+    "asora_grid_scale": (C.c_int, [C.c_int, C.c_double]),
     "asora_device_ptr": (C.c_void_p, [C.c_int]),
     "asora_grid_sum": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "asora_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),

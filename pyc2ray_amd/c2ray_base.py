@@ -13,8 +13,8 @@ Differences from the reference:
     3.04 massless neutrinos).  The lite version could not be compared with astropy in the build
     container (astropy absent), so runs that need cosmological time steps to 1e-6 should have astropy.
   * ``use_mpi`` may be ``pyc2ray_amd.dist.MPI`` (torch.distributed/RCCL) as well as mpi4py's ``MPI``.
-  * ``device_resident`` (opt-in attribute, single GPU): ``ndens``, ``temp``, ``xh`` and ``phi_ion`` stay on the MI355X
-    between time steps; see :class:`C2Ray`.
+  * ``device_resident`` (default True; single GPU): ``ndens``, ``temp``, ``xh`` and ``phi_ion`` stay on the MI355X
+    between time steps and cross PCIe only when the host touches them; see :class:`C2Ray`.
 """
 import atexit
 import re
@@ -120,12 +120,21 @@ class _DeviceGrid:
         except KeyError:
             raise AttributeError(self.name) from None
         if self.name in obj._device_newer:                   # results of the last step(s) still only on the device
-            # into a FRESH array, as the reference binds a fresh array per step (c2ray_base.py:205-226): a caller that keeps
-            # `prev = sim.xh` or appends sim.xh to a history must not see it change under its feet
             lib = load_asora()
             order = 'F' if (arr.flags.f_contiguous and not arr.flags.c_contiguous) else 'C'
-            arr = lib.grid_to_host(self.which, lib.host_empty(arr.shape, order=order))
-            obj.__dict__[self.attr] = arr
+            if self.name in ("xh", "phi_ion"):
+                # into a FRESH array, as the reference binds a fresh array per step (c2ray_base.py:205-226): a caller that keeps
+                # `prev = sim.xh` or appends sim.xh to a history must not see it change under its feet
+                arr = lib.grid_to_host(self.which, lib.host_empty(arr.shape, order=order))
+                obj.__dict__[self.attr] = arr
+            else:
+                # an input grid changed on the device (the density, diluted by cosmo_evolve): into the caller's OWN array, as the
+                # reference scales it in place (c2ray_base.py:248) -- a reference kept to it sees the dilution
+                if not (arr.flags.writeable and (arr.flags.c_contiguous or arr.flags.f_contiguous) and arr.dtype == np.float64):
+                    arr = lib.host_empty(arr.shape, order=order)
+                    obj.__dict__[self.attr] = arr
+                lib.grid_to_host(self.which, arr)
+                obj.__dict__.setdefault("_grid_fingerprints", {})[self.name] = obj._fingerprint(arr)
             obj._device_newer.discard(self.name)
         obj._host_newer.add(self.name)                       # the caller may modify what it gets
         return arr
@@ -137,14 +146,20 @@ class _DeviceGrid:
 
 
 class C2Ray:
-    #: Opt-in (set on an instance, single GPU, use_gpu=True): ndens, temp, xh and phi_ion stay on the device between time
-    #: steps.  evolve3D then uploads only the grids that were assigned or READ on the host since the last step (a read
-    #: hands out the array, which may be written into -- e.g. ``sim.ndens *= f`` in cosmo_evolve), and downloads xh /
-    #: phi_ion only when they are read.  At 256^3 the five 128 MiB transfers of a time step cost as much as five outer
-    #: iterations.  Contract: do not keep a reference to one of these arrays and write into it later WITHOUT touching the
-    #: attribute again (``x = sim.xh`` ... ``x[...] = 0``): the device copy would not notice.  With the default (False)
-    #: every step uploads and downloads everything, as the reference does.
-    device_resident = False
+    #: Default since round 6 (single GPU, use_gpu=True; set False on an instance for the reference's behaviour: every step uploads
+    #: and downloads everything): ndens, temp, xh and phi_ion stay on the device between time steps.  evolve3D then uploads only
+    #: the grids that were assigned or READ on the host since the last step (a read hands out the array, which may be written
+    #: into), and downloads xh / phi_ion only when they are read; cosmo_evolve dilutes a density that lives on the device ON the
+    #: device.  At 256^3 the five 128 MiB transfers of a time step cost as much as the step's outer iterations (32.8 against
+    #: 15.9 ms per time step, profiles/r05_time_steps_resident.json).  xh and phi_ion behave as in the reference: every step
+    #: binds a FRESH array (c2ray_base.py:205-226), an array kept from an earlier step keeps that step's values.  ndens and temp
+    #: are the caller's arrays; writing into one through a reference kept from BEFORE the last step, without touching the
+    #: attribute again (``n = sim.ndens`` ... evolve3D ... ``n *= 2``), is caught by a fingerprint of 65 536 samples of the host
+    #: array taken at upload time (any rescaling or whole-grid update changes it; an edit of a few cells may not: assign or read
+    #: the attribute after such an edit, as ``sim.ndens[...] = v`` does by itself): the grid is uploaded again -- or, if the
+    #: device copy has meanwhile been diluted by cosmo_evolve, so that the write went into stale values, a RuntimeError says so.
+    device_resident = True
+    _FINGERPRINT_SAMPLES = 65536
 
     ndens = _DeviceGrid("ndens", _capi.GRID_NDENS)
     temp = _DeviceGrid("temp", _capi.GRID_TEMP)
@@ -226,13 +241,43 @@ class C2Ray:
             self.xh, self.phi_ion = evolve3D(dt, self.dr, src_flux, src_pos, self.gpu, self.max_subbox,
                                              self.subboxsize, self.loss_fraction, *args)
 
+    @classmethod
+    def _fingerprint(cls, arr):
+        """A strided sample of a host grid (a view of its memory in storage order): what the resident path compares to notice
+        in-place changes made through a reference the caller kept."""
+        flat = arr.ravel(order='K')
+        step = max(1, flat.shape[0] // cls._FINGERPRINT_SAMPLES)
+        return flat[::step].copy()
+
+    def _written_behind_the_attribute(self, name):
+        """Has the host array of input grid `name` changed since it was last in step with the device, without the attribute having
+        been touched?  (``n = sim.ndens`` ... ``n *= 2``.)  True: the caller uploads it again.  If the DEVICE copy has moved on as
+        well -- a density diluted on the device -- the two cannot be reconciled (the write went into stale values): that raises."""
+        prints = self.__dict__.get("_grid_fingerprints", {})
+        if name not in prints or name in self._host_newer:
+            return False
+        if np.array_equal(self._fingerprint(self.__dict__["_grid_" + name]), prints[name]):
+            return False
+        if name in self._device_newer:
+            raise RuntimeError(f"C2Ray.{name} was written into through a reference kept from before the last time step, while the "
+                               f"device held the newer copy (cosmo_evolve dilutes a device-resident density on the device).  Read "
+                               f"sim.{name} again before modifying it (`sim.{name} *= f`, `sim.{name}[...] = v` do), or set "
+                               f"sim.device_resident = False for the reference's all-through-the-host behaviour.")
+        return True
+
     def _evolve3D_resident(self, dt, src_flux, src_pos):
         """The same step with the grids left on the device (see `device_resident`)."""
         d = self.__dict__
         uploads = {}
+        prints = d.setdefault("_grid_fingerprints", {})
         for name, which in (("ndens", _capi.GRID_NDENS), ("temp", _capi.GRID_TEMP), ("xh", _capi.GRID_XH)):
-            if name in self._host_newer:
-                uploads[which] = d["_grid_" + name]
+            host = d["_grid_" + name]
+            # (an input grid the host did not touch through the attribute may still have been written into through a kept reference)
+            changed = name in self._host_newer or self._written_behind_the_attribute(name)
+            if changed:
+                uploads[which] = host
+                if name != "xh":
+                    prints[name] = self._fingerprint(host)
         phi_host = d.get("_grid_phi_ion")                       # (a subclass may never have assigned phi_ion)
         if phi_host is None or (phi_host.flags.f_contiguous and not phi_host.flags.c_contiguous):
             d["_grid_phi_ion"] = np.zeros(self.shape)           # the GPU path returns C-ordered rates (evolve.py:200)
@@ -251,7 +296,14 @@ class C2Ray:
         z_half = self.time2zred(t_half)
         if self.cosmological:
             dilution_factor = ((1 + z_half) / (1 + self.zred)) ** 3
-            self.ndens *= dilution_factor
+            if (self.device_resident and self.gpu and not self.mpi and cuda_is_init() and "ndens" not in self._host_newer
+                    and "ndens" in self.__dict__.get("_grid_fingerprints", {}) and not self._written_behind_the_attribute("ndens")):
+                # the density lives on the device and the host has not touched it since: diluted there (the same IEEE
+                # multiplication per cell); the host array is fetched when someone reads sim.ndens
+                load_asora().grid_scale(_capi.GRID_NDENS, dilution_factor)
+                self._device_newer.add("ndens")
+            else:
+                self.ndens *= dilution_factor
             self.dr = self.dr_c * self._scale_factor(z_half)
         self.zred = z_half
         self.time = t_after

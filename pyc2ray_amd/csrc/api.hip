@@ -921,6 +921,18 @@ int asora_grid_copy(int dst, int src)
     return 0;
 }
 
+int asora_grid_scale(int which, double factor)
+{
+    clear_error();
+    if (int rc = require_init("grid_scale")) return rc;
+    if (which < 0 || which >= ASORA_GRID_COUNT) return fail(3, "grid_scale: bad grid selector");
+    State &st = g_state;
+    if (!st.grid_valid[which]) return fail(3, "grid_scale: grid " + std::to_string(which) + " holds no data");
+    if (int rc = launch_scale(st, st.grid[which], st.ncell, factor)) return rc;
+    if (which == ASORA_GRID_TEMP) st.temp_probe_valid = false;
+    return 0;
+}
+
 int asora_grid_sum(int which, double *sum)
 {
     clear_error();

@@ -412,6 +412,7 @@ struct ChemTileParams {
     double uniform_T = 0, uniform_brech0 = 0, uniform_acolh0 = 0;
 };
 int launch_grid_sum(State &st, const double *a, size_t n, double *out_dev);
+int launch_scale(State &st, double *a, size_t n, double factor);
 int launch_temp_probe(State &st, const double *temp, size_t n, double bh00, double albpow, double colh0, double temph0,
                       double *out_dev);
 int launch_chemistry_tiles(State &st, ChemTileParams &p, hipStream_t stream);

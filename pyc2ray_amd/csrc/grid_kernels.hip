@@ -234,6 +234,21 @@ int launch_fold_sum(State &st, const double *a, const double *b_t, double *dst)
     return 0;
 }
 
+// grid *= factor in place (the dilution of the density in a cosmological run, ref: pyc2ray/c2ray_base.py:248, for a grid that
+// lives on the device)
+__global__ void __launch_bounds__(256) scale_kernel(double *__restrict__ a, size_t n, double factor)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a[i] *= factor;
+}
+
+int launch_scale(State &st, double *a, size_t n, double factor)
+{
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, st.stream, a, n, factor);
+    ASORA_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_transpose(State &st, const double *src, double *dst, int N)
 {
     hipLaunchKernelGGL(transpose_ik_kernel<false>, tile_grid(N), dim3(32, 8), 0, st.stream, src, dst, N);

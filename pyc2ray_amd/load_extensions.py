@@ -140,6 +140,10 @@ class _LibAsora:
     def grid_copy(self, dst, src):
         _capi.check(self._lib.asora_grid_copy(int(dst), int(src)), "grid_copy")
 
+    def grid_scale(self, which, factor):
+        """grid *= factor on the device (c2ray_base.py:248 for a device-resident density)."""
+        _capi.check(self._lib.asora_grid_scale(int(which), float(factor)), "grid_scale")
+
     def grid_sum(self, which):
         out = C.c_double(0.0)
         _capi.check(self._lib.asora_grid_sum(int(which), C.byref(out)), "grid_sum")

@@ -294,12 +294,14 @@ def test_paper_test2_cosmological_ionisation_front(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("cosmological", [False, True])
 def test_device_resident_grids_give_the_same_run_with_fewer_transfers(tmp_path, cosmological):
-    """`sim.device_resident = True`: ndens, temp, xh and phi_ion stay on the device between time steps.  Same fields as
-    the default run after every step that is looked at; uploads only for grids that were assigned or read on the host
-    (the density every step of a cosmological run: cosmo_evolve scales it in place), downloads only on reading."""
+    """`device_resident` (the DEFAULT since round 6): ndens, temp, xh and phi_ion stay on the device between time steps.  Same
+    fields as a run with `device_resident = False` (everything through the host every step, as the reference) after every step
+    that is looked at; uploads only for grids that were assigned or read on the host, the density of a cosmological run is
+    diluted on the device, downloads only on reading."""
     import pyc2ray_amd as pc2r
     from pyc2ray_amd import _capi
     from pyc2ray_amd.load_extensions import load_asora
+    assert pc2r.C2Ray.device_resident is True                  # the class default
     cwd = os.getcwd()
     os.chdir(tmp_path)
     try:
@@ -312,7 +314,9 @@ def test_device_resident_grids_give_the_same_run_with_fewer_transfers(tmp_path, 
                 pc2r.device_close()
             sim = pc2r.C2Ray_Test(PARAMS, N, True)
             sim.cosmological = cosmological
-            sim.device_resident = resident
+            if not resident:
+                sim.device_resident = False                 # (True is what a fresh instance has)
+            assert sim.device_resident is resident
             srcpos, srcflux = sim.read_sources("src.txt", 2)
             zs = sim.generate_redshift_array(2, 4e7)
             dt = sim.set_timestep(zs[0], zs[1], 4)
@@ -345,11 +349,63 @@ def test_device_resident_grids_give_the_same_run_with_fewer_transfers(tmp_path, 
         up0, down0 = runs[False][1]["up"], runs[False][1]["down"]
         up1, down1 = runs[True][1]["up"], runs[True][1]["down"]
         assert len(up0) == 3 * 4 and len(down0) == 2 * 4                       # the default: everything, every step
-        # resident: step 1 uploads ndens, temp, xh; afterwards only what the host touched -- the density when cosmo_evolve
-        # scaled it, and xh / ndens again after the snapshot read them (a read may have been a write)
+        # resident: step 1 uploads ndens, temp, xh; afterwards only what the host touched -- xh / ndens again after the snapshot
+        # read them (a read may have been a write).  The dilution of a cosmological run happens on the device while the density
+        # lives there (steps 2 and 4), on the host when the host holds the newer copy (steps 1 and 3); the snapshot's
+        # sim.ndens then fetches the diluted density
         assert up1.count(_capi.GRID_TEMP) == 1
-        assert up1.count(_capi.GRID_NDENS) == (4 if cosmological else 2)
+        assert up1.count(_capi.GRID_NDENS) == 2
         assert up1.count(_capi.GRID_XH) == 2
-        assert len(down1) == 4                                                 # xh and phi_ion, twice
+        assert down1.count(_capi.GRID_XH) == 2 and down1.count(_capi.GRID_PHI_ION) == 2
+        assert down1.count(_capi.GRID_NDENS) == (2 if cosmological else 0) and len(down1) == (6 if cosmological else 4)
+    finally:
+        os.chdir(cwd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cosmological", [False, True])
+def test_device_resident_default_notices_writes_through_a_kept_reference(tmp_path, cosmological):
+    """The hazard of keeping the grids on the device: `n = sim.ndens` ... evolve3D ... `n *= 3` writes into the host array
+    behind the attribute's back.  The resident path fingerprints the input grids at upload time: a changed fingerprint means
+    "upload again" -- or, when the device copy has moved on as well (a cosmological run dilutes the density on the device, so the
+    write went into stale values), a RuntimeError that says what to do.  Through the attribute (`sim.ndens *= 3`) both work."""
+    import pyc2ray_amd as pc2r
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        N = 24
+        with open("src.txt", "w") as f:
+            f.write("1\n12 12 12 6e52 1.0\n")
+        out = {}
+        for mode in ("host", "resident_kept_reference", "resident_attribute"):
+            if pc2r.cuda_is_init():
+                pc2r.device_close()
+            sim = pc2r.C2Ray_Test(PARAMS, N, True)
+            sim.cosmological = cosmological
+            sim.device_resident = mode != "host"
+            srcpos, srcflux = sim.read_sources("src.txt", 1)
+            zs = sim.generate_redshift_array(2, 4e7)
+            dt = sim.set_timestep(zs[0], zs[1], 4)
+            sim.density_init(zs[0])
+            n = sim.ndens                                   # a reference the script keeps
+            sim.cosmo_evolve(dt); sim.evolve3D(dt, srcflux, srcpos)
+            sim.cosmo_evolve(dt); sim.evolve3D(dt, srcflux, srcpos)       # (resident + cosmological: this dilution ran on the device)
+            if mode == "resident_attribute":
+                sim.ndens *= 3.0
+            else:
+                n *= 3.0                                    # written into WITHOUT touching sim.ndens
+            if mode == "resident_kept_reference" and cosmological:
+                with pytest.raises(RuntimeError, match="kept from before"):
+                    sim.cosmo_evolve(dt)
+                pc2r.device_close()
+                continue
+            sim.cosmo_evolve(dt); sim.evolve3D(dt, srcflux, srcpos)
+            assert sim.ndens is n                           # the caller's own array throughout: diluted (on whichever side) and tripled
+            out[mode] = (np.array(sim.xh, copy=True), np.array(n, copy=True))
+            pc2r.device_close()
+        for mode in out:
+            np.testing.assert_allclose(out[mode][1], out["host"][1], rtol=1e-15)
+            np.testing.assert_allclose(out[mode][0], out["host"][0], rtol=1e-11, atol=0)
+        assert len(out) == (2 if cosmological else 3)
     finally:
         os.chdir(cwd)

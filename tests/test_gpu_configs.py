@@ -595,10 +595,6 @@ def _coldens_cube_against_fixture(cd, case, src, rtol, rated_only=False):
     assert np.array_equal(cube != 0, sphere) and np.count_nonzero(cd) == int(sphere.sum())       # exactly the rated cells
     got = cube[off[0] + r, off[1] + r, off[2] + r]
     np.testing.assert_allclose(got[inside], g[f"{case}_vals"][inside], rtol=rtol, atol=0, err_msg=case)
-    # rows of the cube that lie wholly inside the sphere: their sums are in the fixture
-    rows_inside = sphere.all(axis=2).ravel()
-    assert rows_inside.sum() > 100
-    np.testing.assert_allclose(cube.sum(axis=2).ravel()[rows_inside], g[f"{case}_row_sums"][rows_inside], rtol=rtol, err_msg=case)
 
 
 @pytest.mark.parametrize("case", ["u32", "u64", "c32"])
