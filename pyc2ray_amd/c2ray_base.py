@@ -28,7 +28,7 @@ except ImportError:  # pragma: no cover
     from yaml import SafeLoader
 
 from .asora_core import cuda_is_init, device_close, device_init, photo_table_to_device
-from . import _capi
+from . import _capi, _residency
 from .evolve import evolve3D, evolve3D_MPI, evolve3D_resident
 from .load_extensions import load_asora
 from .radiation import BlackBodySource, make_tau_table
@@ -265,9 +265,21 @@ class C2Ray:
                                f"sim.device_resident = False for the reference's all-through-the-host behaviour.")
         return True
 
+    def _leave_device(self):
+        """Someone else is about to overwrite the device grids (pyc2ray_amd/_residency.py): fetch what exists only there, and
+        upload everything again at the next step."""
+        for name in ("ndens", "temp", "xh", "phi_ion"):
+            if name in self._device_newer and ("_grid_" + name) in self.__dict__:
+                getattr(self, name)                              # (downloads; marks the host copy as the newer one)
+        self._device_newer.clear()
+        self._host_newer |= {"ndens", "temp", "xh"}
+        self.__dict__.pop("_grid_fingerprints", None)
+
     def _evolve3D_resident(self, dt, src_flux, src_pos):
         """The same step with the grids left on the device (see `device_resident`)."""
         d = self.__dict__
+        _residency.reclaim(except_for=self)                     # (another object's device copies, should there be one)
+        _residency.register(self)
         uploads = {}
         prints = d.setdefault("_grid_fingerprints", {})
         for name, which in (("ndens", _capi.GRID_NDENS), ("temp", _capi.GRID_TEMP), ("xh", _capi.GRID_XH)):

@@ -192,15 +192,21 @@ __global__ void __launch_bounds__(SB_THREADS) subbox_sweep_kernel(const SubboxPa
 
             // ---- cinterp, f90:576-815, in source-relative octant coordinates -----------------
             const double u = (double)U, v = (double)V;
-            const double de = 2.0 * fabs(alam * u - (u - 0.5));
-            const double df = 2.0 * fabs(alam * v - (v - 0.5));
+            // corners that would step across a zero offset, or keep a transverse offset equal to s, carry
+            // weight 0 (up to rounding) and do not exist in shell s-1: not fetched
+            const bool em = U >= 1, e0 = U <= sm, fm = V >= 1, f0 = V <= sm;
+            // A transverse offset equal to s (cube edges, the diagonal): alam * s - (s - 1/2) is 0 in exact arithmetic but a few
+            // 1e-17 s in floating point for most s, which the reference multiplies with the column density of a REAL neighbour
+            // (its traversal holds the whole cube) -- a 1e-16 effect.  The corner not being fetched here, its value is 0 and its
+            // weight 1 / max(0.6, 0) instead of 1 / (c sigma): in a medium with tau ~ 200 per cell that amplified the speck by
+            // c sigma / 0.6 ~ 600 s, 5e-9 of the column density at the corner of a +-64 cube (round 6, found by the full-size
+            // column-density fixture).  Its weight is therefore set to the exact 0.
+            const double de = e0 ? 2.0 * fabs(alam * u - (u - 0.5)) : 0.0;
+            const double df = f0 ? 2.0 * fabs(alam * v - (v - 0.5)) : 0.0;
             double w1 = (1. - de) * (1. - df);
             double w2 = (1. - df) * de;
             double w3 = (1. - de) * df;
             double w4 = de * df;
-            // corners that would step across a zero offset, or keep a transverse offset equal to s, carry
-            // weight 0 (up to rounding) and do not exist in shell s-1: not fetched
-            const bool em = U >= 1, e0 = U <= sm, fm = V >= 1, f0 = V <= sm;
             int o1, o2, o3, o4;   // slots of (U-1,V-1) (U,V-1) (U-1,V) (U,V) in shell s-1
             if (face == 2) {
                 o1 = (V - 1) * W + (U - 1); o2 = (V - 1) * W + U; o3 = V * W + (U - 1); o4 = V * W + U;

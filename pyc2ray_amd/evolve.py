@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-from . import _capi
+from . import _capi, _residency
 from .asora_core import cuda_is_init
 from .load_extensions import load_asora, load_c2ray
 from .utils import printlog
@@ -25,6 +25,13 @@ __all__ = ['evolve3D', 'evolve3D_MPI', 'evolve3D_resident']
 #: outer iterations enqueued per host round trip of the single-GPU loop (the device evaluates the convergence test
 #: itself; launches enqueued beyond convergence do nothing)
 EVOLVE_BATCH = int(os.environ.get("PYC2RAY_AMD_EVOLVE_BATCH", "8"))
+
+
+def _has_transposed_twins(libasora):
+    """The sharded / all-reduce device loops need the [k][j][i] twins of the grids (asora_evolve_begin_slab fails without:
+    ASORA_OPT_Z_TRANSPOSED = 0 is a diagnostic setting)."""
+    get = getattr(libasora, "get_option", None)
+    return True if get is None else get(_capi.OPT_Z_TRANSPOSED) != 0
 
 
 def _comm_backend(comm):
@@ -85,6 +92,7 @@ def _evolve_cpu_semantics(dt, dr, src_flux, src_pos, max_subbox, subboxsize, los
     -- and one global_pass.  Both are evaluated on the GPU, and like the use_gpu=True loop this one keeps the grids
     on the device for the whole step (the reference's host round trips are what
     ``libc2ray.raytracing.do_all_sources`` / ``libc2ray.chemistry.global_pass`` of this package still offer)."""
+    _residency.reclaim()              # this step overwrites device grids a resident C2Ray object may be relying on
     libasora = load_asora()
     distributed = bool(use_mpi) and comm is not None and nprocs > 1
     NumSrc = src_flux.shape[0]
@@ -247,6 +255,7 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
             use_mpi=None, comm=None, rank=0, nprocs=1):
     if use_gpu and not cuda_is_init():
         raise RuntimeError("GPU not initialized. Please initialize it by calling device_init(N)")
+    _residency.reclaim()              # this step overwrites device grids a resident C2Ray object may be relying on
     distributed = bool(use_mpi) and comm is not None and nprocs > 1
     libasora = load_asora()
 
@@ -266,7 +275,7 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
     # source shard of this rank, evolve.py:360-371
     # (the sharded device loop needs the [k][j][i] twins, asora_evolve_begin_slab: not with ASORA_OPT_Z_TRANSPOSED = 0)
     slab = (distributed and hasattr(comm, "slab_enqueue") and getattr(comm, "exchange", "") == "slab"
-            and not getattr(comm, "overlap", False) and libasora.get_option(_capi.OPT_Z_TRANSPOSED) != 0)
+            and not getattr(comm, "overlap", False) and _has_transposed_twins(libasora))
     plan = None
     all_pos, all_flux = np.asarray(src_pos), src_flux
     if slab:
@@ -358,7 +367,7 @@ def _evolve(dt, dr, src_flux, src_pos, use_gpu, temp, ndens, xh, photo_thin_tabl
     # (asora_evolve_begin_slab needs the [k][j][i] twins: with ASORA_OPT_Z_TRANSPOSED = 0 the three-call loop below runs)
     reduce_loop = (distributed and not slab and not pipelined and getattr(comm, "device_loop", False)
                    and hasattr(comm, "reduce_begin") and hasattr(libasora, "evolve_slab_fold_all")
-                   and libasora.get_option(_capi.OPT_Z_TRANSPOSED) != 0)
+                   and _has_transposed_twins(libasora))
     if reduce_loop:
         comm.reduce_begin(libasora, N, R_max_LLS, sig, dr, NumSrc_local, minlogtau, dlogtau, NumTau, chem, conv_criterion,
                           convergence_fraction)

@@ -3,7 +3,7 @@ import time
 
 import numpy as np
 
-from . import _capi
+from . import _capi, _residency
 from .asora_core import cuda_is_init
 from .load_extensions import load_asora, load_c2ray
 from .utils import printlog
@@ -37,6 +37,7 @@ def do_raytracing(dr,
     """
     if use_gpu and not cuda_is_init():
         raise RuntimeError("GPU not initialized. Please initialize it by calling device_init(N)")
+    _residency.reclaim()              # this call overwrites device grids a resident C2Ray object may be relying on
 
     NumSrc = src_flux.shape[0]
     N = ndens.shape[0]
