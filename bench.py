@@ -400,6 +400,105 @@ def evolving_state(lib, p, _capi, N, R, thin, thick, dlog, numtau, flux_scale=1e
     }
 
 
+def configs4_block(comm, lib, p, _capi, rank, world, device_id, numtau_arg, want_slab, grid=512, nsrc=100000, R=32.0, iterations=2):
+    """BASELINE configs[4] inside an N-rank run, bounded: `grid`^3 log-normal density, `nsrc` sources on the densest cells IN TOTAL,
+    sharded like the main workload (slab exchange, or the full-grid all-reduce if that is what the main pass took), r_RT = 32:
+    one warm-up iteration + `iterations` timed ones of the device-resident loop over the ranks (TorchComm.slab_enqueue, one poll
+    at the end), MAX over the ranks, with `phases_ms`; and rank 0 ALONE on the whole source list through the one-GPU loop (one
+    warm-up + one timed iteration) -> `speedup_vs_one_gpu`.  This is the regime where sharding by source pays (one GPU
+    needs ~105 ms per iteration, an exchange ~1 ms), next to configs[3] where it cannot.  A COLLECTIVE: every rank calls it.
+    The library is re-initialised for `grid`; returns a dict on every rank (rank 0's is printed)."""
+    import torch
+    import torch.distributed as dist
+    from pyc2ray_amd.dist import SlabPlan
+    from pyc2ray_amd.utils.sourceutils import format_sources
+    t_all = time.perf_counter()
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    N = grid
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 64, device_id=device_id)
+    thin, thick, dlog = make_tables(numtau_arg)
+    p.photo_table_to_device(thin, thick)
+    numtau = thin.shape[0] - 1
+    ndens, xh, temp, dr, pos, flux = make_workload("cosmo", N, nsrc)
+    t_workload = time.perf_counter() - t_all
+    lib.grid_to_device(_capi.GRID_NDENS, ndens)
+    lib.grid_to_device(_capi.GRID_TEMP, temp)
+    lib.grid_to_device(_capi.GRID_XH, xh)
+    del ndens, temp, xh
+    chem = (MYR, BH00, ALBPOW, COLH0, TEMPH0, ABU_C)
+
+    def fence():
+        lib.synchronize()
+        if dev == "cuda":
+            torch.cuda.synchronize()
+        comm.Barrier()
+
+    # rank 0 alone, the whole list, one-GPU loop: the denominator
+    one_gpu_ms = None
+    if rank == 0:
+        try:
+            pa, fa = format_sources(pos, flux)
+            lib.source_data_to_device(pa, fa, flux.shape[0])
+            lib.evolve_begin(*chem, R, SIG, dr, MINLOGTAU, dlog, numtau, 0, flux.shape[0], -1.0, 0.0)
+            lib.evolve_enqueue(1); lib.evolve_poll(1); lib.synchronize()
+            t0 = time.perf_counter()
+            lib.evolve_enqueue(1); lib.evolve_poll(1); lib.synchronize()
+            one_gpu_ms = (time.perf_counter() - t0) * 1e3
+        except Exception as e:
+            print(f"bench: configs4 one-GPU reference failed: {type(e).__name__}: {e}", file=sys.stderr)
+    comm.Barrier()
+
+    spos, sflux, bounds = comm.shard_sources_by_slab(pos, flux, world)
+    plan = SlabPlan(N, world, R, [spos[0, bounds[r]:bounds[r + 1]] - 1 for r in range(world)])
+    lo, hi = bounds[rank], bounds[rank + 1]
+    p0, f0 = format_sources(spos[:, lo:hi], sflux[lo:hi])
+    lib.source_data_to_device(p0, f0, hi - lo)
+    comm.exchange = "slab" if want_slab else "allreduce"
+    if want_slab:
+        comm.slab_begin(lib, plan, N, R, SIG, dr, hi - lo, MINLOGTAU, dlog, numtau, chem, -1.0, 0.0)
+    else:
+        comm.reduce_begin(lib, N, R, SIG, dr, hi - lo, MINLOGTAU, dlog, numtau, chem, -1.0, 0.0)
+    comm.slab_enqueue(lib, 1)                  # warm-up: geometry tables, first touch, the first exchange
+    comm.slab_poll(lib, 1)
+    comm.phase_reset()
+    comm.phase_timing = True
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(iterations):
+        comm.slab_enqueue(lib, 1)
+    comm.slab_poll(lib, iterations)
+    fence()
+    elapsed = time.perf_counter() - t0
+    comm.phase_timing = False
+    phases = None
+    try:
+        phases = comm.phase_report()
+    except Exception as e:
+        print(f"bench: configs4 phase report failed: {type(e).__name__}: {e}", file=sys.stderr)
+    gamma, _ = lib.last_raytrace_counts()
+    n_done, _, _ = comm.slab_poll(lib, 0)
+    t = torch.tensor([elapsed, float(gamma // max(n_done, 1))], dtype=torch.float64, device=dev)
+    tmax, tsum = t.clone(), t.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    ms_step = float(tmax[0].item()) / iterations * 1e3
+    pairs = int(round(float(tsum[1].item())))
+    return {
+        "workload": f"BASELINE configs[4], bounded: {N}^3 log-normal density, {nsrc} sources on the densest cells in total sharded over {world} ranks, "
+                    f"r_RT={R:g}, {iterations} outer iterations of the device-resident loop over the ranks after one warm-up iteration",
+        "exchange": "slab" if want_slab else "allreduce", "ms_per_step": ms_step, "steps": iterations,
+        "value": (pairs + N ** 3) / (ms_step * 1e-3), "unit": "cell-updates/s", "raytrace_updates_per_step": pairs,
+        "sources_rank0": hi - lo, "phases_ms": phases,
+        "one_gpu_same_workload_ms_per_step": one_gpu_ms, "speedup_vs_one_gpu": (one_gpu_ms / ms_step) if one_gpu_ms else None,
+        "busiest_link_bytes_per_exchange": plan.largest_transfer() if want_slab else None,
+        "workload_build_s": t_workload, "block_wall_s": time.perf_counter() - t_all,
+        "note": "every rank builds the workload itself (FFT of the grid, a full sort for the densest cells: workload_build_s on the host); "
+                "one_gpu_same_workload = rank 0 alone, one timed iteration of the one-GPU loop on all sources",
+    }
+
+
 def host_topology():
     """What the host offers this process: logical CPUs and sockets of the machine (/proc/cpuinfo), physical cores per socket,
     the CPUs this process may run on (affinity) and the CPU share its control group grants (cgroup quota), whichever is
@@ -606,7 +705,7 @@ def main():
     ap.add_argument("--R", type=float, default=32.0)
     ap.add_argument("--numtau", type=int, default=NUMTAU,
                     help="entries of the rate tables: 20000 = the benchmark's parameter file (default, BASELINE configs[2]); 2000 = the "
-                         "reference's production parameter files (the tables then fit LDS: ASORA_OPT_LDS_TABLES)")
+                         "reference's production parameter files")
     ap.add_argument("--workload", choices=["uniform", "cosmo"], default=None,
                     help="default: uniform (configs[2]) on one GPU, cosmo (configs[3]) on several")
     ap.add_argument("--cpu-sources", type=int, default=512,
@@ -624,6 +723,11 @@ def main():
     ap.add_argument("--one-gpu-reference", type=int, default=1,
                     help="N>1: before the multi-rank region rank 0 ALONE runs the same workload (all sources) through the one-GPU loop "
                          "while the others wait -> one_gpu_same_workload_ms_per_step, speedup_vs_one_gpu (0 = skip)")
+    ap.add_argument("--configs4", type=int, default=-1,
+                    help="N>1: after the metric's workload also a bounded pass of BASELINE configs[4] (512^3, 1e5 sources, the regime where "
+                         "sharding pays) -> `configs4`; -1 = on for the default N-rank job, 0 = off, 1 = on")
+    ap.add_argument("--configs4-grid", type=int, default=512)
+    ap.add_argument("--configs4-nsrc", type=int, default=100000)
     ap.add_argument("--evolving-state", type=int, default=-1,
                     help="one GPU: also time the trace and the fused pass on a grid WITH ionisation fronts (configs[3], fluxes x 1e3, "
                          "second time step) -> `evolving_state`; default: on for the default job only")
@@ -995,6 +1099,7 @@ def main():
 
     gamma_cells, eval_cells = lib.last_raytrace_counts()
     zero_cells = lib.last_raytrace_zero_rates()
+    raytrace_variant = lib.last_raytrace_variant()
     if comm is not None and state["loop"]:
         # the counters of the device loop over the ranks run on from its begin, like the one-GPU loop's
         n_done, _, _ = comm.slab_poll(lib, 0)
@@ -1041,6 +1146,24 @@ def main():
         except Exception as e:    # reporting only
             print(f"bench: rank-agreement check failed: {type(e).__name__}: {e}", file=sys.stderr)
 
+    grid_placement = lib.debug_placement()         # (of the metric's grids: the configs4 block below re-initialises the library)
+    configs4 = None
+    if comm is not None and state["loop"] and (args.configs4 == 1 or (args.configs4 < 0 and args.workload == "cosmo" and N == 256 and
+                                                                      args.nsrc == 1000 and args.R == 32.0 and strong)):
+        # every rank takes the same branch (same arguments, same exchange choice) -- and votes on the outcome, so that a failure
+        # on one rank costs this block, not the line
+        ok = True
+        try:
+            configs4 = configs4_block(comm, lib, p, _capi, rank, world, int(os.environ.get("PYC2RAY_AMD_BENCH_DEVICE", local_rank)),
+                                      args.numtau, state["slab"], grid=args.configs4_grid, nsrc=args.configs4_nsrc)
+        except Exception as e:
+            print(f"bench: configs4 block failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
+            configs4, ok = {"failed": f"{type(e).__name__}: {e}"}, False
+        try:
+            if not all_ranks_ok(ok) and ok:
+                configs4 = {"failed": "on another rank (see stderr)"}
+        except Exception as e:
+            print(f"bench: configs4 vote failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
     if comm is not None:
         import torch.distributed as dist
         dist.barrier()
@@ -1106,7 +1229,9 @@ def main():
             # where device_init put the grids: allocations of the whole arena tried (at most 8 by default), probe time (a kernel with
             # the fused pass's stream mix) of the one kept and of the slowest -- placements differ by ~15 % on some boxes, not at all
             # on others (csrc/api.hip choose_arena) -- and what device_init and, inside it, the probe cost on the host clock
-            "grid_placement": lib.debug_placement(),
+            "grid_placement": grid_placement,
+            # which form of the raytrace kernel the timed launches took (asora_last_raytrace_variant)
+            "raytrace_variant": raytrace_variant,
             "ranks_agree_on_rates_and_ionised_fraction": ranks_agree,
             "parallelism": ("single GPU" if world == 1 else
                             f"sources sharded over {world} ranks by slab of the first coordinate; rates sent plane-wise to the "
@@ -1229,6 +1354,7 @@ def main():
                               "library's stream (wait_rates_add = what the rate exchange left un-hidden + the adds; xh_av_exchange_nhi is "
                               "serial by construction), all-reduce path: wall clock between the host synchronisations of its three calls")
         out["measured_link_GBs"] = links
+        out["configs4"] = configs4
     if world == 1 and (args.evolving_state == 1 or (args.evolving_state < 0 and default_job)):
         try:
             out["evolving_state"] = evolving_state(lib, p, _capi, N, args.R, thin, thick, dlog, numtau)

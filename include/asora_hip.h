@@ -373,11 +373,7 @@ enum {
      * stays within an eighth of the free device memory, and the probe stops once it holds a placement 7 % faster than another
      * or has seen four within 3 % of each other.  Same results on any placement. */
     ASORA_OPT_PLACEMENT_CANDIDATES = 17,
-    /* raytrace: the photo-ionisation rate tables in LDS instead of global memory when both fit (NumTau <= 2048, the size of the
-     * reference's production parameter files: ref test/paper_eor_simulation/parameters.yml:75), so that the four table gathers
-     * of a cell never leave the CU.  0 = the library decides, 1 = never, 2 = whenever the variant exists.  Same bits. */
-    ASORA_OPT_LDS_TABLES = 18,
-    ASORA_OPT_COUNT = 19
+    ASORA_OPT_COUNT = 18
 };
 int asora_set_option(int option, int value);
 int asora_get_option(int option);
@@ -413,8 +409,7 @@ enum {
     ASORA_VARIANT_BUFFER_ATOMICS = 4,     /* rate atomics through buffer descriptors (else global_atomic_add_f64 under a branch) */
     ASORA_VARIANT_SPLIT_DESCRIPTORS = 8,  /* N > 512: one descriptor per layout of the rate grid */
     ASORA_VARIANT_SKIP_ZERO = 16,         /* the form that leaves exact-zero rates out */
-    ASORA_VARIANT_GLOBAL_SHELLS = 32,     /* shell buffers in global memory (they exceed LDS) */
-    ASORA_VARIANT_LDS_TABLES = 64         /* the rate tables in LDS (ASORA_OPT_LDS_TABLES) */
+    ASORA_VARIANT_GLOBAL_SHELLS = 32      /* shell buffers in global memory (they exceed LDS) */
 };
 int asora_last_raytrace_variant(void);
 

@@ -16,7 +16,7 @@ GRID_NDENS, GRID_XH_AV, GRID_PHI_ION, GRID_TEMP, GRID_XH, GRID_XH_INTERMED, GRID
 (OPT_FORTRAN_CONSTANTS, OPT_GREY_NOTABLES, OPT_TIMING, OPT_Z_TRANSPOSED, OPT_BLOCK_THREADS, OPT_SECTORS,
  OPT_HEATING, OPT_C2RAY_OWN_FLUX, OPT_NO_UNIFORM_T, OPT_SUBBOX_GLOBAL_SHELLS, OPT_PIPELINED_COPIES,
  OPT_SKIP_ZERO_RATES, OPT_GLOBAL_ATOMICS, OPT_PAIR_SOURCES, OPT_SUBBOX_TABLES, OPT_ALIGNED_ROWS, OPT_GEOMETRY_ON_HOST,
- OPT_PLACEMENT_CANDIDATES, OPT_LDS_TABLES) = range(19)
+ OPT_PLACEMENT_CANDIDATES) = range(18)
 KERNEL_RAYTRACE, KERNEL_CHEMISTRY, KERNEL_PREP, KERNEL_FINISH = range(4)
 VARIANT_PAIRED, VARIANT_ALIGNED, VARIANT_BUFFER_ATOMICS, VARIANT_SPLIT_DESCRIPTORS, VARIANT_SKIP_ZERO, VARIANT_GLOBAL_SHELLS = 1, 2, 4, 8, 16, 32
 

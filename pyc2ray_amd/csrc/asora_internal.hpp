@@ -266,7 +266,7 @@ struct State {
     struct PendingTimer { int which; hipEvent_t e0, e1; };
     std::vector<PendingTimer> pending_timers;     // recorded, not yet resolved
     std::vector<hipEvent_t> free_events;
-    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0};
+    int opt[ASORA_OPT_COUNT] = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0};
     double k_ms[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
     long k_n[ASORA_KERNEL_COUNT] = {0, 0, 0, 0};
 };

@@ -217,6 +217,10 @@ extern "C" __device__ double asora_buffer_atomic_fadd_f64(double, __amdgpu_buffe
 #define ASORA_PAIR_MIN_WAVES 1
 #endif
 
+// (round 6: the thick and thin rate table in LDS -- NumTau <= 2048, 2 x 16 KB, lookups as ds_read2_b64 gathers -- was measured on
+//  twelve sector pairs with two workgroups per CU and is 11-14 % SLOWER than the global-memory lookups on the quiet medium and on an
+//  evolving field alike: the LDS pipe is already a third to a half busy with corner reads, the logarithm table and the wrapped
+//  coordinates, and 8 more divergent 16-byte gathers per wave-step tip it over.  LABNOTES round 6, profiles/r06_ab_lds_tables.txt)
 // (round 4: non-temporal loads for the table-entry and nHI streams were measured and are slower -- the workgroups of a CU and of an
 //  XCD share those lines through the L1 and L2: LABNOTES.md)
 // (the flag bits of a table entry, CELL_*: asora_internal.hpp)
@@ -254,19 +258,14 @@ extern "C" __device__ double asora_buffer_atomic_fadd_f64(double, __amdgpu_buffe
 // split descriptors: does this unit's face write the [k][j][i] twin?  (the z-sector with the twins in use)
 __device__ __forceinline__ bool ztr_desc(const RtParams &p, int uinfo) { return p.z_transposed != 0 && ((uinfo >> 8) & 3) == 3; }
 
-// LDSTAB (round 6, ASORA_OPT_LDS_TABLES): the thick and the thin rate table are copied into LDS when the workgroup starts
-// (NumTau <= 2048: the reference's production parameter files use 2000, ref: test/paper_eor_simulation/parameters.yml:75 -- 2 x 16 KB)
-// and the four lookups of a cell are LDS gathers (ds_read2_b64) instead of divergent 16-byte global loads that queue in front of the
-// nHI loads and the rate atomics in the in-order vector-memory pipeline.  Same table entries, same arithmetic: same bits.
 template <int RT_THREADS, bool GLOBAL_SCRATCH, bool DUMP, bool HEAT, int TABCAP, bool SKIP_ZERO = false, bool GREY = false,
-          bool BUFATOM = false, int NSRC = 1, bool SUBBOX = false, bool SPLIT = false, bool LDSTAB = false>
+          bool BUFATOM = false, int NSRC = 1, bool SUBBOX = false, bool SPLIT = false>
 __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? ASORA_PAIR_MIN_WAVES : ASORA_MIN_WAVES) : 1)) raytrace_octant_kernel(const RtParams p)
 {
     extern __shared__ double lds_raw[];
     static_assert(NSRC == 1 || (ASORA_LATE_LOOKUP && !GLOBAL_SCRATCH && !DUMP && BUFATOM), "paired sources: production variant only");
     static_assert(!SUBBOX || (ASORA_LATE_LOOKUP && !GLOBAL_SCRATCH && !DUMP && !SKIP_ZERO && !GREY), "sub-box sweep: table rates, shells in LDS");
     static_assert(!SPLIT || (BUFATOM && !SUBBOX && !HEAT && !GREY && !DUMP), "descriptors per layout: the production forms for 512 < N <= 645");
-    static_assert(!LDSTAB || (ASORA_LATE_LOOKUP && BUFATOM && !GLOBAL_SCRATCH && !SUBBOX && !HEAT && !GREY && !DUMP), "rate tables in LDS: the production forms");
 
     if (p.done_flag && *p.done_flag) return;   // evolve loop: an iteration enqueued beyond convergence does nothing
     const int blk = blockIdx.x;
@@ -340,10 +339,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     double *inv_s = reinterpret_cast<double *>(logtab + LOG_TABLE_SIZE);
     // per source, per axis: wrapped position of offset t on the unit's side [0, TABCAP) and on the mirrored side [TABCAP, 2 TABCAP)
     int *wtab = reinterpret_cast<int *>(inv_s + TABCAP);
-    // LDSTAB: [thick table: table_len + 1 doubles][thin table: the same], as the device allocation holds them, then the shell buffers
-    double *ldstab = reinterpret_cast<double *>(wtab + NSRC * 6 * TABCAP);
-    const int ldstab_doubles = LDSTAB ? ((2 * table_stride(p.table_len) + 1) & ~1) : 0;
-    double *shells = ldstab + ldstab_doubles;
+    double *shells = reinterpret_cast<double *>(wtab + NSRC * 6 * TABCAP);
     const int slots = (p.max_cells + 2) & ~1;      // cells + the zero slot, even (keeps 16-B alignment)
     // source q's two shell buffers follow source q-1's: prev/cur of source q = prev/cur + q * 2 * slots
     double *prev, *cur;
@@ -357,10 +353,6 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     const int src_stride = 2 * slots;
 
     for (int t = threadIdx.x; t < LOG_TABLE_SIZE; t += RT_THREADS) logtab[t] = p.logtab[t];
-    if (LDSTAB) {
-        const double *__restrict__ src = reinterpret_cast<const double *>(p.tables);
-        for (int t = threadIdx.x; t < 2 * table_stride(p.table_len); t += RT_THREADS) ldstab[t] = src[t];
-    }
     for (int t = threadIdx.x; t <= p.S; t += RT_THREADS) {
         inv_s[t] = 1.0 / (double)max(t, 1);
 #pragma unroll
@@ -656,7 +648,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
             // (lanes without a rate run the lookups on whatever they hold: the index is clamped for any input)
             // TAU_PHOTO_LIMIT: rates.cu:7 (double 1e-7) or photorates.f90:69 (single 1e-7 promoted)
             const double limit = p.fortran_consts ? (double)1.0e-7f : 1.0e-7;
-            const double2 *tab = LDSTAB ? reinterpret_cast<const double2 *>(ldstab) : p.tables;
+            const double2 *tab = p.tables;
             bool thick[NSRC];
             double dtau[NSRC], arg_A[NSRC], arg_B[NSRC], tau_at_entry[NSRC];
             int toff[NSRC];
@@ -736,7 +728,7 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
                         B2[q] = lookup_issue<HEAT>(tab, arg_B[q], p, logtab, SUBBOX ? 0 : toff[q]);
                     }
                 }
-                else if (BUFATOM && SKIP_ZERO && !LDSTAB) {       // (LDSTAB: the lookups are no vector-memory operations, nothing to even out)
+                else if (BUFATOM && SKIP_ZERO) {
 #pragma unroll
                     for (int q = 0; q < NSRC; ++q) {     // (distinct addresses, or the loads would be merged)
                         const double2 *__restrict__ dummy = tab + (threadIdx.x & 1) + 4 * q;
@@ -847,7 +839,6 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
         const double2 *__restrict__ prime = p.tables + (threadIdx.x & 1);
 #pragma unroll
         for (int q = 0; q < NSRC; ++q) {
-            if (LDSTAB) break;              // (the lookups of a step are LDS reads: no vector-memory loads to stand in for)
             // (distinct addresses, or the loads would be merged; a further source's come from the 128-entry log table)
             pend_A[q].t = q == 0 ? prime[0] : p.logtab[(threadIdx.x & 1) + 4 * q];
             if (HEAT) pend_A[q].h = prime[2 * p.table_len];
@@ -1036,31 +1027,22 @@ static bool buffer_atomics_fit(const State &st, const RtParams &p, int units, in
     return false;
 }
 
-// Rate tables in LDS: up to 2049 entries per table (NumTau <= 2048)
-constexpr int LDS_TABLES_MAX_LEN = 2049;
-// auto mode of ASORA_OPT_LDS_TABLES: where the A/B runs say it pays (see the record in LABNOTES round 6)
-static bool lds_tables_auto(const State &st, const RtParams &p)
-{
-    (void)st; (void)p;
-    return false;
-}
-
 constexpr size_t lds_table_bytes(int tabcap, int nsrc = 1) { return LOG_TABLE_SIZE * sizeof(double2) + (size_t)tabcap * (sizeof(double) + (size_t)nsrc * 6 * sizeof(int)); }
 
 // the paired-sources variant (NSRC = 2) exists for the production path only: table rates, no heating, no dump, shell
 // buffers in LDS, buffer atomics
-template <int T, int TABCAP, bool SPLIT = false, bool LT = false>
+template <int T, int TABCAP, bool SPLIT = false>
 static int launch_variant_pairs(State &st, const RtParams &q, unsigned grid, size_t lds_bytes, hipStream_t stream, bool skip_zero)
 {
     if (skip_zero) {
-        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, false, TABCAP, true, false, true, 2, false, SPLIT, LT>,
+        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, false, TABCAP, true, false, true, 2, false, SPLIT>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, false, TABCAP, true, false, true, 2, false, SPLIT, LT>), dim3(grid), dim3(T),
+        hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, false, TABCAP, true, false, true, 2, false, SPLIT>), dim3(grid), dim3(T),
                            lds_bytes, stream, q);
     } else {
-        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, false, TABCAP, false, false, true, 2, false, SPLIT, LT>,
+        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, false, TABCAP, false, false, true, 2, false, SPLIT>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, false, TABCAP, false, false, true, 2, false, SPLIT, LT>), dim3(grid), dim3(T),
+        hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, false, TABCAP, false, false, true, 2, false, SPLIT>), dim3(grid), dim3(T),
                            lds_bytes, stream, q);
     }
     ASORA_HIP_TRY(hipGetLastError());
@@ -1184,14 +1166,6 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
 {
     int units, threads;   // one workgroup per (source, octant) or per (source, octant, sector)
     pick_launch_shape(st, p.R, p.N, p.shape_src_count > 0 ? p.shape_src_count : p.src_count, dump, units, threads);
-    // Rate tables in LDS (the kernel's LDSTAB, ASORA_OPT_LDS_TABLES): both tables must fit beside the shell buffers -- 2 x (len + 1)
-    // doubles, 32.8 KB for the 2001 entries of NumTau = 2000.  Where the radius takes the six-sector units (two workgroups of 61 KB per
-    // CU), the twelve sector pairs take their place: half the shell buffers, so that two workgroups per CU remain with the tables.
-    const size_t lds_rate_table_bytes = (((size_t)2 * table_stride(p.table_len) + 1) & ~(size_t)1) * sizeof(double);
-    const int lds_tables_opt = st.opt[ASORA_OPT_LDS_TABLES];
-    const bool lds_tables_wanted = lds_tables_opt != 1 && !dump && !heat && !p.grey && p.table_len <= LDS_TABLES_MAX_LEN &&
-                                   (lds_tables_opt == 2 || lds_tables_auto(st, p));
-    if (lds_tables_wanted && units == 6 && st.opt[ASORA_OPT_SECTORS] == 0) units = 12;
     {   // number of shells, known before the tables are built: the 1024-entry LDS tables exist for 256/512 threads
         const double R2hi = p.R * p.R * (1.0 + 1e-9) + 1e-9;
         const int Emax = p.N / 2;
@@ -1263,10 +1237,6 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
         fixed_bytes = lds_table_bytes(pairs_tiny ? 32 : pairs_small ? 64 : 256, 2);
         shell_bytes *= 2;
     }
-    // ... built for the paired production forms of 256 threads (the shapes of r_RT = 25.5 ... 52.5) without split descriptors
-    const bool lds_tables = lds_tables_wanted && pairs && !split && use_lds && threads == 256 &&
-                            shell_bytes + fixed_bytes + lds_rate_table_bytes <= LDS_LIMIT_BYTES;
-    if (lds_tables) fixed_bytes += lds_rate_table_bytes;
     size_t lds_bytes = (use_lds ? shell_bytes : 0) + fixed_bytes;
 #ifdef ASORA_ENABLE_ABLATION        // diagnostic builds only: unused LDS per workgroup, to lower the occupancy (ASORA_DIAG_EXTRA_LDS bytes)
     if (const char *e = getenv("ASORA_DIAG_EXTRA_LDS")) lds_bytes = std::min<size_t>(LDS_LIMIT_BYTES, lds_bytes + (size_t)atol(e));
@@ -1345,8 +1315,7 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
         const unsigned grid = q.spread ? (unsigned)units * (unsigned)groups : 8u * (unsigned)units * (unsigned)((groups + 7) / 8);
         st.last_variant = (pairs ? ASORA_VARIANT_PAIRED : 0) | (aligned ? ASORA_VARIANT_ALIGNED : 0) |
                           ((bufatom_fits && use_lds && !dump) ? ASORA_VARIANT_BUFFER_ATOMICS : 0) | (split ? ASORA_VARIANT_SPLIT_DESCRIPTORS : 0) |
-                          (skip_zero ? ASORA_VARIANT_SKIP_ZERO : 0) | (use_lds ? 0 : ASORA_VARIANT_GLOBAL_SHELLS) |
-                          (lds_tables ? ASORA_VARIANT_LDS_TABLES : 0) | (units << 8) | (threads << 16);
+                          (skip_zero ? ASORA_VARIANT_SKIP_ZERO : 0) | (use_lds ? 0 : ASORA_VARIANT_GLOBAL_SHELLS) | (units << 8) | (threads << 16);
         {
             KernelTimer kt(ASORA_KERNEL_RAYTRACE, stream);
             int rc = 0;
@@ -1358,10 +1327,6 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
             } else if (split) {
                 rc = threads == 512 ? launch_variant_split<512>(st, q, grid, lds_bytes, stream, skip_zero)
                                     : launch_variant_split<256>(st, q, grid, lds_bytes, stream, skip_zero);
-            } else if (pairs && lds_tables) {
-                if (pairs_tiny)       rc = launch_variant_pairs<256, 32, false, true>(st, q, grid, lds_bytes, stream, skip_zero);
-                else if (pairs_small) rc = launch_variant_pairs<256, 64, false, true>(st, q, grid, lds_bytes, stream, skip_zero);
-                else                  rc = launch_variant_pairs<256, 256, false, true>(st, q, grid, lds_bytes, stream, skip_zero);
             } else if (pairs) {
                 if (pairs_tiny) rc = launch_variant_pairs<256, 32>(st, q, grid, lds_bytes, stream, skip_zero);
                 else if (pairs_small) {

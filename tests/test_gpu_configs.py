@@ -570,7 +570,7 @@ def test_c2ray_do_all_sources_256_uniform_1000_sources_against_reference_fortran
     # the column densities that come back are the LAST source's, over its whole +-32 cube (raytracing.f90:181,488): against
     # the reference Fortran's own coldensh_out of this call (tests/golden/make_fullsize_coldens_golden.py)
     assert np.count_nonzero(cd) == (2 * R + 1) ** 3 and np.isfinite(cd).all() and not heat.any()
-    _coldens_cube_against_fixture(cd, "u32", pos[:, -1], rtol=1e-9)
+    _coldens_cube_against_fixture(cd, "u32", pos[:, -1], rtol=1e-11)
 
 
 def _coldens_cube_against_fixture(cd, case, src, rtol, rated_only=False):
@@ -637,7 +637,7 @@ def test_column_density_at_full_size_against_reference_fortran(asora, bench_tabl
     nbox, loss = load_c2ray().raytracing.do_all_sources(flux[-8:], pos[:, -8:].astype(np.int32), R, R, cd, bench.SIG, dr, f(ndens), f(xh),
                                                         phi, heat, 0.0, thin, thick, zeros, zeros, bench.MINLOGTAU, dlog, float(R))
     assert nbox == 8
-    _coldens_cube_against_fixture(cd, case, pos[:, -1], rtol=1e-9)
+    _coldens_cube_against_fixture(cd, case, pos[:, -1], rtol=1e-11)
 
 
 # ---- configs[1] ---------------------------------------------------------------------------------------------------
