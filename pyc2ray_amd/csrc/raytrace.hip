@@ -967,6 +967,18 @@ static void pick_launch_shape(const State &st, double R, int N, int src_count, b
         else if (r < 36.5) { mu = 6; mt = 256; }
         else if (r < 52.5) { mu = 12; mt = 256; }
         if (mu && (long)src_count * mu >= 2L * st.cu_count && !dump) { units = mu; threads = mt; }
+        // Beyond N = 512 a buffer descriptor spans ONE layout of the rate grid (launch_raytrace, `split`), so the production forms --
+        // two sources per workgroup, buffer atomics -- need units whose rated cells all lie on one kind of face.  Where the radius
+        // would take the whole sphere or the half spheres (cells of every face in one workgroup: the global-atomic family, one
+        // source per workgroup), the three all-sign sectors take their place (round 6; the reference's meshes end at 645,
+        // ref: src/asora/raytracing.cu:95).  Measured at N = 576, 1000 sources (profiles/r06_ab_576_small_radii.txt): r_RT = 16
+        // 0.286 -> 0.241 ms, r_RT = 24 0.605 -> 0.589 ms; below the radius from which two sources share a workgroup (15.5) the
+        // whole sphere stays (r_RT = 12: 0.137 against 0.140 ms).
+        if ((units == 1 || units == 2) && units == mu && r >= 15.5 && N > 512 && N <= 645 && (long)src_count * 3 >= 2L * st.cu_count &&
+            !st.opt[ASORA_OPT_GLOBAL_ATOMICS] && st.opt[ASORA_OPT_Z_TRANSPOSED]) {
+            units = 3;
+            threads = r < 21.5 ? 256 : 512;
+        }
     }
     // Few sources (fewer workgroups than CUs): the time of the call is the time of ONE workgroup, so cut a source
     // into more (24 sectors) and wider pieces.  One source, 128^3, R = 64: 0.235 -> 0.146 ms (tools/sweep_single_source.sh)
