@@ -155,6 +155,14 @@ void build_unit_geometry(HostGeom &h, const UnitSpec &us, double R, double dr, i
             nb.y = (e0 && fm) ? corner(U, V - 1) : zero_slot_marker;
             nb.z = (em && f0) ? corner(U - 1, V) : zero_slot_marker;
             nb.w = (e0 && f0) ? corner(U, V) : zero_slot_marker;
+            // A transverse offset EQUAL to s (cube edges, the diagonal): the two corners at that offset do not exist in shell s-1 and
+            // carry weight 1 - s * (1/s), which is 0 for most s and 2^-53 for s = 49, 98, 103, 107, ... (230 values below 2048).  The
+            // reference multiplies such a speck with the column density of a real neighbour; pointed at the zero slot it would meet
+            // the value 0, i.e. a weight 1 / max(0.6, 0) instead of 1 / (c sigma), amplified by c sigma / 0.6 (round 6: 5e-9 at the
+            // corners of a +-64 cube in tau = 200 cells, found in the sub-box kernel).  So they ALIAS their existing neighbour at
+            // offset s - 1: same LDS word, a weight of 0 or 2^-53 on a real value.
+            if (!e0) { nb.y = nb.x; nb.w = nb.z; }
+            if (!f0) { nb.z = nb.x; nb.w = nb.y; }
             {   // every corner that carries weight must be part of this unit
                 const double fu = U == s ? 1.0 : u / sd, fv = V == s ? 1.0 : v / sd;
                 const double wts[4] = {fu * fv, fv * (1.0 - fu), fu * (1.0 - fv), (1.0 - fu) * (1.0 - fv)};

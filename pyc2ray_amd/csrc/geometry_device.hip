@@ -298,6 +298,9 @@ __global__ void __launch_bounds__(GB_THREADS) geometry_write_kernel(const TableJ
         nb.y = (e0c && fm) ? corner(U, V - 1) : MARK;
         nb.z = (em && f0c) ? corner(U - 1, V) : MARK;
         nb.w = (e0c && f0c) ? corner(U, V) : MARK;
+        // (a transverse offset equal to s: the corners at that offset alias their existing neighbour -- see build_unit_geometry)
+        if (!e0c) { nb.y = nb.x; nb.w = nb.z; }
+        if (!f0c) { nb.z = nb.x; nb.w = nb.y; }
         const double u = (double)U, v = (double)V;
         {   // every corner that carries weight must be part of this table
             const double fu = U == s ? 1.0 : u / sd, fv = V == s ? 1.0 : v / sd;

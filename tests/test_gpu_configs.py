@@ -458,14 +458,17 @@ def test_mesh_576_both_atomic_families_at_real_size(asora):
     np.testing.assert_allclose(acc, full, rtol=1e-11, atol=0)
     del acc, one, full
 
-    # many sources: the launch shapes of a full chip (whole spheres x 512 threads at this radius; one source per workgroup,
-    # dense tables) against the oracle on the host
+    # many sources: the launch shapes of a full chip against the oracle on the host -- at this radius the three all-sign sectors with
+    # two sources per workgroup and a buffer descriptor per layout (round 6; the whole sphere in one workgroup, which N <= 512 takes
+    # here, holds cells of every face and could only use global atomics) -- and the global-atomic family forced onto the same launch
     NM = 600
     mpos = 1 + rng.integers(0, N, size=(3, NM))
     mflux = rng.uniform(0.5e3, 2.0e3, size=NM)
     m0, mf0 = cases.flat_sources(mpos, mflux)
     lib.source_data_to_device(m0, mf0, NM)
     lib.raytrace_device(R, cases.SIG, dr, 0, NM, cases.MINLOGTAU, dlog, numtau)
+    v = lib.last_raytrace_variant()
+    assert v["units"] == 3 and v["paired"] and v["buffer_atomics"] and v["split_descriptors"], v
     many = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
     gam, ev = lib.last_raytrace_counts()
     assert gam == NM * _lattice_points_within(R)
@@ -474,7 +477,16 @@ def test_mesh_576_both_atomic_families_at_real_size(asora):
     w = ref != 0
     assert np.array_equal(many != 0, w)
     np.testing.assert_allclose(many[w], ref[w], rtol=1e-8, atol=0)
-    del many, ref, w
+    del ref
+    lib.set_option(capi.OPT_GLOBAL_ATOMICS, 1)              # the whole sphere x 512 threads, one source per workgroup
+    lib.raytrace_device(R, cases.SIG, dr, 0, NM, cases.MINLOGTAU, dlog, numtau)
+    v = lib.last_raytrace_variant()
+    lib.set_option(capi.OPT_GLOBAL_ATOMICS, 0)
+    assert v["units"] == 1 and not v["buffer_atomics"] and not v["paired"], v
+    glob = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
+    assert np.array_equal(glob != 0, w)
+    np.testing.assert_allclose(glob[w], many[w], rtol=1e-11, atol=0)
+    del many, glob, w
 
     # the production forms beyond N = 512 (round 5).  At r_RT = 30 a source is cut into six sectors, whose rated cells lie on one
     # face each, so the rate atomics of a workgroup go through a buffer descriptor over ONE layout of the grid (8 N^3 bytes

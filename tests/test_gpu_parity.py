@@ -1582,6 +1582,43 @@ def test_column_density_dump_of_cells_on_the_sphere_follows_dr(asora):
     p.device_close()
 
 
+def test_column_density_on_cube_edges_of_shells_whose_reciprocal_is_inexact(asora):
+    """A cell with a transverse offset EQUAL to its shell index s (cube edges, the diagonal) has two upstream corners that do
+    not exist in shell s-1; their bilinear weight is 1 - s * (1/s): 0 for most s, 2^-53 for s = 49, 98, 103, 107, ...  The
+    reference multiplies that speck with a real neighbour's column density.  Until round 6 the tables pointed such corners at
+    the zero slot, where the speck met the value 0 -- a weight 1 / max(0.6, 0) instead of 1 / (c sigma), amplified by
+    c sigma / 0.6: ~3e-12 of the column density behind shell 49 in cells of optical depth ~200 (the benchmark medium).  They
+    alias their existing neighbour now.  128^3, one source, a trace beyond the box (shells up to 64, cube edges of shell 49
+    at distance 69 inside it), the benchmark medium: column densities against the oracle at 5e-13 -- everywhere, and in
+    particular on and behind the edge cells of shell 49."""
+    import bench
+    p, lib, capi = asora
+    N, R = 128, 100.0
+    thin, thick, dlog = cases.soft_tables(400)
+    nd = np.full((N, N, N), 1e-3)
+    xh = np.full((N, N, N), 2e-4)
+    dr = 3 * 3.086e24 / 256                                  # tau = 227 per cell
+    pos = np.array([[64], [64], [64]])
+    flux = np.array([1.0])
+    p0, f0 = cases.flat_sources(pos, flux)
+    if p.cuda_is_init():
+        p.device_close()
+    p.device_init(N, 8)
+    p.photo_table_to_device(thin, thick)
+    lib.source_data_to_device(p0, f0, 1)
+    lib.grid_to_device(capi.GRID_NDENS, nd)
+    lib.grid_to_device(capi.GRID_XH_AV, xh)
+    cd = lib.debug_coldens(R, bench.SIG, dr, 0, N)
+    one = O.asora_do_all_sources(R, bench.SIG, dr, nd, xh, p0, f0, thin, thick, cases.MINLOGTAU, dlog, NumTau=thin.shape[0],
+                                 flags=O.ASORA_MODE, want_coldens=True)
+    w = cd != 0
+    assert w.sum() > 0.9 * N ** 3
+    np.testing.assert_allclose(cd[w], one["coldens"][w], rtol=5e-13, atol=0)
+    # the cells in question were part of the comparison: offsets (49, 49, t) and beyond, on the source's +++ side
+    assert w[63 + 49, 63 + 49, 63 + 10] and w[63 + 55, 63 + 55, 63 + 55] and not w[63 + 60, 63 + 60, 63 + 60]
+    p.device_close()
+
+
 def test_two_sources_per_workgroup_give_the_same_rates(asora):
     """ASORA_OPT_PAIR_SOURCES: one workgroup sweeps its unit for two consecutive sources at once.  Sources whose spheres do
     not overlap (no summation-order freedom) -> grids IDENTICAL to the one-source-per-workgroup kernel, for every
