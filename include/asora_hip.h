@@ -370,8 +370,8 @@ enum {
     /* How many allocations of the grid arena asora_device_init may try before it keeps the one on which a kernel with the fused
      * pass's stream mix runs fastest (api.hip choose_arena; set BEFORE device_init): 0 (default) = up to 8, 1 = take the first
      * allocation (memory-tight or shared-GPU runs), n = up to n (at most 32).  Whatever the value, what is held during the probe
-     * stays within an eighth of the free device memory, and the probe stops once it holds a placement 7 % faster than another
-     * or has seen four within 3 % of each other.  Same results on any placement. */
+     * stays within an eighth of the free device memory, and the probe stops once it holds a placement 7 % faster than another.
+     * Same results on any placement. */
     ASORA_OPT_PLACEMENT_CANDIDATES = 17,
     ASORA_OPT_COUNT = 18
 };

@@ -699,8 +699,9 @@ extern "C" {
 //   * at most ASORA_OPT_PLACEMENT_CANDIDATES allocations (0 = default 8; 1 = take the first; the environment variable
 //     ASORA_PLACEMENT_CANDIDATES does the same for a process that cannot call asora_set_option before device_init);
 //   * what is held during the probe stays within an EIGHTH of the free device memory (512^3: two candidates of 14 GiB);
-//   * it stops as soon as it holds a candidate 7 % faster than another (both kinds seen, one of the fast kind in hand), and after
-//     four candidates within 3 % of each other (a box of one kind: nothing to find).
+//   * it stops as soon as it holds a candidate 7 % faster than another (both kinds seen, one of the fast kind in hand); a box of one
+//     kind costs all eight (10 ms at 256^3: one placement in eight to one in three is of the fast kind where both occur, so fewer
+//     tries would miss it too often).
 // The losers are held until the probe ends: a freed arena's pages are what the next allocation of that size gets back, so
 // freeing as it goes would time the same placement again and again.  Meshes below 128^3 take the first allocation (their grids
 // sit in the caches).  asora_debug_placement reports what was tried and what the probe cost.
@@ -766,7 +767,6 @@ static int choose_arena(State &st, size_t slot, int slots)
         if (best < 0 || t < ms[(size_t)best]) best = c;
         worst = std::max(worst, t);
         if (c >= 1 && ms[(size_t)best] <= 0.93f * worst) break;     // both kinds seen, and one of the fast kind in hand
-        if (c >= 3 && ms[(size_t)best] >= 0.97f * worst) break;     // four of one kind: a box that has nothing else to offer
     }
     (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
     if (best < 0) return fail(2, "device_init: out of device memory for the grids");
