@@ -265,7 +265,8 @@ __global__ void __launch_bounds__(RT_THREADS, (RT_THREADS <= 512 ? (NSRC == 2 ? 
     extern __shared__ double lds_raw[];
     static_assert(NSRC == 1 || (ASORA_LATE_LOOKUP && !GLOBAL_SCRATCH && !DUMP && BUFATOM), "paired sources: production variant only");
     static_assert(!SUBBOX || (ASORA_LATE_LOOKUP && !GLOBAL_SCRATCH && !DUMP && !SKIP_ZERO && !GREY), "sub-box sweep: table rates, shells in LDS");
-    static_assert(!SPLIT || (BUFATOM && !SUBBOX && !HEAT && !GREY && !DUMP), "descriptors per layout: the production forms for 512 < N <= 645");
+    static_assert(!SPLIT || (BUFATOM && !SUBBOX && !DUMP && (NSRC == 1 || (!HEAT && !GREY)) && !(SKIP_ZERO && (HEAT || GREY))),
+                  "descriptors per layout: the production forms for 512 < N <= 645, and the single-source form with heating or grey opacity");
 
     if (p.done_flag && *p.done_flag) return;   // evolve loop: an iteration enqueued beyond convergence does nothing
     const int blk = blockIdx.x;
@@ -1027,8 +1028,9 @@ static bool pair_sources_pays(const State &st, double R, int N, int src_count, i
 // Can the rate atomics go through buffer descriptors (the kernel's BUFATOM)?  One descriptor over both layouts of the rate
 // grid while the pair fits 2 GiB (N <= 512); one per layout (split) up to 2 GiB per layout (N <= 645) for units whose rated
 // cells all lie on one face -- the sector kinds.
-// The split form is built for the shapes such meshes take at ordinary radii: 256 or 512 threads, up to 256 shells, table rates
-// without heating (everything else beyond N = 512 keeps the global-atomic family).
+// The split form is built for the shapes such meshes take at ordinary radii: 256 or 512 threads, up to 256 shells; two sources
+// per workgroup for table rates without heating, one source per workgroup also with heating or grey opacity (everything else
+// beyond N = 512 -- column-density dump, more than 256 shells, whole spheres below r = 15.5 -- keeps the global-atomic family).
 static bool buffer_atomics_fit(const State &st, const RtParams &p, int units, int threads, bool plain_tables, bool &split)
 {
     split = false;
@@ -1061,19 +1063,21 @@ static int launch_variant_pairs(State &st, const RtParams &q, unsigned grid, siz
     return 0;
 }
 
-// single source, table rates, buffer descriptors per layout (512 < N <= 645): the plain and the zero-skipping form
+// single source, buffer descriptors per layout (512 < N <= 645): table rates (plain and zero-skipping form), with heating, grey opacity
 template <int T>
-static int launch_variant_split(State &st, const RtParams &q, unsigned grid, size_t lds_bytes, hipStream_t stream, bool skip_zero)
+static int launch_variant_split(State &st, const RtParams &q, unsigned grid, size_t lds_bytes, hipStream_t stream, bool skip_zero, bool heat)
 {
-    if (skip_zero) {
-        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, false, 256, true, false, true, 1, false, true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, false, 256, true, false, true, 1, false, true>), dim3(grid), dim3(T), lds_bytes, stream, q);
-    } else {
-        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, false, 256, false, false, true, 1, false, true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, false, 256, false, false, true, 1, false, true>), dim3(grid), dim3(T), lds_bytes, stream, q);
-    }
+#define ASORA_LAUNCH_SPLIT(HT, SZ, GR)                                                                                                 \
+    do {                                                                                                                           \
+        ASORA_HIP_TRY(hipFuncSetAttribute((const void *)raytrace_octant_kernel<T, false, false, HT, 256, SZ, GR, true, 1, false, true>, \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                            \
+        hipLaunchKernelGGL((raytrace_octant_kernel<T, false, false, HT, 256, SZ, GR, true, 1, false, true>), dim3(grid), dim3(T), lds_bytes, stream, q); \
+    } while (0)
+    if (q.grey)         ASORA_LAUNCH_SPLIT(false, false, true);
+    else if (heat)      ASORA_LAUNCH_SPLIT(true, false, false);
+    else if (skip_zero) ASORA_LAUNCH_SPLIT(false, true, false);
+    else                ASORA_LAUNCH_SPLIT(false, false, false);
+#undef ASORA_LAUNCH_SPLIT
     ASORA_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1228,7 +1232,8 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
     size_t shell_bytes = 2 * slots * sizeof(double);
     const bool use_lds = shell_bytes + fixed_bytes <= LDS_LIMIT_BYTES;
     bool split = false;
-    const bool bufatom_fits = buffer_atomics_fit(st, p, units, threads, use_lds && !dump && !heat && !p.grey && !big_tables, split);
+    // (beyond N = 512: per-layout descriptors also for the single-source form with heating or grey opacity, round 6)
+    const bool bufatom_fits = buffer_atomics_fit(st, p, units, threads, use_lds && !dump && !big_tables, split);
     p.split_desc = split ? 1 : 0;
     // Two sources per workgroup (see the kernel's NSRC): the variant exists for table rates without heating, column-density
     // dump or exact-zero skipping, with the shell buffers in LDS and the rates through buffer atomics, for 64..512 threads
@@ -1337,8 +1342,8 @@ int launch_raytrace(State &st, RtParams &p, bool dump, bool heat, hipStream_t si
                 else if (threads == 512) rc = launch_variant_pairs<512, 256, true>(st, q, grid, lds_bytes, stream, skip_zero);
                 else                     rc = launch_variant_pairs<256, 256, true>(st, q, grid, lds_bytes, stream, skip_zero);
             } else if (split) {
-                rc = threads == 512 ? launch_variant_split<512>(st, q, grid, lds_bytes, stream, skip_zero)
-                                    : launch_variant_split<256>(st, q, grid, lds_bytes, stream, skip_zero);
+                rc = threads == 512 ? launch_variant_split<512>(st, q, grid, lds_bytes, stream, skip_zero, heat)
+                                    : launch_variant_split<256>(st, q, grid, lds_bytes, stream, skip_zero, heat);
             } else if (pairs) {
                 if (pairs_tiny) rc = launch_variant_pairs<256, 32>(st, q, grid, lds_bytes, stream, skip_zero);
                 else if (pairs_small) {

@@ -486,7 +486,30 @@ def test_mesh_576_both_atomic_families_at_real_size(asora):
     glob = lib.grid_to_host(capi.GRID_PHI_ION, np.empty((N, N, N)))
     assert np.array_equal(glob != 0, w)
     np.testing.assert_allclose(glob[w], many[w], rtol=1e-11, atol=0)
-    del many, glob, w
+    del many, glob
+
+    # heating and grey opacity beyond N = 512 (round 6): one source per workgroup, a buffer descriptor per layout of the rate grid AND
+    # of the heating grid -- the same arithmetic as the global-atomic family (parity of both with the oracle: tests/test_gpu_parity.py),
+    # so the two must agree to the order of the additions
+    lib.heat_table_to_device(2e-11 * thin * np.linspace(1.0, 3.0, thin.shape[0]), 1e-11 * thick, thin.shape[0])
+    for opt, grids in ((capi.OPT_HEATING, (capi.GRID_PHI_ION, capi.GRID_PHI_HEAT)), (capi.OPT_GREY_NOTABLES, (capi.GRID_PHI_ION,))):
+        res = {}
+        for glob_atomics in (0, 1):
+            lib.set_option(opt, 1)
+            lib.set_option(capi.OPT_GLOBAL_ATOMICS, glob_atomics)
+            try:
+                lib.raytrace_device(R, cases.SIG, dr, 0, NM, cases.MINLOGTAU, dlog, numtau)
+                v = lib.last_raytrace_variant()
+                res[glob_atomics] = [lib.grid_to_host(g, np.empty((N, N, N))) for g in grids]
+            finally:
+                lib.set_option(opt, 0)
+                lib.set_option(capi.OPT_GLOBAL_ATOMICS, 0)
+            assert v["buffer_atomics"] == (not glob_atomics) and v["split_descriptors"] == (not glob_atomics) and not v["paired"], (opt, v)
+        for a, b in zip(res[0], res[1]):
+            assert np.array_equal(a != 0, w) and np.array_equal(b != 0, w)
+            np.testing.assert_allclose(a[w], b[w], rtol=1e-11, atol=0)
+        del res
+    del w
 
     # the production forms beyond N = 512 (round 5).  At r_RT = 30 a source is cut into six sectors, whose rated cells lie on one
     # face each, so the rate atomics of a workgroup go through a buffer descriptor over ONE layout of the grid (8 N^3 bytes

@@ -17,7 +17,7 @@ timeout -k 10 400 python bench.py --steps 10 --warmup 3 --workload cosmo --cpu-s
 timeout -k 10 600 python bench.py --N 512 --nsrc 100000 --workload cosmo --steps 3 --warmup 1 --repeats 3 --cpu-sources 0 > $O/bench_cfg4_512_1e5.json 2> $O/cfg4.err; echo "cfg4 exit $?"
 timeout -k 10 300 python bench.py --N 576 --steps 10 --warmup 3 --repeats 3 --cpu-sources 0 --evolving-state 0 > $O/bench_576.json 2> $O/bench_576.err
 timeout -k 10 300 python bench.py --N 576 --R 16 --steps 10 --warmup 3 --repeats 3 --cpu-sources 0 --evolving-state 0 > $O/bench_576_R16.json 2> $O/bench_576_R16.err
-tools/ab_options.sh 2 "--steps 20 --warmup 5" base u12=5=3 > $O/ab_twelve_sector_pairs.txt 2>&1
+tools/ab_options.sh 2 "--steps 20 --warmup 5" "base|||" "u12||--sectors 3|" > $O/ab_twelve_sector_pairs.txt 2>&1
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --repeats 2 --cpu-sources 0 --evolving-state 0 > $O/stats.log 2>&1; echo "stats exit $?"
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv; rm -rf $O/stats
