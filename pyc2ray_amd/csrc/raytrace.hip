@@ -254,6 +254,7 @@ extern "C" __device__ double asora_buffer_atomic_fadd_f64(double, __amdgpu_buffe
 //   single source, global atomics  same (N > 512, option, shells in global memory) f/t  f    f/t  f (t: GS=f) f/t f       1    f        launch_variant
 //   column-density dump            256 x {256,1024}                                f/t  t    f    f         f/t  f       1    f        launch_variant
 //   sub-box sweep                  {256,512} x 256                                 f    f    f/t  f         f    t       1|2  t        launch_subbox_tables_variant
+//   descriptors per layout (SPLIT) paired {256x32, 256x64, 256x256, 512x256}; single {256,512}x256            f    f    f/t  f/t       f/t  t       1|2  f        launch_variant_pairs / _split
 //   (SKIP_ZERO with HEAT or GREY, NSRC = 2 with HEAT, DUMP, GREY or global atomics, SUBBOX with NSRC = 2 and HEAT: not built)
 // split descriptors: does this unit's face write the [k][j][i] twin?  (the z-sector with the twins in use)
 __device__ __forceinline__ bool ztr_desc(const RtParams &p, int uinfo) { return p.z_transposed != 0 && ((uinfo >> 8) & 3) == 3; }
