@@ -205,3 +205,92 @@ def test_bench_trip_counts_equal_the_oracles_do_chemistry():
                                    bench.ABU_C)[2] for q in range(n)])
     assert np.array_equal(mine, ref)
     assert ref.max() >= 3 and ref.min() == 1
+
+
+# ---- round 6: host logic of the multi-rank batches and of the device-resident C2Ray grids (no GPU) ----------------------------
+def test_next_batch_follows_the_distance_to_the_convergence_test():
+    """evolve._next_batch: a multi-rank iteration's collectives are not gated by the device's `done` flag, so the batch shrinks as
+    the test of evolve.py:232 comes within reach -- computed from the rows every rank polled, hence the same on every rank."""
+    from pyc2ray_amd.evolve import _next_batch
+    assert _next_batch([], 1, 3.0, 1e-4) == 1                       # gloo: always one
+    assert _next_batch([], 8, 3.0, 1e-4) == 2                       # nothing to extrapolate from yet
+    assert _next_batch([(1e5, 0, 0, 1.0, 1.0)], 8, 3.0, 1e-4) == 2
+    # both criteria decay by 5 per iteration: rel 2e-2 -> 1e-4 needs ceil(log(200)/log(5)) = 4 more
+    h = [(1e5, 0, 0, 1e-1, 1e-2), (2e4, 0, 0, 2e-2, 2e-3)]
+    assert _next_batch(h, 8, 3.0, 1e-4) == 4
+    assert _next_batch(h, 2, 3.0, 1e-4) == 2                        # never beyond the cap
+    # the count criterion gets there first: 2e4 -> below 5e3 in one step of 5
+    assert _next_batch(h, 8, 5e3, 1e-4) == 1
+    # not decaying (or growing): no extrapolation, the full batch
+    assert _next_batch([(10, 0, 0, 1e-2, 1e-3), (10, 0, 0, 2e-2, 2e-3)], 8, 3.0, 1e-4) == 8
+    # conv_criterion = 0 (one source): only the relative changes count
+    assert _next_batch(h, 8, 0, 1e-4) == 4
+    # every simulated run ends without an iteration wasted once the decay is steady
+    rows, rel, flag, wasted = [], 20.0, 3000.0, 0
+    while True:
+        b = _next_batch(rows, 8, 1.3, 1e-4)
+        done_at = None
+        for q in range(b):
+            rows.append((flag, 0, 0, rel, 0.1 * rel))
+            if done_at is None and (flag < 1.3 or rel < 1e-4):
+                done_at = q
+            rel *= 0.2
+            flag *= 0.4
+        if done_at is not None:
+            wasted = b - 1 - done_at
+            break
+    assert wasted == 0 and len(rows) < 20
+
+
+def test_comm_backend_of_foreign_communicators():
+    from pyc2ray_amd.evolve import _comm_backend
+
+    class WithProperty:
+        backend = "nccl"
+
+    class WithMethodOnly:
+        def _backend(self):
+            return "gloo"
+
+    class Mpi4pyLike:
+        pass
+
+    assert _comm_backend(WithProperty()) == "nccl" and _comm_backend(WithMethodOnly()) == "gloo" and _comm_backend(Mpi4pyLike()) == "gloo"
+
+
+def test_residency_registry_reclaims_every_other_holder():
+    """pyc2ray_amd/_residency.py: whoever is about to overwrite the device grids first lets resident holders take their data home."""
+    from pyc2ray_amd import _residency
+
+    class Holder:
+        def __init__(self):
+            self.left = 0
+
+        def _leave_device(self):
+            self.left += 1
+
+    a, b = Holder(), Holder()
+    _residency.register(a)
+    _residency.register(b)
+    _residency.reclaim(except_for=a)
+    assert (a.left, b.left) == (0, 1)
+    _residency.reclaim()
+    assert (a.left, b.left) == (1, 2)
+    del b                                   # (weak references: a holder that is gone is not kept alive)
+    import gc
+    gc.collect()
+    _residency.reclaim()
+    assert a.left == 2
+
+
+def test_grid_fingerprint_sees_rescalings_and_respects_storage_order():
+    from pyc2ray_amd.c2ray_base import C2Ray
+    g = np.asfortranarray(np.random.default_rng(0).random((48, 48, 48)))
+    f0 = C2Ray._fingerprint(g)
+    assert f0.base is None and f0.shape[0] >= min(C2Ray._FINGERPRINT_SAMPLES, g.size) // 2       # a copy, not a view
+    assert np.array_equal(C2Ray._fingerprint(g), f0)
+    g *= 3.0                                # what cosmo_evolve / a script does in place
+    assert not np.array_equal(C2Ray._fingerprint(g), f0)
+    c = np.ascontiguousarray(g)
+    assert C2Ray._fingerprint(c).shape == C2Ray._fingerprint(g).shape
+    assert C2Ray.device_resident is True
