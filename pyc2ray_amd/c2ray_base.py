@@ -154,12 +154,12 @@ class C2Ray:
     #: 15.9 ms per time step, profiles/r05_time_steps_resident.json).  xh and phi_ion behave as in the reference: every step
     #: binds a FRESH array (c2ray_base.py:205-226), an array kept from an earlier step keeps that step's values.  ndens and temp
     #: are the caller's arrays; writing into one through a reference kept from BEFORE the last step, without touching the
-    #: attribute again (``n = sim.ndens`` ... evolve3D ... ``n *= 2``), is caught by a fingerprint of 65 536 samples of the host
-    #: array taken at upload time (any rescaling or whole-grid update changes it; an edit of a few cells may not: assign or read
+    #: attribute again (``n = sim.ndens`` ... evolve3D ... ``n *= 2``), is caught by a fingerprint of 16 384 samples of the host
+    #: array taken at upload time (0.1 ms per grid and step at 256^3; any rescaling or whole-grid update changes it, an edit of a few cells may not: assign or read
     #: the attribute after such an edit, as ``sim.ndens[...] = v`` does by itself): the grid is uploaded again -- or, if the
     #: device copy has meanwhile been diluted by cosmo_evolve, so that the write went into stale values, a RuntimeError says so.
     device_resident = True
-    _FINGERPRINT_SAMPLES = 65536
+    _FINGERPRINT_SAMPLES = 16384
 
     ndens = _DeviceGrid("ndens", _capi.GRID_NDENS)
     temp = _DeviceGrid("temp", _capi.GRID_TEMP)
