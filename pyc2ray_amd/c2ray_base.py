@@ -150,8 +150,8 @@ class C2Ray:
     #: and downloads everything): ndens, temp, xh and phi_ion stay on the device between time steps.  evolve3D then uploads only
     #: the grids that were assigned or READ on the host since the last step (a read hands out the array, which may be written
     #: into), and downloads xh / phi_ion only when they are read; cosmo_evolve dilutes a density that lives on the device ON the
-    #: device.  At 256^3 the five 128 MiB transfers of a time step cost as much as the step's outer iterations (32.8 against
-    #: 15.9 ms per time step, profiles/r05_time_steps_resident.json).  xh and phi_ion behave as in the reference: every step
+    #: device.  At 256^3 the five 128 MiB transfers of a time step cost as much as the step's outer iterations (33.2 against
+    #: 17.4 ms per time step, profiles/r06_time_steps_resident.json).  xh and phi_ion behave as in the reference: every step
     #: binds a FRESH array (c2ray_base.py:205-226), an array kept from an earlier step keeps that step's values.  ndens and temp
     #: are the caller's arrays; writing into one through a reference kept from BEFORE the last step, without touching the
     #: attribute again (``n = sim.ndens`` ... evolve3D ... ``n *= 2``), is caught by a fingerprint of 16 384 samples of the host
